@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by importing the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference; never on the GPU box).  The reference's
+CUDA-only natives are replaced by stubs that call oracle/native_ref.c (the kernel-text restatement);
+everything else -- RAFT-small, the ZSM/DCN-LSTM encoder, SIREN MLPs, reliability maps, nearest
+gather, post-splat normalisation, the time-chunking shell -- is the reference's own Python running on
+torch CPU.  Recipe: SURVEY.md §8(c).
+
+  python tests/golden/make_golden.py            # writes *.npz + state_dict_keys.json here
+
+Fixtures are DATA only (seeded inputs + reference outputs); no reference source is stored.
+"""
+import json
+import os
+import sys
+import types
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import native  # noqa: E402
+from oracle.motif_ref import MotifRef  # noqa: E402
+from motif_amd.utils.synth_weights import fill_state_dict, synth_tensor  # noqa: E402
+from motif_amd.data.synthetic import synthetic_sample, smooth_video  # noqa: E402
+
+
+# ----------------------------------------------------------------------------------------- stubs
+def install_stubs():
+    cupy = types.ModuleType("cupy")
+    cupy.memoize = lambda **kw: (lambda f: f)
+    cupy.RawModule = object
+    cupy.int32 = int
+    cupy.ndarray = type("ndarray", (), {})
+    sys.modules["cupy"] = cupy
+
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvu = types.ModuleType("torchvision.utils")
+    for n in ("Resize", "Compose", "ToTensor", "Normalize"):
+        setattr(tvt, n, lambda *a, **k: None)
+    tvu.make_grid = lambda *a, **k: None
+    tv.transforms, tv.utils = tvt, tvu
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.utils": tvu})
+    for name in ("cv2", "lmdb"):
+        sys.modules[name] = types.ModuleType(name)
+
+    ext = types.ModuleType("_ext")
+    ext.dcn_v2_forward = lambda inp, w, b, off, m, kh, kw, sh, sw, ph, pw, dh, dw, dg: native.dcn_v2_forward(
+        inp, w, b, off, m, kh, kw, sh, sw, ph, pw, dh, dw, dg)
+    sys.modules["_ext"] = ext
+    acc = types.ModuleType("alt_cuda_corr")
+    acc.forward = lambda f1, f2, coords, r: native.alt_corr(f1, f2, coords, r)
+    sys.modules["alt_cuda_corr"] = acc
+
+    # device shims (Ours.py:443,621,677; convlstm.py:62-63; correlation.py:7-8; PWCNet.py:161)
+    torch.cuda.FloatTensor = lambda data, device=None: torch.tensor(data, dtype=torch.float32)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.cuda.current_stream = lambda *a, **k: types.SimpleNamespace(cuda_stream=0)
+
+
+def ref_raft_ckpt(path, *a, **k):
+    """Stand-in for the hard-coded RAFT checkpoint load at Ours.py:424-430."""
+    from models.core.raft import RAFT
+    import argparse
+    args = argparse.Namespace(small=True, mixed_precision=False, alternate_corr=True)
+    sd = RAFT(args).state_dict()
+    return {"model": {"flow_predictor." + kk: synth_tensor("flow_predictor." + kk, v) for kk, v in sd.items()}}
+
+
+def build_reference():
+    install_stubs()
+    sys.path.insert(0, REF)
+    real_load = torch.load
+    torch.load = lambda p, *a, **k: ref_raft_ckpt(p) if "raft_smooth" in str(p) else real_load(p, *a, **k)
+    import models.modules.Ours as Ours
+    import models.softsplat_cp as sp
+    import models.softsplat_max_cp as spm
+    import models.softsplat_count_cp as spc
+    sp._FunctionSoftsplat.apply = staticmethod(lambda i, f: native.splat(i, f, "sum"))
+    spm._FunctionSoftsplat.apply = staticmethod(lambda i, f: native.splat(i, f, "max"))
+    spc._FunctionSoftsplat.apply = staticmethod(lambda i, f: native.splat(i, f, "count"))
+    net = Ours.LunaTokis(setting=5)
+    fill_state_dict(net)
+    net.eval()
+    return net, Ours
+
+
+# -------------------------------------------------------------------------------------- fixtures
+def digest(t):
+    t = t.detach().double().reshape(-1)
+    return np.array([t.sum().item(), t.abs().sum().item(), float(t.numel())])
+
+
+def sample_idx(numel, key, n=4096):
+    rng = np.random.RandomState(zlib.crc32(key.encode()))
+    return np.sort(rng.choice(numel, size=min(n, numel), replace=False)).astype(np.int64)
+
+
+def pack(store, key, t, limit=300_000):
+    """Full tensor if small, else a seeded subsample; always a float64 digest."""
+    t = t.detach().float().contiguous()
+    store[key + "__digest"] = digest(t)
+    store[key + "__shape"] = np.array(t.shape, dtype=np.int64)
+    if t.numel() <= limit:
+        store[key] = t.numpy()
+    else:
+        idx = sample_idx(t.numel(), key)
+        store[key + "__idx"] = idx
+        store[key + "__vals"] = t.reshape(-1)[idx].numpy()
+
+
+def run_case(net, name, h, w, scale, n_times, batch=1, seed=0, n_frames=4, pad_to=None):
+    sample = synthetic_sample(h, w, scale, n_times, n_frames=n_frames, batch=batch, seed=seed)
+    stages = {}
+    hooks = []
+
+    def hook(key, pick=lambda o: o):
+        def f(mod, inp, out):
+            o = pick(out)
+            stages.setdefault(key, []).append(o.detach().clone())
+        return f
+
+    hooks.append(net.flow_predictor.register_forward_hook(hook("raft_flow", lambda o: o[-1])))
+    hooks.append(net.encoder.register_forward_hook(hook("encoder")))
+    hooks.append(net.flow_process.register_forward_hook(hook("flow_process")))
+    hooks.append(net.flow_imnet.register_forward_hook(hook("flow_imnet")))
+    hooks.append(net.imnet.register_forward_hook(hook("imnet")))
+    hooks.append(net.fwarp.register_forward_hook(hook("fwarp", lambda o: o[0])))
+    hooks.append(net.fwarp.register_forward_hook(hook("fwarp_norm", lambda o: o[1])))
+    hooks.append(net.fwarp_max.register_forward_hook(hook("fwarp_max")))
+    hooks.append(net.fwarp_count.register_forward_hook(hook("fwarp_count")))
+    hooks.append(net.bwarp.register_forward_hook(hook("bwarp", lambda o: o[0])))
+    hooks.append(net.synth_net.register_forward_hook(
+        lambda m, i, o: stages.setdefault("synth_in", []).append(i[0].detach().clone())))
+    with torch.no_grad():
+        out, flow, flow_gt = net(sample["LQs"], None, sample["time"], sample["scale"], use_GT=False, iter=4)
+    for hk in hooks:
+        hk.remove()
+
+    # the oracle restatement on the same inputs, compared stage by stage
+    orc = fill_state_dict(MotifRef().eval())
+    ost = {}
+    with torch.no_grad():
+        o_out, o_flow, _ = orc(sample["LQs"], None, sample["time"], sample["scale"], use_GT=False, iter=4, stages=ost)
+    report = {}
+
+    def cmp(k, a, b):
+        report[k] = float((a.float() - b.float()).abs().max())
+
+    cmp("out", out, o_out)
+    cmp("flow", flow, o_flow)
+    for k in ("raft_flow", "encoder", "flow_process", "flow_imnet", "imnet", "fwarp", "fwarp_norm", "fwarp_max", "fwarp_count"):
+        cmp(k, stages[k][0], ost[k])
+    B = batch
+    Q = out.shape[-1] * out.shape[-2]
+    cmp("synth_in", stages["synth_in"][0], ost["synth_in"].reshape(B * n_times, -1, Q).permute(0, 2, 1))
+    print(name, "reference vs oracle restatement, max|diff| per stage:", json.dumps(report))
+
+    store = {"LQs": sample["LQs"].numpy(), "times": torch.stack(sample["time"], 0).numpy(),
+             "scale": np.array([sample["scale"][0][0], sample["scale"][1][0]], dtype=np.int64),
+             "iters": np.array(4), "torch_version": np.array(torch.__version__)}
+    pack(store, "out", out)
+    pack(store, "flow", flow)
+    for k in ("raft_flow", "encoder", "flow_process", "flow_imnet", "imnet", "fwarp", "fwarp_norm", "fwarp_max", "fwarp_count"):
+        pack(store, k, stages[k][0])
+    pack(store, "synth_in", stages["synth_in"][0].permute(0, 2, 1).reshape(B * n_times, -1, out.shape[-2], out.shape[-1]))
+    pack(store, "flow_lr", ost["flow_lr"])     # reference-internal tensors without a module hook:
+    pack(store, "psies", ost["psies"])         # taken from the restatement, which the report above
+    pack(store, "rel_coord", ost["rel_coord"])  # shows equal to the reference downstream
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **store)
+    return report
+
+
+def shell_case(net):
+    """Row H: VideoSRBaseModel.test time-chunking (VideoSR_base_model.py:169-200) driven on the
+    reference class with a stand-in `self`, T=7 timestamps -> chunks 3,3,1."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_vsr_src", os.path.join(REF, "models", "VideoSR_base_model.py"))
+    src = open(spec.origin).read()
+    # the module's imports pull every ablation model; only the `test` method body is needed
+    ns = {"torch": torch, "nn": torch.nn, "BaseModel": object, "logging": __import__("logging"),
+          "OrderedDict": dict, "np": np, "random": __import__("random")}
+    body = src[src.index("class VideoSRBaseModel"):]
+    exec(compile("import logging\nlogger = logging.getLogger('base')\n" + body, spec.origin, "exec"), ns)
+    cls = ns["VideoSRBaseModel"]
+    sample = synthetic_sample(32, 32, 4, 7, seed=3)
+    me = types.SimpleNamespace(netG=net, net_base="Ours", var_L=sample["LQs"], real_H=sample["GT"],
+                               times=sample["time"], scale=sample["scale"])
+    cls.test(me)
+    net.eval()
+    store = {"LQs": sample["LQs"].numpy(), "GT": sample["GT"].numpy(), "times": torch.stack(sample["time"], 0).numpy(),
+             "scale": np.array([sample["scale"][0][0], sample["scale"][1][0]], dtype=np.int64)}
+    pack(store, "fake_H", me.fake_H, limit=10_000_000)
+    np.savez_compressed(os.path.join(HERE, "shell_T7_lr32_s4.npz"), **store)
+    print("shell fake_H", tuple(me.fake_H.shape))
+
+
+def pwc_case():
+    """PWCNet (OpticalFlow/PWCNet.py) on a 96x128 pair with key-hashed weights."""
+    import OpticalFlow.correlation as corr
+    corr._FunctionCorrelation.apply = staticmethod(lambda a, b: native.corr81(a, b))
+    import OpticalFlow.PWCNet as P
+    net = P.PWCNet()
+    fill_state_dict(net)
+    net.eval()
+    frames = smooth_video(2, 96, 128, seed=5, shift=(2.1, -1.2))
+    with torch.no_grad():
+        flow = net(frames[:, 0], frames[:, 1])
+    store = {"first": frames[:, 0].numpy(), "second": frames[:, 1].numpy(), "torch_version": np.array(torch.__version__)}
+    pack(store, "flow", flow)
+    np.savez_compressed(os.path.join(HERE, "pwc_96x128.npz"), **store)
+    json.dump({k: list(v.shape) for k, v in net.state_dict().items()}, open(os.path.join(HERE, "pwc_state_dict_keys.json"), "w"), indent=0)
+    print("pwc flow", tuple(flow.shape), float(flow.abs().mean()))
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    net, Ours = build_reference()
+    json.dump({k: list(v.shape) for k, v in net.state_dict().items()},
+              open(os.path.join(HERE, "state_dict_keys.json"), "w"), indent=0)
+    reports = {}
+    reports["lr32_s4_n3"] = run_case(net, "lr32_s4_n3", 32, 32, 4, 3)
+    reports["lr64_s2_n3"] = run_case(net, "lr64_s2_n3", 64, 64, 2, 3, seed=1)        # BASELINE config 1
+    reports["lr32x48_s4_n2_b2"] = run_case(net, "lr32x48_s4_n2_b2", 32, 48, 4, 2, batch=2, seed=2)
+    shell_case(net)
+    pwc_case()
+    json.dump(reports, open(os.path.join(HERE, "restatement_vs_reference.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
