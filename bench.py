@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Benchmark of the MoTIF C-STVSR hot path on MI355X (contract: see the task's bench.py section).
+
+One step = one synthetic clip through feed_data -> test():  4-frame 180x320 LR -> 720x1280, x4 spatial,
+x6 temporal = 7 timestamps (BASELINE.json configs[1], "c2"), B = 1 clip per step per GPU, fp32.
+metric = HR pixels / second = T*B*HH*WW / wall, whole job over all ranks (clips shard embarrassingly:
+rank r renders its own clips, weak scaling; the only collective is the final gather of the uint8 frames).
+
+Extra objects on the JSON line:
+  roofline     dominant kernel = conv_igemm_kernel<2> (fp32 MFMA implicit GEMM): algorithmic FLOP of
+               its launches / their measured duration (events on the launch stream, one instrumented
+               clip after the timed region), vs the 157.3 TFLOP/s fp32-MFMA peak.
+  cpu_baseline the CPU oracle (oracle/, "port" of the reference) on a bounded crop of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--lr", type=int, nargs=2, default=[180, 320], help="LR height width")
+    ap.add_argument("--scale", type=int, default=4)
+    ap.add_argument("--times", type=int, default=7)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def conv_flops(desc_log):
+    return sum(2.0 * n * co * (ci // g) * kh * kw * ho * wo for (n, co, ci, g, kh, kw, ho, wo) in desc_log)
+
+
+def instrumented_clip(model, sample):
+    """Re-run one clip with event pairs around every conv-engine launch (same stream as the launches)."""
+    from motif_amd import ops
+    log, events = [], []
+    orig = ops.conv2d
+
+    def timed_conv(plan, x, x2=None, *a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(plan, x, x2, *a, **k)
+        e1.record()
+        co, cig, kh, kw = plan.weight.shape
+        events.append((e0, e1, co > 32 * plan.groups))
+        log.append((x.shape[0], co, cig * plan.groups, plan.groups, kh, kw, out.shape[2], out.shape[3]))
+        return out
+
+    ops.conv2d = timed_conv
+    try:
+        model.feed_data(sample)
+        model.test()
+        torch.cuda.synchronize()
+    finally:
+        ops.conv2d = orig
+    big = [(e0.elapsed_time(e1), l) for (e0, e1, is_nc2), l in zip(events, log) if is_nc2]
+    ms = sum(t for t, _ in big)
+    fl = conv_flops([l for _, l in big])
+    all_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
+    return dict(launches=len(big), ms=ms, flops=fl, all_conv_ms=all_ms, all_conv_flops=conv_flops(log), all_launches=len(log))
+
+
+def cpu_baseline(times):
+    """The CPU oracle on a bounded crop of the workload: LR 48x80 -> 192x320, same 7 timestamps, same
+    <=3-timestamp chunking with everything recomputed per chunk (the reference's schedule)."""
+    from oracle.motif_ref import MotifRef
+    from motif_amd.data.synthetic import synthetic_sample
+    from motif_amd.utils.synth_weights import fill_state_dict
+    h, w, s = 48, 80, 4
+    sample = synthetic_sample(h, w, s, times)
+    net = fill_state_dict(MotifRef().eval())
+    cores = torch.get_num_threads()
+    t0 = time.time()
+    with torch.no_grad():
+        for l in range(0, times, 3):
+            net(sample["LQs"], None, sample["time"][l:l + 3], sample["scale"], use_GT=False, iter=4)
+    dt = time.time() - t0
+    return {"value": times * h * s * w * s / dt, "unit": "HR px/s", "cores": cores, "kind": "port",
+            "sample": "oracle/motif_ref.py (CPU restatement, bit-identical to the reference on the goldens), one clip "
+                      "LR %dx%d -> %dx%d, %d timestamps in chunks of 3, %.1f s on %d torch threads" % (h, w, h * s, w * s, times, dt, cores)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU route")
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    from motif_amd import dist as mdist
+    from motif_amd.data.synthetic import synthetic_sample
+    from motif_amd.models import create_model
+    from motif_amd.option import default_opt
+    from motif_amd.utils.synth_weights import fill_state_dict
+
+    h, w = a.lr
+    model = create_model(default_opt(scale=a.scale, gpu_ids=[local]))
+    fill_state_dict(model.netG)
+    HH, WW = h * a.scale, w * a.scale
+    # two distinct clips per rank, resident in HBM before the timed region
+    clips = []
+    for i in range(2):
+        s = synthetic_sample(h, w, a.scale, a.times, seed=100 * rank + i)
+        s = {"LQs": s["LQs"].cuda(), "GT": s["GT"][:, :1].cuda(), "time": [t.cuda() for t in s["time"]], "scale": s["scale"]}
+        clips.append(s)
+
+    def step(i):
+        model.feed_data(clips[i % 2])
+        model.test()
+        if world > 1:
+            u8 = mdist.frames_to_uint8(model.fake_H.permute(1, 0, 2, 3, 4))       # [B,T,3,HH,WW] = this rank's clip
+            mdist.gather_to_rank0(u8, world)
+        return model.fake_H
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    px = a.times * 1 * HH * WW
+    line = {
+        "metric": "HR pixels/sec", "value": world * a.steps * px / dt, "unit": "px/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "c2: 4-frame %dx%d LR clip -> %dx%d (x%d spatial), x%dt = %d timestamps, B=1 clip per step per GPU, "
+                               "RAFT-small iters=4, seeded key-hashed weights" % (h, w, HH, WW, a.scale, a.times - 1, a.times),
+                   "parallelism": "clips sharded per GPU (dp%d), uint8 frame gather to rank 0" % world},
+    }
+    if rank == 0:
+        if not a.no_roofline:
+            r = instrumented_clip(model, clips[0])
+            ach = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
+            line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                                "kernel": "conv_igemm_kernel<2>", "launches_per_clip": r["launches"],
+                                "avg_launch_us": 1000.0 * r["ms"] / max(r["launches"], 1),
+                                "avg_launch_gflop": r["flops"] / max(r["launches"], 1) / 1e9,
+                                "all_conv_ms_per_clip": r["all_conv_ms"], "all_conv_tflop_per_clip": r["all_conv_flops"] / 1e12}
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.times)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

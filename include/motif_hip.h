@@ -1,0 +1,177 @@
+/*
+ * motif_hip.h -- C ABI of libmotif_hip.so, the MI355X (gfx950) device library behind the MoTIF
+ * C-STVSR inference hot path.  This is the drop-in boundary: every entry point
+ * replaces one native interface the reference binds today (cited per function, paths under
+ * /root/reference).  The reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions (SURVEY.md §8(b) "Native FFI"):
+ *   - extern "C", plain pointers and sizes; all tensors fp32, NCHW contiguous unless stated.
+ *   - every pointer is a DEVICE pointer; the caller (PyTorch) owns all memory incl. workspaces;
+ *     the library never allocates, frees or synchronises.
+ *   - `stream` is the hipStream_t to launch on (torch.cuda.current_stream().cuda_stream), the same
+ *     raw-pointer + stream contract the reference uses for cupy (models/softsplat_cp.py:240-249).
+ *   - return value: 0 = ok, <0 = argument error (MOTIF_E*), >0 = hipError_t of the failed launch.
+ *   - no host threads, no global mutable state; re-entrant across streams; one process per GPU.
+ */
+#ifndef MOTIF_HIP_H
+#define MOTIF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOTIF_OK 0
+#define MOTIF_EINVAL (-1)   /* bad size / null pointer */
+#define MOTIF_ELIMIT (-2)   /* shape outside what the kernel supports */
+
+/* activation codes for fused epilogues */
+#define MOTIF_ACT_NONE 0
+#define MOTIF_ACT_RELU 1
+#define MOTIF_ACT_LRELU 2   /* negative slope 0.1 */
+#define MOTIF_ACT_SIGMOID 3
+#define MOTIF_ACT_TANH 4
+
+int motif_abi_version(void);                 /* bumps when any signature below changes */
+int motif_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * A1-A3  fused soft-splat forward.
+ * Replaces the three cupy launches of kernel_Softsplat_updateOutput:
+ *   models/softsplat_cp.py:12-52,221-258 (sum of [feat*e^z, e^z], via FunctionSoftsplat :320-347),
+ *   models/softsplat_max_cp.py:12-58,254 (max of e^z*w, output initialised to 1),
+ *   models/softsplat_count_cp.py:14-52,163-165 (unweighted +1 per touched corner).
+ * Plain operator form (reference module surface): inputs NCHW, flow [N,2,H,W], metric z [N,1,H,W]
+ * (may be NULL -> only `cnt`/`mx` on `src`), outputs caller-initialised (sum/cnt: zeros, mx: ones),
+ * any output pointer may be NULL.  out_sum has C channels, out_norm 1 channel.
+ * ---------------------------------------------------------------------------------------------- */
+int motif_splat_fwd(const float* src, const float* flow, const float* z,
+                    float* out_sum, float* out_norm, float* out_max, float* out_cnt,
+                    int N, int C, int H, int W, void* stream);
+
+/* Fused MoTIF form (Ours.py:777-816): sources are never materialised.  Per direction d (0,1),
+ * batch b, timestamp n the source stack is [imnet_out(64) | pred flow(2, raw) | feat_low(64 gathered
+ * from the LR encoder feature by the nearest tables)], flow = pred[0:2]*flow_scale,
+ * z = relu(pred[2])*alpha.  Both directions accumulate into the same accumulator
+ *   acc [B*N, 133, HH, WW]: planes 0..129 feature sums, 130 sum of e^z*w, 131 max (init 1), 132 count.
+ * imnet_out [2B,64,Q], pred [2B*N,3,Q], feat_lr [2B,64,H,W], iy[HH], ix[WW] int32 tables. */
+int motif_splat_motif_fwd(const float* imnet_out, const float* pred, const float* feat_lr,
+                          const int32_t* iy, const int32_t* ix, const float* alpha, float flow_scale,
+                          float* acc, int B, int N, int H, int W, int HH, int WW, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * B1-B4  space-time local implicit MLPs (SIREN, omega0=30) with the nearest gather fused in.
+ * Replaces torch's grid_sample(nearest)+cat+Linear+sin chains at Ours.py:699-737 and 839-858 over
+ * models/modules/SIREN.py:44-45,77-79.  Weights are passed PACKED (motif_siren_pack).
+ * ---------------------------------------------------------------------------------------------- */
+/* n_layers linear layers: dims[0]=in, dims[1..n_layers]=out of each layer (last is the linear head).
+ * w[i] is [dims[i+1], dims[i]] row-major (nn.Linear.weight), b[i] is [dims[i+1]].
+ * Returns number of floats the packed blob needs when `packed` is NULL. */
+long motif_siren_pack(const float* const* w, const float* const* b, const int* dims, int n_layers,
+                      float* packed, void* stream);
+
+/* imnet: in = [feat_lr[d*B+b](64 gathered) | rel_y | rel_x] -> out [2B,64,Q] planar. */
+int motif_siren_imnet_fwd(const float* packed, const float* feat_lr, const int32_t* iy, const int32_t* ix,
+                          const float* rel_y, const float* rel_x, float* out,
+                          int B2, int H, int W, int HH, int WW, void* stream);
+/* flow_imnet: in = [flow_feat_lr(64 gathered) | t | rel_y | rel_x] -> pred [B2*N,3,Q] planar,
+ * image index i = b2*N + n, t taken from times[(i) % (B*N)] laid out [B,N] (Ours.py:727-733). */
+int motif_siren_flow_fwd(const float* packed, const float* flowfeat_lr, const int32_t* iy, const int32_t* ix,
+                         const float* rel_y, const float* rel_x, const float* times, float* pred,
+                         int B2, int N, int H, int W, int HH, int WW, void* stream);
+/* synth: post-splat normalise (Ours.py:811-836) + [out(130) | extra(3) | residual_lr(64 gathered) | t]
+ * -> synth_net -> clamp(0,1) -> frames [N,B,3,HH,WW].  acc as produced by motif_splat_motif_fwd. */
+int motif_siren_synth_fwd(const float* packed, const float* acc, const float* residual_lr,
+                          const int32_t* iy, const int32_t* ix, const float* times, float* frames,
+                          int B, int N, int H, int W, int HH, int WW, void* stream);
+/* debugging/parity aid: materialise the 198-channel synth input [B*N,198,HH,WW] (Ours.py:839-844). */
+int motif_synth_input_fwd(const float* acc, const float* residual_lr, const int32_t* iy, const int32_t* ix,
+                          const float* times, float* out, int B, int N, int H, int W, int HH, int WW, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense convolution engine: fp32 MFMA implicit GEMM (D1, C1, C3, E1 contractions).
+ * Replaces cuDNN conv2d as reached through torch.nn.Conv2d in Ours.py / models/core / OpticalFlow.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct MotifConvDesc {
+    int N, H, W;              /* input batch and spatial size */
+    int C0, C1;               /* channels taken from in0 and in1 (in1 may be NULL, C1=0): fused concat */
+    int Cout, KH, KW;
+    int stride, pad, dil, groups;
+    int pad_mode;             /* 0 zeros, 1 reflect */
+    int act, act2, act_split; /* channels >= act_split use act2 (act_split<=0: all use act) */
+    int res_mode;             /* 0 none; 1 out=act(acc+res); 2 out=act(acc)+res; 3 out=relu(act(acc)+res);
+                                 4 out=act(acc)*res */
+    long in0_bs, in1_bs, res_bs, out_bs;  /* batch strides in elements (0 -> dense default) */
+} MotifConvDesc;
+
+long motif_conv2d_packed_size(const MotifConvDesc* d);
+int motif_conv2d_pack(const MotifConvDesc* d, const float* weight /*[Cout,Cin/groups,KH,KW]*/,
+                      float* packed, void* stream);
+int motif_conv2d_fwd(const MotifConvDesc* d, const float* in0, const float* in1, const float* packed,
+                     const float* bias /*may be NULL*/, const float* res /*may be NULL*/, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * D2  modulated deformable convolution v2, forward.
+ * Replaces _ext.dcn_v2_forward (models/modules/DCNv2/src/dcn_v2.h:9-39, cuda/dcn_v2_cuda.cu:42-171,
+ * cuda/dcn_v2_im2col_cuda.cu:125-194).  offset [B,2*dg*kh*kw,Ho,Wo] ((dy,dx) interleaved per tap per
+ * group), mask [B,dg*kh*kw,Ho,Wo] (already sigmoid'ed), `packed` = motif_conv2d_pack of the weight
+ * viewed as a 1x1 conv over C*kh*kw channels, `columns` workspace of B*C*kh*kw*Ho*Wo floats.
+ * offset_bs/mask_bs: batch strides (elements) so both can alias one conv_offset_mask output. */
+int motif_dcn_v2_fwd(const float* input, const float* offset, const float* mask, const float* packed,
+                     const float* bias, float* columns, float* out,
+                     int B, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil,
+                     int deformable_groups, long offset_bs, long mask_bs, int act, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * C2  RAFT windowed correlation lookup.  Replaces alt_cuda_corr.forward (third-party, not vendored;
+ * call site models/core/corr.py:78-83).  fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C] channels-last,
+ * coords [B,2,H1,W1] (x,y planes; the caller passes coords/2^level through `coord_scale`),
+ * out channel (ix*(2r+1)+iy) written at out[b, ch_off + ., h, w] of a [B,out_C,H1,W1] tensor,
+ * every value divided by `div` (corr.py:87). */
+int motif_raft_corr_lookup(const float* fmap1, const float* fmap2, const float* coords, float coord_scale,
+                           float* out, int B, int H1, int W1, int H2, int W2, int C, int r,
+                           int out_C, int ch_off, float div, void* stream);
+
+/* C4  PWC-Net 9x9 cost volume.  Replaces kernel_Correlation_rearrange + kernel_Correlation_updateOutput
+ * (OpticalFlow/correlation.py:17-112,294-348): out[b,(dy+4)*9+(dx+4),y,x] = mean_c f1*f2(y+dy,x+dx). */
+int motif_corr81_fwd(const float* first, const float* second, float* out, int B, int C, int H, int W,
+                     int act, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pointwise / resampling kernels of the path (E1, F1 and RAFT/encoder glue).
+ * ---------------------------------------------------------------------------------------------- */
+/* F.interpolate(mode='bilinear') (Ours.py:540,548; PCD_Align 123-167; utils.py:80-82), out *= mul */
+int motif_resize_bilinear(const float* in, float* out, int NC, int H, int W, int Ho, int Wo,
+                          int align_corners, float mul, void* stream);
+/* BackWarp.forward (Ours.py:899-923): (x/w)*2-1 grid, grid_sample(bilinear, align_corners=True, border);
+ * sign multiplies `img` (the -flow case at Ours.py:565). */
+int motif_backwarp(const float* img, const float* flow, float* out, int N, int C, int H, int W, float sign, void* stream);
+/* PWC Decoder.Backward (PWCNet.py:146-177): linspace grid + flow/((size-1)/2), grid_sample default
+ * (align_corners=False, zeros) and the >0.999 validity mask. */
+int motif_pwc_backward_warp(const float* img, const float* flow, const float* gx_table /*linspace(-1,1,W)*/,
+                            const float* gy_table /*linspace(-1,1,H)*/, float* out, int N, int C, int H, int W, void* stream);
+/* reliability maps (Ours.py:562-578) + flow encoder input (Ours.py:614-631):
+ * fr0/fr1: the centre pair, each [3,H,W] per batch item with batch stride fr_bs (elements);
+ * flow [4B,2,H,W] (pairs 00,01,10,11; 00 and 11 already zeroed) -> psies [4B,3,H,W], flow_feat [2B,14,H,W]. */
+int motif_reliability_fwd(const float* fr0, const float* fr1, long fr_bs, const float* flow, const float* g_filter,
+                          float* psies, float* flow_feat, int B, int H, int W, void* stream);
+/* InstanceNorm2d (eps 1e-5, no affine) + optional relu, optional residual: out = relu?(res + relu?(norm(x)))
+ * mode 0: norm; 1: relu(norm); 2: relu(res + relu(norm))   (models/core/extractor.py:60-116,246-248) */
+int motif_instance_norm(const float* x, const float* res, float* out, int NC, int HW, int mode, void* stream);
+int motif_avg_pool2(const float* in, float* out, int NC, int H, int W, void* stream);   /* F.avg_pool2d(x,2,2) */
+int motif_nchw_to_nhwc(const float* in, float* out, int N, int C, int HW, void* stream);
+/* ConvGRU update (update.py:24-31): h' = (1-z)*h + z*q */
+int motif_gru_update(const float* z, const float* q, const float* h, float* out, long n, void* stream);
+/* ConvLSTM gates (convlstm.py:49-58): cc [B,4*hid,H,W] (i,f,o,g pre-activations) */
+int motif_lstm_gates(const float* cc, const float* c_cur, float* h_next, float* c_next, int B, int hid, int HW, void* stream);
+/* out = a*x + b*y (y may be NULL) */
+int motif_axpby(const float* x, const float* y, float a, float b, float* out, long n, void* stream);
+/* ConvTranspose2d(k=4,s=2,p=1) with few output channels (PWCNet.py:102-106) */
+int motif_deconv4x4s2(const float* in, const float* weight /*[Cin,Cout,4,4]*/, const float* bias, float* out,
+                      int N, int Cin, int Cout, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOTIF_HIP_H */

@@ -1,0 +1,78 @@
+"""ctypes binding of libmotif_hip.so (the C ABI declared in include/motif_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a RuntimeError is
+raised (SURVEY.md §8(b) "Errors").  `load(build=True)` may compile it with hipcc (in-tree) first.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libmotif_hip.so")
+_lib = None
+
+
+class MotifConvDesc(Structure):
+    _fields_ = [("N", c_int), ("H", c_int), ("W", c_int), ("C0", c_int), ("C1", c_int),
+                ("Cout", c_int), ("KH", c_int), ("KW", c_int),
+                ("stride", c_int), ("pad", c_int), ("dil", c_int), ("groups", c_int),
+                ("pad_mode", c_int), ("act", c_int), ("act2", c_int), ("act_split", c_int), ("res_mode", c_int),
+                ("in0_bs", c_long), ("in1_bs", c_long), ("res_bs", c_long), ("out_bs", c_long)]
+
+
+P = c_void_p
+_SIGS = {
+    "motif_abi_version": (c_int, []),
+    "motif_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
+    "motif_splat_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "motif_splat_motif_fwd": (c_int, [P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "motif_siren_pack": (c_long, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), c_int, P, P]),
+    "motif_siren_imnet_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "motif_siren_flow_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "motif_siren_synth_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "motif_synth_input_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "motif_conv2d_packed_size": (c_long, [POINTER(MotifConvDesc)]),
+    "motif_conv2d_pack": (c_int, [POINTER(MotifConvDesc), P, P, P]),
+    "motif_conv2d_fwd": (c_int, [POINTER(MotifConvDesc), P, P, P, P, P, P, P]),
+    "motif_dcn_v2_fwd": (c_int, [P, P, P, P, P, P, P] + [c_int] * 11 + [c_long, c_long, c_int, P]),
+    "motif_raft_corr_lookup": (c_int, [P, P, P, c_float, P] + [c_int] * 7 + [c_int, c_int, c_float, P]),
+    "motif_corr81_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "motif_resize_bilinear": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    "motif_backwarp": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "motif_pwc_backward_warp": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "motif_reliability_fwd": (c_int, [P, P, c_long, P, P, P, P, c_int, c_int, c_int, P]),
+    "motif_instance_norm": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "motif_avg_pool2": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "motif_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "motif_gru_update": (c_int, [P, P, P, P, c_long, P]),
+    "motif_lstm_gates": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "motif_axpby": (c_int, [P, P, c_float, c_float, P, c_long, P]),
+    "motif_deconv4x4s2": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def load(build=False):
+    """Return the loaded library; raises RuntimeError if it is absent (no CPU/eager fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build or not os.path.exists(SO_PATH):
+        if build:
+            from .csrc import build as _b
+            _b.build()
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError("libmotif_hip.so not found at %s -- run `python -m motif_amd.csrc.build` "
+                           "(hipcc --offload-arch=gfx950); there is no fallback path" % SO_PATH)
+    lib = ctypes.CDLL(SO_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI mismatch with include/motif_hip.h
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d (%s)" % (what, rc, "argument error" if rc < 0 else "hipError_t"))

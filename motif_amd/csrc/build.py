@@ -1,0 +1,44 @@
+"""Build libmotif_hip.so for gfx950 with hipcc (in-tree; cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "libmotif_hip.so")
+SOURCES = ["api.hip", "conv_igemm.hip", "siren.hip", "splat.hip", "misc.hip", "corr.hip", "dcn.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value",
+         "-Wno-pass-failed"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hdrs = [os.path.join(HERE, "common.h"), os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "motif_hip.h")]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs, jobs = [], []
+    for s in SOURCES:
+        src = os.path.join(HERE, s)
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append(["hipcc"] + FLAGS + ["-c", src, "-o", obj])
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(OUT, objs):
+        run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,248 @@
+// Dense convolution as an fp32-MFMA implicit GEMM for gfx950.
+//
+//   D[cout][pixel] = sum_k  Wp[k][cout] * im2col[k][pixel],   k = (c, ky, kx)
+//
+// v_mfma_f32_32x32x2_f32 computes a 32(cout) x 32(pixel) tile per wave-instruction with K=2: the lower
+// half-wave supplies k=2s, the upper half k=2s+1.  NCHW planar fp32 is the natural layout for it: a
+// wave's 32 pixels are 32 consecutive x of one output row, so the B operand is one conflict-free
+// ds_read_b32 from an LDS input patch, and the A operand one ds_read_b32 from a [k][cout] weight slab.
+//
+// Block = 4 waves = 8 output rows x 32 columns; each wave owns 2 rows x NC cout-tiles of 32
+// (NC*2 accumulators of 16 VGPRs).  The reduction runs over channel chunks: stage the input patch of
+// CK channels (+halo, zero/reflect padded) and the matching weight rows in LDS, barrier, MFMA steps.
+// The (c,ky,kx)->patch-offset map is a small LDS table so ONE kernel serves every kernel size, stride,
+// dilation and group count on the path (3x3 s1/s2, 1x1, 7x7 s2, dilated PWC refiner, grouped).
+// Fused: channel concat of two inputs, bias, residual, activation (per channel range).
+#include "common.h"
+
+struct ConvArgs {
+    const float* in0; const float* in1; const float* wp; const float* bias; const float* res; float* out;
+    long in0_bs, in1_bs, res_bs, out_bs;
+    int C0, H, W, Ho, Wo;
+    int Cin_g, Cout_g, Cout;
+    int KH, KW, stride, pad, dil, pad_mode;
+    int act, act2, act_split, res_mode;
+    int CK, PH, PW, Kpad, tiles_x, ncg;
+};
+
+template <int NC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    const int g = blockIdx.y / a.ncg, cg = blockIdx.y % a.ncg;
+    const int n = blockIdx.z;
+    const int PHW = a.PH * a.PW;
+    const int T = a.KH * a.KW;
+    const int KC = a.CK * T;                 // rows per full chunk (host guarantees even)
+    constexpr int WN = 32 * NC;              // weight slab row width
+    const int patch_elems = (a.CK * PHW + 3) & ~3;
+    float* patch = smem;
+    float* wl = smem + patch_elems;
+    int* koff = (int*)(wl + KC * WN);
+    int* goff = koff + KC;
+
+    // one-off tables: patch position -> input offset (or -1), chunk row -> patch offset
+    const int iy0 = ty * 8 * a.stride - a.pad, ix0 = tx * 32 * a.stride - a.pad;
+    for (int p = tid; p < PHW; p += 256) {
+        int py = p / a.PW, px = p - py * a.PW;
+        int iy = iy0 + py, ix = ix0 + px;
+        if (a.pad_mode == 1) {
+            if (iy < 0) iy = -iy; else if (iy >= a.H) iy = 2 * (a.H - 1) - iy;
+            if (ix < 0) ix = -ix; else if (ix >= a.W) ix = 2 * (a.W - 1) - ix;
+        }
+        goff[p] = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? iy * a.W + ix : -1;
+    }
+    for (int kk = tid; kk < KC; kk += 256) {
+        int c = kk / T, t = kk - c * T;
+        int ky = t / a.KW, kx = t - ky * a.KW;
+        koff[kk] = c * PHW + ky * a.dil * a.PW + kx * a.dil;
+    }
+
+    f32x16 acc[NC][2];
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const long HW = (long)a.H * a.W;
+    const float* wbase = a.wp + ((long)(g * a.ncg + cg) * a.Kpad) * WN;
+    const int pix0 = (2 * wave) * a.stride * a.PW + l31 * a.stride;
+    const int pix1 = pix0 + a.stride * a.PW;
+
+    for (int c0 = 0; c0 < a.Cin_g; c0 += a.CK) {
+        __syncthreads();   // previous chunk's reads done (also orders the table writes the first time)
+        for (int c = 0; c < a.CK; ++c) {
+            const int ch = c0 + c;
+            const float* base = nullptr;
+            if (ch < a.Cin_g) {
+                const int gch = g * a.Cin_g + ch;
+                base = (gch < a.C0) ? a.in0 + (long)n * a.in0_bs + (long)gch * HW
+                                    : a.in1 + (long)n * a.in1_bs + (long)(gch - a.C0) * HW;
+            }
+            float* dst = patch + c * PHW;
+            for (int p = tid; p < PHW; p += 256) {
+                const int go = goff[p];
+                dst[p] = (base != nullptr && go >= 0) ? base[go] : 0.f;
+            }
+        }
+        const int r0 = c0 * T;
+        int rows = a.Kpad - r0; if (rows > KC) rows = KC;     // even
+        {
+            const f32x4* src = (const f32x4*)(wbase + (long)r0 * WN);
+            f32x4* d4 = (f32x4*)wl;
+            const int n4 = rows * WN / 4;
+            for (int i = tid; i < n4; i += 256) d4[i] = src[i];
+        }
+        __syncthreads();
+        const int steps = rows >> 1;
+#pragma unroll 4
+        for (int s = 0; s < steps; ++s) {
+            const int k = 2 * s + half;
+            const int ko = koff[k];
+            const float b0 = patch[ko + pix0];
+            const float b1 = patch[ko + pix1];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const float av = wl[k * WN + i * 32 + l31];
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[i][1], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: C/D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*half (cout within tile)
+    const int ox = tx * 32 + l31;
+    if (ox < a.Wo) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int oy = ty * 8 + 2 * wave + j;
+            if (oy >= a.Ho) continue;
+            const long pix = (long)oy * a.Wo + ox;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = cg * WN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (col >= a.Cout_g) continue;
+                    const int co = g * a.Cout_g + col;
+                    float v = acc[i][j][r];
+                    if (a.bias) v += a.bias[co];
+                    const int act = (a.act_split > 0 && co >= a.act_split) ? a.act2 : a.act;
+                    const long HWo = (long)a.Ho * a.Wo;
+                    float rv = 0.f;
+                    if (a.res_mode) rv = a.res[(long)n * a.res_bs + (long)co * HWo + pix];
+                    if (a.res_mode == 1) v = act_apply(v + rv, act);
+                    else if (a.res_mode == 2) v = act_apply(v, act) + rv;
+                    else if (a.res_mode == 3) { v = act_apply(v, act) + rv; v = v > 0.f ? v : 0.f; }
+                    else if (a.res_mode == 4) v = act_apply(v, act) * rv;
+                    else v = act_apply(v, act);
+                    a.out[(long)n * a.out_bs + (long)co * HWo + pix] = v;
+                }
+            }
+        }
+    }
+}
+
+// weight [Cout, Cin_g, KH, KW] -> packed [groups][ncg][Kpad][32*NC], zero padded
+__global__ void conv_pack_kernel(const float* w, float* wp, int Cout_g, int K, int Kpad, int ncg, int WN, long total) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int j = (int)(i % WN);
+    long t = i / WN;
+    int k = (int)(t % Kpad);
+    t /= Kpad;
+    int cgi = (int)(t % ncg);
+    int g = (int)(t / ncg);
+    int col = cgi * WN + j;
+    float v = 0.f;
+    if (col < Cout_g && k < K) v = w[((long)(g * Cout_g + col)) * K + k];
+    wp[i] = v;
+}
+
+namespace {
+struct ConvPlan { int Cin, Cin_g, Cout_g, K, Kpad, NC, WN, ncg, Ho, Wo, PH, PW, CK, T; size_t lds; };
+
+bool plan_conv(const MotifConvDesc* d, ConvPlan* p) {
+    if (!d || d->groups < 1 || d->KH < 1 || d->KW < 1 || d->stride < 1 || d->dil < 1) return false;
+    p->Cin = d->C0 + d->C1;
+    if (p->Cin % d->groups || d->Cout % d->groups || p->Cin <= 0 || d->Cout <= 0) return false;
+    p->Cin_g = p->Cin / d->groups;
+    p->Cout_g = d->Cout / d->groups;
+    p->T = d->KH * d->KW;
+    p->K = p->Cin_g * p->T;
+    p->Kpad = (p->K + 1) & ~1;
+    p->NC = p->Cout_g > 32 ? 2 : 1;
+    p->WN = 32 * p->NC;
+    p->ncg = (p->Cout_g + p->WN - 1) / p->WN;
+    p->Ho = (d->H + 2 * d->pad - (d->dil * (d->KH - 1) + 1)) / d->stride + 1;
+    p->Wo = (d->W + 2 * d->pad - (d->dil * (d->KW - 1) + 1)) / d->stride + 1;
+    if (p->Ho <= 0 || p->Wo <= 0) return false;
+    p->PH = 7 * d->stride + (d->KH - 1) * d->dil + 1;
+    p->PW = 31 * d->stride + (d->KW - 1) * d->dil + 1;
+    // chunk: as many channels as fit ~40 KB of LDS, CK*T even
+    const long PHW = (long)p->PH * p->PW;
+    int ck = 1;
+    const long budget = 40 * 1024;
+    for (int c = 1; c <= p->Cin_g + 1 && c <= 64; ++c) {
+        long bytes = (((long)c * PHW + 3) & ~3L) * 4 + (long)c * p->T * (p->WN * 4 + 4) + PHW * 4;
+        if (bytes > budget) break;
+        ck = c;
+    }
+    if ((ck * p->T) & 1) { if (ck > 1) ck -= 1; else ck = 2; }
+    if (ck > p->Cin_g) { ck = p->Cin_g; if ((ck * p->T) & 1) ck += 1; }
+    p->CK = ck;
+    p->lds = ((((size_t)ck * PHW + 3) & ~(size_t)3) + (size_t)ck * p->T * p->WN + (size_t)ck * p->T + PHW) * 4;
+    return p->lds <= 160 * 1024;
+}
+}  // namespace
+
+extern "C" long motif_conv2d_packed_size(const MotifConvDesc* d) {
+    ConvPlan p;
+    if (!plan_conv(d, &p)) return MOTIF_EINVAL;
+    return (long)d->groups * p.ncg * p.Kpad * p.WN;
+}
+
+extern "C" int motif_conv2d_pack(const MotifConvDesc* d, const float* weight, float* packed, void* stream) {
+    ConvPlan p;
+    if (!plan_conv(d, &p) || !weight || !packed) return MOTIF_EINVAL;
+    long total = (long)d->groups * p.ncg * p.Kpad * p.WN;
+    conv_pack_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(weight, packed, p.Cout_g, p.K, p.Kpad, p.ncg, p.WN, total);
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}
+
+extern "C" int motif_conv2d_fwd(const MotifConvDesc* d, const float* in0, const float* in1, const float* packed,
+                                const float* bias, const float* res, float* out, void* stream) {
+    ConvPlan p;
+    if (!plan_conv(d, &p)) return MOTIF_ELIMIT;
+    if (!in0 || !packed || !out || (d->C1 > 0 && !in1) || (d->res_mode && !res) || d->N < 1) return MOTIF_EINVAL;
+    ConvArgs a;
+    a.in0 = in0; a.in1 = in1; a.wp = packed; a.bias = bias; a.res = res; a.out = out;
+    const long HW = (long)d->H * d->W, HWo = (long)p.Ho * p.Wo;
+    a.in0_bs = d->in0_bs ? d->in0_bs : (long)d->C0 * HW;
+    a.in1_bs = d->in1_bs ? d->in1_bs : (long)d->C1 * HW;
+    a.res_bs = d->res_bs ? d->res_bs : (long)d->Cout * HWo;
+    a.out_bs = d->out_bs ? d->out_bs : (long)d->Cout * HWo;
+    a.C0 = d->C0; a.H = d->H; a.W = d->W; a.Ho = p.Ho; a.Wo = p.Wo;
+    a.Cin_g = p.Cin_g; a.Cout_g = p.Cout_g; a.Cout = d->Cout;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil; a.pad_mode = d->pad_mode;
+    a.act = d->act; a.act2 = d->act2; a.act_split = d->act_split; a.res_mode = d->res_mode;
+    a.CK = p.CK; a.PH = p.PH; a.PW = p.PW; a.Kpad = p.Kpad;
+    a.tiles_x = (p.Wo + 31) / 32;
+    const int tiles_y = (p.Ho + 7) / 8;
+    a.ncg = p.ncg;
+    dim3 grid(a.tiles_x * tiles_y, d->groups * p.ncg, d->N);
+    hipStream_t s = (hipStream_t)stream;
+    if (p.NC == 2) {
+        if (p.lds > 64 * 1024) hipFuncSetAttribute((const void*)conv_igemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+        conv_igemm_kernel<2><<<grid, 256, p.lds, s>>>(a);
+    } else {
+        if (p.lds > 64 * 1024) hipFuncSetAttribute((const void*)conv_igemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+        conv_igemm_kernel<1><<<grid, 256, p.lds, s>>>(a);
+    }
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}

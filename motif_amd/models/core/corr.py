@@ -1,0 +1,42 @@
+"""RAFT correlation lookup on the HIP kernel that replaces `alt_cuda_corr`.
+
+Mirrors `AlternateCorrBlock` (`/root/reference/models/core/corr.py:59-87`): 5-level avg-pool pyramid of
+fmap2 (4 used), per level a windowed bilinear lookup at coords/2^i, stacked to [B,196,H,W], / sqrt(C).
+`alt_cuda_corr_forward` keeps the third-party extension's call signature (corr.py:78-83).
+"""
+import math
+
+import torch
+
+from ... import ops
+
+
+def alt_cuda_corr_forward(fmap1, fmap2, coords, r):
+    """alt_cuda_corr.forward(fmap1[B,H,W,C], fmap2[B,H2,W2,C], coords[B,1,H,W,2], r) -> (corr[B,1,(2r+1)^2,H,W],)"""
+    b, h, w, _ = fmap1.shape
+    out = torch.empty(b, (2 * r + 1) ** 2, h, w, dtype=torch.float32, device=fmap1.device)
+    c = coords.reshape(b, h, w, 2).permute(0, 3, 1, 2).contiguous()
+    ops.raft_corr_lookup(fmap1.contiguous(), fmap2.contiguous(), c, 1.0, out, 0, 1.0, r)
+    return (out.unsqueeze(1),)
+
+
+class AlternateCorrBlock:
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        self.num_levels = num_levels
+        self.radius = radius
+        self.dim = fmap1.shape[1]
+        self.f1 = ops.nchw_to_nhwc(fmap1)
+        self.f2 = []
+        for i in range(self.num_levels):
+            self.f2.append(ops.nchw_to_nhwc(fmap2))
+            if i + 1 < self.num_levels:
+                fmap2 = ops.avg_pool2(fmap2)
+
+    def __call__(self, coords):
+        b, _, h, w = coords.shape
+        n = (2 * self.radius + 1) ** 2
+        out = torch.empty(b, self.num_levels * n, h, w, dtype=torch.float32, device=coords.device)
+        div = float(torch.sqrt(torch.tensor(self.dim).float()))
+        for i in range(self.num_levels):
+            ops.raft_corr_lookup(self.f1, self.f2[i], coords, 1.0 / 2 ** i, out, i * n, div, self.radius)
+        return out

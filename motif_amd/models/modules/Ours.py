@@ -1,0 +1,385 @@
+"""MoTIF network (`LunaTokis`, setting 5) on hand-written HIP kernels for MI355X.
+
+Host-side mirror of `/root/reference/models/modules/Ours.py`: same class names, constructor
+arguments, `forward` signature / return triple (`Ours.py:512,858`) and the same 698 state-dict keys,
+so `best.pth` loads with `strict=True`.  Every device computation goes through libmotif_hip.so
+(`motif_amd.ops`); torch is used for memory, views and a few scalar glue ops only.
+
+What is restructured relative to the reference schedule (results unchanged):
+  * the t-independent stage (RAFT, reliability maps, encoder, flow encoder, `imnet`) is cached across
+    the <=3-timestamp chunks `VideoSRBaseModel.test` issues for one clip (`VideoSR_base_model.py:189-193`);
+  * RAFT runs only on the frame pairs 01 and 10 -- the 00 and 11 flows are multiplied by zero at
+    `Ours.py:552-553`;
+  * the nearest-gathered 322-channel HR stack, `feat*e^z`, the 198-channel decoder input and every
+    channel concat are never materialised: they are fused into the MLP / splat / conv kernels.
+"""
+import argparse
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from ..core.raft import RAFT
+from ..softsplat_cp import Softsplat
+from ..softsplat_count_cp import Softsplat_Count
+from ..softsplat_max_cp import Softsplat_Max
+from .DCNv2.dcn_v2 import DCN_sep
+from .layers import Conv2d
+from .SIREN import Siren
+
+LRELU, RELU, NONE = ops.ACT_LRELU, ops.ACT_RELU, ops.ACT_NONE
+
+
+def up2(x, mul=1.0):
+    """F.interpolate(scale_factor=2, bilinear, align_corners=False) (Ours.py:123,128,...)."""
+    return ops.resize_bilinear(x, (2 * x.shape[2], 2 * x.shape[3]), False, mul)
+
+
+class TMB(nn.Module):
+    """Temporal modulation block: parameters exist in the checkpoint (`Ours.py:27-50`) but the eval
+    path passes t=None (`Ours.py:393`), so it never runs."""
+
+    def __init__(self):
+        super().__init__()
+        self.t_process = nn.Sequential(Conv2d(1, 64, 1, bias=False), nn.Identity(), Conv2d(64, 64, 1, bias=False), nn.Identity(),
+                                       Conv2d(64, 64, 1, bias=False), nn.Identity())
+        self.f_process = nn.Sequential(Conv2d(64, 64, 3, 1, 1), nn.Identity(), Conv2d(64, 64, 3, 1, 1), nn.Identity())
+
+
+class PCD_Align(nn.Module):
+    """Pyramid / cascading / deformable alignment, 3 levels, both directions (`Ours.py:53-172`)."""
+
+    def __init__(self, nf=64, groups=8, use_time=True):
+        super().__init__()
+        for s in ("1", "2"):
+            setattr(self, "L3_offset_conv1_" + s, Conv2d(nf * 2, nf, 3, 1, 1))
+            setattr(self, "L3_offset_conv2_" + s, Conv2d(nf, nf, 3, 1, 1))
+            setattr(self, "L3_dcnpack_" + s, DCN_sep(nf, nf, 3, stride=1, padding=1, dilation=1, deformable_groups=groups))
+            for L in ("L2", "L1"):
+                setattr(self, L + "_offset_conv1_" + s, Conv2d(nf * 2, nf, 3, 1, 1))
+                setattr(self, L + "_offset_conv2_" + s, Conv2d(nf * 2, nf, 3, 1, 1))
+                setattr(self, L + "_offset_conv3_" + s, Conv2d(nf, nf, 3, 1, 1))
+                setattr(self, L + "_dcnpack_" + s, DCN_sep(nf, nf, 3, stride=1, padding=1, dilation=1, deformable_groups=groups))
+                setattr(self, L + "_fea_conv_" + s, Conv2d(nf * 2, nf, 3, 1, 1))
+        if use_time:
+            for n in ("A_l1", "B_l1", "A_l2", "B_l2", "A_l3", "B_l3"):
+                setattr(self, "TMB_" + n, TMB())
+
+    def _align(self, a, b, s):
+        g = lambda name: getattr(self, name + "_" + s)
+        o3 = g("L3_offset_conv1")(a[2], b[2], act=LRELU)
+        o3 = g("L3_offset_conv2")(o3, act=LRELU)
+        f3 = g("L3_dcnpack")(a[2], o3, act=LRELU)
+        o2 = g("L2_offset_conv1")(a[1], b[1], act=LRELU)
+        o2 = g("L2_offset_conv2")(o2, up2(o3, 2.0), act=LRELU)
+        o2 = g("L2_offset_conv3")(o2, act=LRELU)
+        f2 = g("L2_dcnpack")(a[1], o2)
+        f2 = g("L2_fea_conv")(f2, up2(f3), act=LRELU)
+        o1 = g("L1_offset_conv1")(a[0], b[0], act=LRELU)
+        o1 = g("L1_offset_conv2")(o1, up2(o2, 2.0), act=LRELU)
+        o1 = g("L1_offset_conv3")(o1, act=LRELU)
+        f1 = g("L1_dcnpack")(a[0], o1)
+        return g("L1_fea_conv")(f1, up2(f2))
+
+    def forward(self, fea1, fea2, t=None, t_back=None):
+        if t is not None or t_back is not None:
+            raise NotImplementedError("temporal modulation is a training-time branch (Ours.py:393 passes None)")
+        return self._align(fea1, fea2, "1"), self._align(fea2, fea1, "2")     # the 128-ch concat is fused into `fusion`
+
+
+class Easy_PCD(nn.Module):
+    def __init__(self, nf=64, groups=8):
+        super().__init__()
+        self.fea_L2_conv1 = Conv2d(nf, nf, 3, 2, 1)
+        self.fea_L2_conv2 = Conv2d(nf, nf, 3, 1, 1)
+        self.fea_L3_conv1 = Conv2d(nf, nf, 3, 2, 1)
+        self.fea_L3_conv2 = Conv2d(nf, nf, 3, 1, 1)
+        self.pcd_align = PCD_Align(nf=nf, groups=groups)
+        self.fusion = Conv2d(2 * nf, nf, 1, 1)
+
+    def forward(self, f1, f2):
+        b = f1.shape[0]
+        l1 = torch.stack([f1, f2], dim=1).flatten(0, 1)                       # [2B,C,H,W], (b, n) order as Ours.py:192-194
+        l2 = self.fea_L2_conv2(self.fea_L2_conv1(l1, act=LRELU), act=LRELU)
+        l3 = self.fea_L3_conv2(self.fea_L3_conv1(l2, act=LRELU), act=LRELU)
+        pick = lambda t, i: t.view(b, 2, *t.shape[1:])[:, i]                  # batch-strided planar views
+        fea1 = [pick(l1, 0), pick(l2, 0), pick(l3, 0)]
+        fea2 = [pick(l1, 1), pick(l2, 1), pick(l3, 1)]
+        y1, y2 = self.pcd_align(fea1, fea2)
+        return self.fusion(y1, y2)
+
+
+class ConvLSTMCell(nn.Module):
+    """`/root/reference/models/modules/convlstm.py:6-64`: one 3x3 conv over cat(x, h) + gates."""
+
+    def __init__(self, input_size, input_dim, hidden_dim, kernel_size, bias):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.conv = Conv2d(input_dim + hidden_dim, 4 * hidden_dim, kernel_size[0], padding=kernel_size[0] // 2, bias=bias)
+
+    def forward(self, input_tensor, cur_state):
+        h_cur, c_cur = cur_state
+        return ops.lstm_gates(self.conv(input_tensor, h_cur), c_cur)
+
+
+class DeformableConvLSTM(nn.Module):
+    def __init__(self, input_size, input_dim, hidden_dim, kernel_size, num_layers, front_RBs, groups,
+                 batch_first=False, bias=True, return_all_layers=False):
+        super().__init__()
+        if num_layers != 1:
+            raise NotImplementedError("MoTIF uses one layer (Ours.py:362-364)")
+        hid = hidden_dim[0] if isinstance(hidden_dim, (list, tuple)) else hidden_dim
+        self.pcd_h = Easy_PCD(nf=input_dim, groups=groups)
+        self.pcd_c = Easy_PCD(nf=input_dim, groups=groups)
+        self.cell_list = nn.ModuleList([ConvLSTMCell(input_size, input_dim, hid, kernel_size, bias)])
+
+    def forward(self, x):                          # x [B,T,C,H,W] -> list of T tensors [B,C,H,W]
+        b, t, c, hh, ww = x.shape
+        h = torch.zeros(b, c, hh, ww, dtype=torch.float32, device=x.device)
+        cs = torch.zeros_like(h)
+        outs = []
+        for i in range(t):
+            xi = x[:, i]
+            h_temp = self.pcd_h(xi, h)
+            c_temp = self.pcd_c(xi, cs)
+            h, cs = self.cell_list[0](xi, [h_temp, c_temp])
+            outs.append(h)
+        return outs
+
+
+class BiDeformableConvLSTM(nn.Module):
+    def __init__(self, input_size, input_dim, hidden_dim, kernel_size, num_layers, front_RBs, groups,
+                 batch_first=False, bias=True, return_all_layers=False):
+        super().__init__()
+        self.forward_net = DeformableConvLSTM(input_size, input_dim, hidden_dim, kernel_size, num_layers, front_RBs, groups,
+                                              batch_first, bias, return_all_layers)
+        self.conv_1x1 = Conv2d(2 * input_dim, input_dim, 1, 1)
+
+    def forward(self, x):                          # [B,T,C,H,W] -> [B,T,C,H,W]
+        b, t, c, h, w = x.shape
+        fwd = self.forward_net(x)
+        rev = self.forward_net(x.flip(1))[::-1]
+        out = torch.empty(b, t, c, h, w, dtype=torch.float32, device=x.device)
+        for i in range(t):
+            self.conv_1x1(fwd[i], rev[i], out=out[:, i])
+        return out
+
+
+class ResidualBlock_noBN(nn.Module):
+    """`module_util.py:34-52`: x + conv2(relu(conv1(x)))."""
+
+    def __init__(self, nf=64):
+        super().__init__()
+        self.conv1 = Conv2d(nf, nf, 3, 1, 1)
+        self.conv2 = Conv2d(nf, nf, 3, 1, 1)
+
+    def forward(self, x):
+        return self.conv2(self.conv1(x, act=RELU), res=x, res_mode=1)
+
+
+class ZSM_encoder(nn.Module):
+    def __init__(self, channel):
+        super().__init__()
+        self.conv_first = Conv2d(3, channel, 3, 1, 1)
+        self.feature_extraction = nn.Sequential(*[ResidualBlock_noBN(channel) for _ in range(5)])
+        self.fea_L2_conv1 = Conv2d(channel, channel, 3, 2, 1)
+        self.fea_L2_conv2 = Conv2d(channel, channel, 3, 1, 1)
+        self.fea_L3_conv1 = Conv2d(channel, channel, 3, 2, 1)
+        self.fea_L3_conv2 = Conv2d(channel, channel, 3, 1, 1)
+        self.pcd_align = PCD_Align(nf=channel, groups=8)
+        self.fusion = Conv2d(2 * channel, channel, 1, 1)
+        self.ConvBLSTM = BiDeformableConvLSTM(input_size=(64, 112), input_dim=channel, hidden_dim=[channel], kernel_size=(3, 3),
+                                              num_layers=1, batch_first=True, front_RBs=5, groups=8)
+        self.recon_trunk = nn.Sequential(*[ResidualBlock_noBN(channel) for _ in range(40)])
+
+    def forward(self, x, target_t=None):           # x [B,N,3,H,W] -> [B,2N-1,64,H,W]
+        B, N, C, H, W = x.shape
+        l1 = self.conv_first(x.reshape(-1, C, H, W), act=LRELU)
+        for rb in self.feature_extraction:
+            l1 = rb(l1)
+        l2 = self.fea_L2_conv2(self.fea_L2_conv1(l1, act=LRELU), act=LRELU)
+        l3 = self.fea_L3_conv2(self.fea_L3_conv1(l2, act=LRELU), act=LRELU)
+        l1, l2, l3 = (t.view(B, N, *t.shape[1:]) for t in (l1, l2, l3))
+        T = 2 * N - 1
+        seq = torch.empty(B, T, l1.shape[2], H, W, dtype=torch.float32, device=x.device)
+        for i in range(N - 1):
+            fea1 = [l1[:, i], l2[:, i], l3[:, i]]
+            fea2 = [l1[:, i + 1], l2[:, i + 1], l3[:, i + 1]]
+            y1, y2 = self.pcd_align(fea1, fea2)
+            self.fusion(y1, y2, out=seq[:, 2 * i + 1])
+            if i == 0:
+                seq[:, 0].copy_(fea1[0])
+            seq[:, 2 * i + 2].copy_(fea2[0])
+        feats = self.ConvBLSTM(seq)
+        out = feats.view(B * T, -1, H, W)
+        for rb in self.recon_trunk:
+            out = rb(out)
+        return out.view(B, T, 64, H, W)
+
+
+class LateralBlock(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.layers = nn.Sequential(Conv2d(dim, dim, 3, 1, 1), nn.Identity(), Conv2d(dim, dim, 3, 1, 1))
+
+    def forward(self, x, act=NONE):
+        return self.layers[2](self.layers[0](x, act=LRELU), res=x, res_mode=1, act=act)
+
+
+def make_coord(shape, ranges=None, flatten=True):
+    """Grid-centre coordinates, float32 order of operations as `Ours.py:874-889`."""
+    seqs = []
+    for i, n in enumerate(shape):
+        v0, v1 = (-1, 1) if ranges is None else ranges[i]
+        r = (v1 - v0) / (2 * n)
+        seqs.append(v0 + r + (2 * r) * torch.arange(n).float())
+    ret = torch.stack(torch.meshgrid(*seqs, indexing="ij"), dim=-1)
+    return ret.view(-1, ret.shape[-1]) if flatten else ret
+
+
+class BackWarp(nn.Module):
+    """`Ours.py:892-923` (bilinear, clip=True form)."""
+
+    def __init__(self, clip=True):
+        super().__init__()
+        if not clip:
+            raise NotImplementedError("MoTIF constructs BackWarp(clip=True) (Ours.py:436)")
+
+    def forward(self, img, flow, mode="bilinear"):
+        return ops.backwarp(img, flow), None
+
+
+_TABLES = {}
+
+
+def gather_tables(H, W, HH, WW, device):
+    """Separable tables of the nearest gather + rel_coord, computed on the host
+    with the reference's literal float32 arithmetic (`Ours.py:667-722`): iy[HH], ix[WW] int32 LR indices as
+    grid_sample(nearest, align_corners=False) picks them, rel_y[HH], rel_x[WW]."""
+    key = (H, W, HH, WW, str(device))
+    if key in _TABLES:
+        return _TABLES[key]
+    hr = make_coord((HH, WW), flatten=False)                # [HH,WW,2] (y,x)
+    hr_y, hr_x = hr[:, 0, 0].clone(), hr[0, :, 1].clone()
+    lr = make_coord((H, W), flatten=False)
+    lr_y, lr_x = lr[:, 0, 0].clone(), lr[0, :, 1].clone()
+
+    def nearest(c, n_in):
+        c = c.clone()
+        c += 1e-6
+        c.clamp_(-1 + 1e-6, 1 - 1e-6)
+        src = torch.arange(n_in, dtype=torch.float32).view(1, 1, n_in, 1)
+        grid = torch.stack([torch.zeros_like(c), c], dim=-1).view(1, -1, 1, 2)        # (x, y)
+        return F.grid_sample(src, grid, mode="nearest", align_corners=False).view(-1).to(torch.int64)
+
+    iy, ix = nearest(hr_y, H), nearest(hr_x, W)
+    rel_y = (hr_y - lr_y[iy]) * H
+    rel_x = (hr_x - lr_x[ix]) * W
+    t = (iy.to(torch.int32).to(device), ix.to(torch.int32).to(device), rel_y.to(device), rel_x.to(device))
+    _TABLES[key] = t
+    return t
+
+
+class LunaTokis(nn.Module):
+    def __init__(self, setting=5):
+        super().__init__()
+        if setting != 5:
+            raise NotImplementedError("test.yml selects setting 5 (test.yml:50); other settings are ablations")
+        args = argparse.Namespace(small=True, mixed_precision=False, alternate_corr=True)
+        self.flow_predictor = RAFT(args)          # weights arrive through load_state_dict (flow_predictor.* keys)
+        self.fwarp, self.fwarp_max, self.fwarp_count = Softsplat(), Softsplat_Max(), Softsplat_Count()
+        self.bwarp = BackWarp(clip=True)
+        self.norm_gamma = nn.Parameter(torch.ones(1, 3, 1))
+        self.norm_beta = nn.Parameter(torch.zeros(1, 3, 1))
+        self.g_filter = nn.Parameter(torch.tensor([[1 / 16, 1 / 8, 1 / 16], [1 / 8, 1 / 4, 1 / 8], [1 / 16, 1 / 8, 1 / 16]])
+                                     .reshape(1, 1, 1, 3, 3), requires_grad=False)
+        channel = 64
+        self.groups = 1
+        self.encoder = ZSM_encoder(channel)
+        self.flow_imnet = Siren(in_features=67, out_features=3, hidden_features=[64, 64, 256], hidden_layers=2, outermost_linear=True)
+        self.imnet = Siren(in_features=66, out_features=64, hidden_features=[64, 64, 256], hidden_layers=2, outermost_linear=True)
+        self.synth_net = Siren(in_features=198, out_features=3, hidden_features=[64, 64, 64, 256], hidden_layers=3, outermost_linear=True)
+        self.flow_process = nn.Sequential(
+            Conv2d(14, channel, 3, 1, 1, groups=2), Conv2d(channel, channel, 3, 1, 1, groups=2), nn.Identity(),
+            LateralBlock(channel), LateralBlock(channel), LateralBlock(channel), LateralBlock(channel), LateralBlock(channel),
+            nn.Identity(), Conv2d(channel, channel, 3, 1, 1, padding_mode="reflect"))
+        self.alpha = nn.Parameter(torch.ones(1) * -20.0)
+        self.shuffle = Conv2d(channel, channel, 1, 1, 0)
+        self.skip_zero_pairs = True
+        self._cache_key, self._cache = None, None
+
+    # ----------------------------------------------------------------------------- t-independent stage
+    def _flow_encoder(self, x):
+        fp = self.flow_process
+        y = fp[1](fp[0](x), act=LRELU)
+        for i in range(3, 8):
+            y = fp[i](y, act=LRELU if i == 7 else NONE)
+        return fp[9](y)
+
+    def _clip_stage(self, x, HH, WW, iters):
+        """Everything of `Ours.py:514-638` + the `imnet` branch of 699-737 that does not depend on t."""
+        B, n = x.shape[0], x.shape[1]
+        H, W = x.shape[3], x.shape[4]
+        fr0, fr1 = x[:, n // 2 - 1], x[:, n // 2]                              # centre pair, [B,3,H,W] views
+        pair = torch.stack([fr0, fr1], dim=1)                                   # [B,2,3,H,W]
+        hr = ops.resize_bilinear(pair.reshape(B * 2, 3, H, W), (HH, WW), False).view(B, 2, 3, HH, WW)
+        a, b = hr[:, 0], hr[:, 1]
+        if self.skip_zero_pairs:
+            i1 = torch.cat([a, b], 0) * 255.0                                   # pairs 01, 10
+            i2 = torch.cat([b, a], 0) * 255.0
+            f = self.flow_predictor(i1, i2, iters=iters, last_only=True)[-1]
+            f = ops.resize_bilinear(f, (H, W), False, H / HH)
+            flow = torch.zeros(4 * B, 2, H, W, dtype=torch.float32, device=x.device)
+            flow[B:3 * B].copy_(f)
+        else:
+            i1 = torch.cat([a, a, b, b], 0) * 255.0
+            i2 = torch.cat([a, b, a, b], 0) * 255.0
+            f = self.flow_predictor(i1, i2, iters=iters, last_only=True)[-1]
+            flow = ops.resize_bilinear(f, (H, W), False, H / HH)
+            flow[:B] *= 0.0
+            flow[3 * B:] *= 0.0
+        psies, flow_feat_in = ops.reliability(fr0, fr1, flow, self.g_filter, B, H, W)
+        feat = self.encoder(pair, None)                                        # [B,3,64,H,W]
+        residual = feat[:, 1].contiguous()
+        feat01 = torch.cat((feat[:, 0], feat[:, 2]), 0)                         # [2B,64,H,W]
+        flow_feat = self._flow_encoder(flow_feat_in)                            # [2B,64,H,W]
+        iy, ix, rel_y, rel_x = gather_tables(H, W, HH, WW, x.device)
+        imnet_out = ops.siren_imnet(self.imnet.packed(), feat01, iy, ix, rel_y, rel_x, HH, WW)
+        return dict(flow=flow, psies=psies, flow_feat_in=flow_feat_in, feat=feat, residual=residual, feat01=feat01,
+                    flow_feat=flow_feat, imnet_out=imnet_out, tables=(iy, ix, rel_y, rel_x))
+
+    def clear_cache(self):
+        self._cache_key, self._cache = None, None
+
+    # ----------------------------------------------------------------------------- forward
+    def forward(self, x, input_target_frames, target_t, scale=None, rank=0, train_idx=0, use_GT=True, iter=12, flows=None,
+                stages=None):
+        if self.training or use_GT:
+            raise NotImplementedError("this is the inference path (VideoSR_base_model.py:189: use_GT=False, eval mode)")
+        if not x.is_cuda:
+            raise RuntimeError("LunaTokis runs on the MI355X HIP kernels only; move inputs to 'cuda'")
+        x = x.float()
+        B, _, _, H, W = x.shape
+        target_t = torch.stack(list(target_t), 1).squeeze(-1).to(x.device).float().reshape(B, -1)
+        N = target_t.shape[1]
+        if isinstance(scale, list):
+            HH, WW = int(scale[0][0]), int(scale[1][0])
+        else:
+            HH, WW = round(H * scale), round(W * scale)
+        # the cached clip tensor is kept alive, so its address cannot be recycled for another clip
+        key = (x.data_ptr(), x._version, tuple(x.shape), HH, WW, iter)
+        if key != self._cache_key:
+            self._cache, self._cache_key = self._clip_stage(x, HH, WW, iter), key
+            self._cache["x"] = x
+        c = self._cache
+        iy, ix, rel_y, rel_x = c["tables"]
+        times = target_t.contiguous()                                           # [B,N]
+        pred = ops.siren_flow(self.flow_imnet.packed(), c["flow_feat"], iy, ix, rel_y, rel_x, times, N, HH, WW)   # [2BN,3,HH,WW]
+        acc = ops.splat_motif(c["imnet_out"], pred, c["feat01"], iy, ix, self.alpha, HH / H, B, N, HH, WW)
+        frames = ops.siren_synth(self.synth_net.packed(), acc, c["residual"], iy, ix, times, B, N, HH, WW)
+        if stages is not None:
+            stages.update(c)
+            stages.update(pred=pred, acc=acc)
+        flow_hr = pred[:, :2] * 20.0 * (HH / H)
+        return frames, flow_hr / 20.0 / (HH / H), 0

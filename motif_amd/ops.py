@@ -1,0 +1,394 @@
+"""Tensor-level wrappers over the C ABI (include/motif_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every computation below is a
+hand-written HIP kernel in libmotif_hip.so.  All tensors must be CUDA (ROCm) fp32; there is no CPU or
+eager fallback -- a missing library or a non-GPU tensor raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import MotifConvDesc, check
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype not in (torch.float32, torch.int32):
+        raise RuntimeError("motif_amd ops need CUDA(ROCm) fp32/int32 tensors, got %s %s" % (t.device, t.dtype))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _planar(t):
+    """True if t is [N,C,H,W] with dense C,H,W (batch stride free)."""
+    n, c, h, w = t.shape
+    return t.stride(3) == 1 and t.stride(2) == w and t.stride(1) == h * w
+
+
+# ----------------------------------------------------------------------------------------- conv engine
+class ConvPlan:
+    """Packed weights of one convolution layer, re-packed when the parameter changes."""
+
+    def __init__(self, weight, bias, stride=1, pad=0, dil=1, groups=1, pad_mode=0):
+        self.weight, self.bias = weight, bias
+        self.stride, self.pad, self.dil, self.groups, self.pad_mode = stride, pad, dil, groups, pad_mode
+        self._packed = None
+        self._key = None
+
+    def desc(self, n, h, w, c0, c1=0):
+        co, _, kh, kw = self.weight.shape
+        d = MotifConvDesc()
+        d.N, d.H, d.W, d.C0, d.C1 = n, h, w, c0, c1
+        d.Cout, d.KH, d.KW = co, kh, kw
+        d.stride, d.pad, d.dil, d.groups, d.pad_mode = self.stride, self.pad, self.dil, self.groups, self.pad_mode
+        return d
+
+    def packed(self):
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if self._key != key:
+            lib = _lib.load()
+            d = self.desc(1, 64, 64, w.shape[1] * self.groups)
+            size = lib.motif_conv2d_packed_size(ctypes.byref(d))
+            if size <= 0:
+                raise RuntimeError("motif_conv2d_packed_size failed (%d) for weight %s" % (size, tuple(w.shape)))
+            buf = torch.empty(size, dtype=torch.float32, device=w.device)
+            wc = _c(w.detach())
+            check(lib.motif_conv2d_pack(ctypes.byref(d), _p(wc), _p(buf), _stream()), "motif_conv2d_pack")
+            self._packed, self._key = buf, key
+        return self._packed
+
+
+def conv2d(plan, x, x2=None, act=ACT_NONE, res=None, res_mode=0, act2=ACT_NONE, act_split=0, out=None):
+    """out = epilogue(conv(cat(x, x2))) through the fp32-MFMA implicit GEMM."""
+    lib = _lib.load()
+    if not _planar(x):
+        x = x.contiguous()
+    if x2 is not None and not _planar(x2):
+        x2 = x2.contiguous()
+    n, c0, h, w = x.shape
+    c1 = x2.shape[1] if x2 is not None else 0
+    d = plan.desc(n, h, w, c0, c1)
+    d.act, d.act2, d.act_split, d.res_mode = act, act2, act_split, res_mode
+    kh, kw = plan.weight.shape[2:]
+    ho = (h + 2 * plan.pad - (plan.dil * (kh - 1) + 1)) // plan.stride + 1
+    wo = (w + 2 * plan.pad - (plan.dil * (kw - 1) + 1)) // plan.stride + 1
+    co = plan.weight.shape[0]
+    if out is None:
+        out = torch.empty(n, co, ho, wo, dtype=torch.float32, device=x.device)
+    elif not _planar(out) or tuple(out.shape) != (n, co, ho, wo):
+        raise RuntimeError("conv2d: bad `out` view")
+    d.in0_bs = x.stride(0)
+    d.in1_bs = x2.stride(0) if x2 is not None else 0
+    d.out_bs = out.stride(0)
+    if res is not None:
+        if not _planar(res):
+            res = res.contiguous()
+        d.res_bs = res.stride(0)
+    bias = plan.bias.detach() if plan.bias is not None else None
+    check(lib.motif_conv2d_fwd(ctypes.byref(d), _p(x), _p(x2), _p(plan.packed()), _p(bias), _p(res), _p(out), _stream()),
+          "motif_conv2d_fwd")
+    return out
+
+
+class DcnPlan:
+    """DCNv2 main weight viewed as a 1x1 conv over C*kh*kw column channels."""
+
+    def __init__(self, weight, bias):
+        self.weight, self.bias = weight, bias
+        self._plan, self._key = None, None
+
+    def plan(self):
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if self._key != key:
+            co, ci, kh, kw = w.shape
+            self._w1x1 = w.detach().reshape(co, ci * kh * kw, 1, 1)
+            self._plan = ConvPlan(self._w1x1, self.bias)
+            self._key = key
+        return self._plan
+
+
+_ws = {}
+
+
+def workspace(numel, device, tag="default"):
+    key = (tag, str(device))
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < numel:
+        buf = torch.empty(numel, dtype=torch.float32, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def dcn_v2(dplan, x, offset_mask, dg=8, act=ACT_NONE, kh=3, kw=3, stride=1, pad=1, dil=1):
+    """x [B,C,H,W]; offset_mask [B, 3*dg*kh*kw, Ho, Wo] = conv_offset_mask output with the mask third
+    already sigmoid'ed (chunk/cat of dcn_v2.py:131-138 is a no-op on the channel order)."""
+    lib = _lib.load()
+    x = _c(x)
+    offset_mask = _c(offset_mask)
+    b, c, h, w = x.shape
+    co = dplan.weight.shape[0]
+    ho = (h + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+    wo = (w + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    t = kh * kw
+    cols = workspace(b * c * t * ho * wo, x.device, "dcn_cols")
+    out = torch.empty(b, co, ho, wo, dtype=torch.float32, device=x.device)
+    plan = dplan.plan()
+    mask = offset_mask[:, 2 * dg * t:]
+    bs = offset_mask.stride(0)
+    bias = dplan.bias.detach() if dplan.bias is not None else None
+    check(lib.motif_dcn_v2_fwd(_p(x), _p(offset_mask), ctypes.c_void_p(mask.data_ptr()), _p(plan.packed()), _p(bias), _p(cols), _p(out),
+                               b, c, h, w, co, kh, kw, stride, pad, dil, dg, bs, bs, act, _stream()), "motif_dcn_v2_fwd")
+    return out
+
+
+def dcn_v2_raw(x, offset, mask, weight, bias, kh, kw, stride, pad, dil, dg, act=ACT_NONE):
+    """Operator form of _ext.dcn_v2_forward (separate offset / mask tensors)."""
+    lib = _lib.load()
+    x, offset, mask = _c(x), _c(offset), _c(mask)
+    b, c, h, w = x.shape
+    co = weight.shape[0]
+    ho = (h + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+    wo = (w + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    cols = workspace(b * c * kh * kw * ho * wo, x.device, "dcn_cols")
+    out = torch.empty(b, co, ho, wo, dtype=torch.float32, device=x.device)
+    plan = ConvPlan(weight.detach().reshape(co, c * kh * kw, 1, 1), bias)
+    check(lib.motif_dcn_v2_fwd(_p(x), _p(offset), _p(mask), _p(plan.packed()), _p(bias.detach() if bias is not None else None),
+                               _p(cols), _p(out), b, c, h, w, co, kh, kw, stride, pad, dil, dg, 0, 0, act, _stream()),
+          "motif_dcn_v2_fwd")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- SIREN
+def siren_pack(linears):
+    """linears: list of (weight [out,in], bias [out]) device tensors -> packed blob tensor."""
+    lib = _lib.load()
+    n = len(linears)
+    ws = [_c(w.detach()) for w, _ in linears]
+    bs = [_c(b.detach()) for _, b in linears]
+    dims = [ws[0].shape[1]] + [w.shape[0] for w in ws]
+    wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+    bp = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bs])
+    dm = (ctypes.c_int * (n + 1))(*dims)
+    total = lib.motif_siren_pack(wp, bp, dm, n, None, None)
+    if total <= 0:
+        raise RuntimeError("motif_siren_pack size query failed (%d)" % total)
+    blob = torch.empty(total, dtype=torch.float32, device=ws[0].device)
+    rc = lib.motif_siren_pack(wp, bp, dm, n, _p(blob), _stream())
+    if rc != total:
+        raise RuntimeError("motif_siren_pack failed (%d)" % rc)
+    return blob
+
+
+def siren_imnet(blob, feat_lr, iy, ix, rel_y, rel_x, HH, WW):
+    lib = _lib.load()
+    feat_lr = _c(feat_lr)
+    b2, c, h, w = feat_lr.shape
+    out = torch.empty(b2, 64, HH, WW, dtype=torch.float32, device=feat_lr.device)
+    check(lib.motif_siren_imnet_fwd(_p(blob), _p(feat_lr), _p(iy), _p(ix), _p(rel_y), _p(rel_x), _p(out),
+                                    b2, h, w, HH, WW, _stream()), "motif_siren_imnet_fwd")
+    return out
+
+
+def siren_flow(blob, flowfeat_lr, iy, ix, rel_y, rel_x, times, N, HH, WW):
+    lib = _lib.load()
+    flowfeat_lr = _c(flowfeat_lr)
+    b2, c, h, w = flowfeat_lr.shape
+    pred = torch.empty(b2 * N, 3, HH, WW, dtype=torch.float32, device=flowfeat_lr.device)
+    check(lib.motif_siren_flow_fwd(_p(blob), _p(flowfeat_lr), _p(iy), _p(ix), _p(rel_y), _p(rel_x), _p(_c(times)), _p(pred),
+                                   b2, N, h, w, HH, WW, _stream()), "motif_siren_flow_fwd")
+    return pred
+
+
+def siren_synth(blob, acc, residual_lr, iy, ix, times, B, N, HH, WW):
+    lib = _lib.load()
+    residual_lr = _c(residual_lr)
+    _, _, h, w = residual_lr.shape
+    frames = torch.empty(N, B, 3, HH, WW, dtype=torch.float32, device=acc.device)
+    check(lib.motif_siren_synth_fwd(_p(blob), _p(acc), _p(residual_lr), _p(iy), _p(ix), _p(_c(times)), _p(frames),
+                                    B, N, h, w, HH, WW, _stream()), "motif_siren_synth_fwd")
+    return frames
+
+
+def synth_input(acc, residual_lr, iy, ix, times, B, N, HH, WW):
+    lib = _lib.load()
+    residual_lr = _c(residual_lr)
+    _, _, h, w = residual_lr.shape
+    out = torch.empty(B * N, 198, HH, WW, dtype=torch.float32, device=acc.device)
+    check(lib.motif_synth_input_fwd(_p(acc), _p(residual_lr), _p(iy), _p(ix), _p(_c(times)), _p(out), B, N, h, w, HH, WW, _stream()),
+          "motif_synth_input_fwd")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- splat
+def splat(src, flow, z=None, want=("sum", "norm")):
+    """Operator form.  Returns dict with the requested outputs among sum/norm/max/cnt."""
+    lib = _lib.load()
+    flow = _c(flow)
+    n, _, h, w = flow.shape
+    src = _c(src) if src is not None else None
+    c = src.shape[1] if src is not None else 1
+    dev = flow.device
+    outs = {
+        "sum": torch.zeros(n, c, h, w, device=dev) if "sum" in want else None,
+        "norm": torch.zeros(n, 1, h, w, device=dev) if "norm" in want else None,
+        "max": torch.ones(n, 1, h, w, device=dev) if "max" in want else None,
+        "cnt": torch.zeros(n, 1, h, w, device=dev) if "cnt" in want else None,
+    }
+    check(lib.motif_splat_fwd(_p(src), _p(flow), _p(_c(z)) if z is not None else None, _p(outs["sum"]), _p(outs["norm"]),
+                              _p(outs["max"]), _p(outs["cnt"]), n, c, h, w, _stream()), "motif_splat_fwd")
+    return outs
+
+
+def splat_motif(imnet_out, pred, feat_lr, iy, ix, alpha, flow_scale, B, N, HH, WW, acc=None):
+    lib = _lib.load()
+    feat_lr = _c(feat_lr)
+    _, _, h, w = feat_lr.shape
+    if acc is None:
+        acc = torch.empty(B * N, 133, HH, WW, dtype=torch.float32, device=pred.device)
+    acc.zero_()
+    acc[:, 131].fill_(1.0)
+    check(lib.motif_splat_motif_fwd(_p(imnet_out), _p(pred), _p(feat_lr), _p(iy), _p(ix), _p(alpha.detach()), float(flow_scale), _p(acc),
+                                    B, N, h, w, HH, WW, _stream()), "motif_splat_motif_fwd")
+    return acc
+
+
+# ----------------------------------------------------------------------------------------- misc
+def resize_bilinear(x, size, align_corners=False, mul=1.0):
+    lib = _lib.load()
+    x = _c(x)
+    n, c, h, w = x.shape
+    ho, wo = size
+    out = torch.empty(n, c, ho, wo, dtype=torch.float32, device=x.device)
+    check(lib.motif_resize_bilinear(_p(x), _p(out), n * c, h, w, ho, wo, int(align_corners), float(mul), _stream()), "motif_resize_bilinear")
+    return out
+
+
+def backwarp(img, flow, sign=1.0):
+    lib = _lib.load()
+    img, flow = _c(img), _c(flow)
+    n, c, h, w = img.shape
+    out = torch.empty_like(img)
+    check(lib.motif_backwarp(_p(img), _p(flow), _p(out), n, c, h, w, float(sign), _stream()), "motif_backwarp")
+    return out
+
+
+_linspace_cache = {}
+
+
+def pwc_backward_warp(img, flow):
+    lib = _lib.load()
+    img, flow = _c(img), _c(flow)
+    n, c, h, w = img.shape
+    key = (h, w, str(img.device))
+    if key not in _linspace_cache:
+        _linspace_cache[key] = (torch.linspace(-1.0, 1.0, w).to(img.device), torch.linspace(-1.0, 1.0, h).to(img.device))
+    gx, gy = _linspace_cache[key]
+    out = torch.empty_like(img)
+    check(lib.motif_pwc_backward_warp(_p(img), _p(flow), _p(gx), _p(gy), _p(out), n, c, h, w, _stream()), "motif_pwc_backward_warp")
+    return out
+
+
+def reliability(fr0, fr1, flow, g_filter, B, H, W):
+    """fr0/fr1: [B,3,H,W] views (channel/row dense, any batch stride); flow [4B,2,H,W]."""
+    lib = _lib.load()
+    if not (_planar(fr0) and _planar(fr1) and fr0.stride(0) == fr1.stride(0)):
+        fr0, fr1 = fr0.contiguous(), fr1.contiguous()
+    flow = _c(flow)
+    psies = torch.empty(4 * B, 3, H, W, dtype=torch.float32, device=flow.device)
+    flow_feat = torch.empty(2 * B, 14, H, W, dtype=torch.float32, device=flow.device)
+    check(lib.motif_reliability_fwd(_p(fr0), _p(fr1), fr0.stride(0), _p(flow), _p(_c(g_filter.detach())), _p(psies), _p(flow_feat),
+                                    B, H, W, _stream()), "motif_reliability_fwd")
+    return psies, flow_feat
+
+
+def instance_norm(x, mode=0, res=None):
+    lib = _lib.load()
+    x = _c(x)
+    n, c, h, w = x.shape
+    out = torch.empty_like(x)
+    check(lib.motif_instance_norm(_p(x), _p(_c(res)) if res is not None else None, _p(out), n * c, h * w, mode, _stream()), "motif_instance_norm")
+    return out
+
+
+def avg_pool2(x):
+    lib = _lib.load()
+    x = _c(x)
+    n, c, h, w = x.shape
+    out = torch.empty(n, c, h // 2, w // 2, dtype=torch.float32, device=x.device)
+    check(lib.motif_avg_pool2(_p(x), _p(out), n * c, h, w, _stream()), "motif_avg_pool2")
+    return out
+
+
+def nchw_to_nhwc(x):
+    lib = _lib.load()
+    x = _c(x)
+    n, c, h, w = x.shape
+    out = torch.empty(n, h, w, c, dtype=torch.float32, device=x.device)
+    check(lib.motif_nchw_to_nhwc(_p(x), _p(out), n, c, h * w, _stream()), "motif_nchw_to_nhwc")
+    return out
+
+
+def raft_corr_lookup(fmap1_nhwc, fmap2_nhwc, coords, coord_scale, out, ch_off, div, r=3):
+    lib = _lib.load()
+    b, h1, w1, c = fmap1_nhwc.shape
+    _, h2, w2, _ = fmap2_nhwc.shape
+    check(lib.motif_raft_corr_lookup(_p(fmap1_nhwc), _p(fmap2_nhwc), _p(_c(coords)), float(coord_scale), _p(out),
+                                     b, h1, w1, h2, w2, c, r, out.shape[1], ch_off, float(div), _stream()), "motif_raft_corr_lookup")
+    return out
+
+
+def corr81(first, second, act=ACT_NONE):
+    lib = _lib.load()
+    first, second = _c(first), _c(second)
+    b, c, h, w = first.shape
+    out = torch.empty(b, 81, h, w, dtype=torch.float32, device=first.device)
+    check(lib.motif_corr81_fwd(_p(first), _p(second), _p(out), b, c, h, w, act, _stream()), "motif_corr81_fwd")
+    return out
+
+
+def gru_update(z, q, h):
+    lib = _lib.load()
+    out = torch.empty_like(h)
+    check(lib.motif_gru_update(_p(_c(z)), _p(_c(q)), _p(_c(h)), _p(out), h.numel(), _stream()), "motif_gru_update")
+    return out
+
+
+def lstm_gates(cc, c_cur):
+    lib = _lib.load()
+    cc, c_cur = _c(cc), _c(c_cur)
+    b, c4, h, w = cc.shape
+    h_next, c_next = torch.empty_like(c_cur), torch.empty_like(c_cur)
+    check(lib.motif_lstm_gates(_p(cc), _p(c_cur), _p(h_next), _p(c_next), b, c4 // 4, h * w, _stream()), "motif_lstm_gates")
+    return h_next, c_next
+
+
+def axpby(x, y=None, a=1.0, b=1.0):
+    lib = _lib.load()
+    x = _c(x)
+    out = torch.empty_like(x)
+    check(lib.motif_axpby(_p(x), _p(_c(y)) if y is not None else None, float(a), float(b), _p(out), x.numel(), _stream()), "motif_axpby")
+    return out
+
+
+def deconv4x4s2(x, weight, bias):
+    lib = _lib.load()
+    x = _c(x)
+    n, ci, h, w = x.shape
+    co = weight.shape[1]
+    out = torch.empty(n, co, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
+    check(lib.motif_deconv4x4s2(_p(x), _p(_c(weight.detach())), _p(bias.detach()) if bias is not None else None, _p(out),
+                                n, ci, co, h, w, _stream()), "motif_deconv4x4s2")
+    return out

@@ -1,0 +1,180 @@
+"""CPU: host-side logic of the boundary -- state-dict compatibility, gather tables, shell chunking,
+checkpoint plumbing, metrics, options, clip sharding over gloo (world_size 2)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_product_state_dict_keys_match_reference():
+    from motif_amd.models.modules.Ours import LunaTokis
+    keys = json.load(open(os.path.join(GOLD, "state_dict_keys.json")))
+    sd = LunaTokis().state_dict()
+    assert set(sd) == set(keys)
+    assert all(list(sd[k].shape) == keys[k] for k in keys)
+    from motif_amd.OpticalFlow.PWCNet import PWCNet
+    pk = json.load(open(os.path.join(GOLD, "pwc_state_dict_keys.json")))
+    psd = PWCNet().state_dict()
+    assert set(psd) == set(pk) and all(list(psd[k].shape) == pk[k] for k in pk)
+
+
+@pytest.mark.parametrize("dims", [(32, 32, 128, 128), (64, 64, 128, 128), (45, 80, 180, 320), (24, 40, 60, 100), (20, 28, 56, 72)])
+def test_gather_tables_are_the_literal_nearest_gather(dims):
+    """iy/ix/rel tables == what the reference's full 2-D grid_sample(nearest) + rel_coord arithmetic gives
+    (Ours.py:667-722), bit-exact; integer scales pick (i//s, j//s)."""
+    from motif_amd.models.modules.Ours import gather_tables, make_coord
+    H, W, HH, WW = dims
+    iy, ix, rel_y, rel_x = gather_tables(H, W, HH, WW, "cpu")
+    hr = make_coord((HH, WW)).unsqueeze(0)
+    coord_ = hr.clone()
+    coord_ += 1e-6
+    coord_.clamp_(-1 + 1e-6, 1 - 1e-6)
+    idx_img = torch.arange(H * W, dtype=torch.float32).view(1, 1, H, W)
+    feat_coord = make_coord((H, W), flatten=False).permute(2, 0, 1).unsqueeze(0)
+    g = F.grid_sample(torch.cat([idx_img, feat_coord], 1), coord_.flip(-1).unsqueeze(1), mode="nearest", align_corners=False)[:, :, 0, :]
+    lin = g[0, 0].long().view(HH, WW)
+    assert torch.equal(lin, iy.long()[:, None] * W + ix.long()[None, :])
+    rel = hr - g[:, 1:3].permute(0, 2, 1)
+    rel[:, :, 0] *= H
+    rel[:, :, 1] *= W
+    rel = rel.view(HH, WW, 2)
+    assert torch.equal(rel[..., 0], rel_y[:, None].expand(HH, WW))
+    assert torch.equal(rel[..., 1], rel_x[None, :].expand(HH, WW))
+    if HH % H == 0 and WW % W == 0:
+        assert torch.equal(iy.long(), torch.arange(HH) // (HH // H)) and torch.equal(ix.long(), torch.arange(WW) // (WW // W))
+
+
+class FakeNet(torch.nn.Module):
+    """Records the chunks VideoSRBaseModel.test issues; output frame value = its timestamp."""
+
+    def __init__(self):
+        super().__init__()
+        self.p = torch.nn.Parameter(torch.zeros(1))
+        self.calls = []
+
+    def forward(self, x, gt, times, scale, use_GT=True, iter=12):
+        self.calls.append(([float(t[0, 0]) for t in times], gt is not None, use_GT, iter, self.training))
+        return torch.stack([t.view(-1, 1, 1, 1).expand(x.shape[0], 3, 8, 8) for t in times], 0), torch.zeros(1), 0
+
+
+def make_model(monkeypatch, tmp_path, ckpt=None):
+    from motif_amd.models import create_model, networks
+    from motif_amd.option import default_opt
+    monkeypatch.setattr(networks, "define_G", lambda opt: FakeNet())
+    opt = default_opt(scale=4, gpu_ids=None, pretrain_model_G=ckpt)
+    opt["path"]["models"] = str(tmp_path)
+    return create_model(opt)
+
+
+def test_shell_chunks_timestamps_in_threes(monkeypatch, tmp_path):
+    m = make_model(monkeypatch, tmp_path)
+    T = 7
+    data = {"LQs": torch.zeros(1, 4, 3, 8, 8), "GT": torch.zeros(1, T + 2, 3, 32, 32), "time": [torch.full((1, 1), i / 6) for i in range(T)]}
+    m.feed_data(data)
+    assert m.scale == 4 and m.device.type == "cpu"
+    m.test()
+    calls = m.netG.calls
+    assert [len(c[0]) for c in calls] == [3, 3, 1]
+    assert calls[0][1] and not calls[1][1]                 # real_H only on the first chunk (VideoSR_base_model.py:189-191)
+    assert all(c[2] is False and c[3] == 4 and c[4] is False for c in calls)   # use_GT=False, iter=4, eval mode inside
+    assert m.netG.training                                  # left in train() mode (:198)
+    assert m.fake_H.shape == (7, 1, 3, 8, 8)
+    assert np.allclose(m.fake_H[:, 0, 0, 0, 0].numpy(), np.arange(7) / 6)
+    assert m.get_current_learning_rate() == [0.0]
+    data["scale"] = [[16], [16]]
+    m.feed_data(data)
+    assert m.scale == [[16], [16]]
+
+
+def test_checkpoint_formats_load(monkeypatch, tmp_path):
+    """base_model.py:89-101: plain dict, {'params': ...} wrapper and 'module.' prefixes all load."""
+    from motif_amd.models.modules.Ours import LunaTokis
+    from motif_amd.utils.synth_weights import fill_state_dict, synth_state_dict
+    keys = json.load(open(os.path.join(GOLD, "state_dict_keys.json")))
+    sd = synth_state_dict(keys)
+    p1, p2 = str(tmp_path / "best.pth"), str(tmp_path / "wrapped.pth")
+    torch.save(sd, p1)
+    torch.save({"params": {"module." + k: v for k, v in sd.items()}}, p2)
+    from motif_amd.models import create_model
+    from motif_amd.option import default_opt
+    for p in (p1, p2):
+        m = create_model(default_opt(gpu_ids=None, pretrain_model_G=p))
+        got = m.netG.state_dict()
+        assert all(torch.equal(got[k], sd[k]) for k in sd)
+    ref = fill_state_dict(LunaTokis()).state_dict()
+    assert all(torch.equal(ref[k], sd[k]) for k in sd)
+    m.opt["path"]["models"] = str(tmp_path)
+    m.save("latest")
+    assert os.path.exists(str(tmp_path / "latest_G.pth"))
+
+
+def test_metrics():
+    from motif_amd.utils import util
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(2, 3, 24, 24, generator=g)
+    b = (a + 0.01 * torch.randn(2, 3, 24, 24, generator=g)).clamp(0, 1)
+    p = util.y_psnr_per_frame(a, b)
+    y = lambda x: ((x[:, 0] * 255 * 65.481 + x[:, 1] * 255 * 128.553 + x[:, 2] * 255 * 24.966) / 255.0 + 16.0) / 255.0
+    ref = 10 * np.log10(1.0 / ((y(a) - y(b)) ** 2).reshape(2, -1).mean(1).numpy())
+    assert np.allclose(p, ref, atol=1e-4)
+    img = (a[0, 0].numpy() * 255)
+    assert util.calculate_psnr(img, img) == float("inf")
+    assert abs(util.ssim(img, img) - 1.0) < 1e-12
+    from scipy.ndimage import correlate
+    w = util._gauss_window()
+    assert np.allclose(util._valid_filter(img, w), correlate(img.astype(np.float64), w, mode="reflect")[5:-5, 5:-5])
+    assert 0 < util.calculate_ssim(np.stack([img] * 3, -1), np.stack([b[0, 0].numpy() * 255] * 3, -1)) < 1
+
+
+def test_option_parse_accepts_cpu_and_keeps_root(tmp_path):
+    from motif_amd import option
+    y = tmp_path / "t.yml"
+    y.write_text("name: t\nmodel: VideoSR_base\ndistortion: sr\nscale: 2\ngpu_ids: ~\nnetwork_G:\n  which_model_G: Ours\n  setting: 5\n"
+                 "path:\n  pretrain_model_G: ~\n  strict_load: true\n  root: %s\ndatasets:\n  train:\n    name: x\n    mode: y\n" % tmp_path)
+    opt = option.dict_to_nonedict(option.parse(str(y), is_train=True))
+    assert opt["gpu_ids"] is None and opt["network_G"]["scale"] == 2 and opt["path"]["root"] == str(tmp_path)
+    assert opt["datasets"]["train"]["scale"] == 2 and opt["nothing"] is None
+
+
+def test_synthetic_sample_contract():
+    from motif_amd.data.synthetic import synthetic_sample
+    s = synthetic_sample(16, 24, 4, 7, batch=2)
+    assert s["LQs"].shape == (2, 4, 3, 16, 24) and s["GT"].shape == (2, 9, 3, 64, 96)
+    assert len(s["time"]) == 7 and s["time"][0].shape == (2, 1)
+    assert abs(float(s["time"][3][0, 0]) - 0.5) < 1e-7 and float(s["LQs"].min()) >= 0 and float(s["LQs"].max()) <= 1
+    assert torch.equal(s["LQs"], synthetic_sample(16, 24, 4, 7, batch=2)["LQs"])
+
+
+def test_clip_sharding_and_gather_over_gloo_world2(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text('''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from motif_amd import dist as md
+dist.init_process_group("gloo")
+r, w = md.world()
+n = 5
+idx = md.shard_indices(n)
+local = torch.stack([torch.full((2, 3), float(i)) for i in idx]) if idx else torch.zeros(0, 2, 3)
+u8 = md.frames_to_uint8(local / 255.0)
+out = md.gather_to_rank0(u8, n)
+if r == 0:
+    assert out.shape == (n, 2, 3) and out.dtype == torch.uint8
+    assert [int(out[i, 0, 0]) for i in range(n)] == list(range(n)), out[:, 0, 0]
+    print("GATHER_OK", idx)
+else:
+    assert out is None and idx == [1, 3]
+dist.destroy_process_group()
+''' % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "GATHER_OK [0, 2, 4]" in r.stdout, r.stdout + r.stderr

@@ -1,0 +1,388 @@
+"""GPU parity tests, one per C-ABI kernel family: HIP path vs the CPU oracle / torch CPU on seeded inputs.
+
+Bit-exact where the domain is integer/index (splat count & max, corner indices), fp32 tolerance stated
+per test elsewhere.  All calls go through the C ABI (motif_amd.ops -> libmotif_hip.so).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def close(a, b, atol, rtol=0.0, what=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bad.any(), "%s: max|diff|=%.3e (tol %.1e) at %d/%d elements, ref max %.3e" % (
+        what, err.max().item(), atol, int(bad.sum()), bad.numel(), b.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------- conv engine
+CONV_CASES = [
+    # cin, cout, k, stride, pad, dil, groups, pad_mode, H, W, N
+    (64, 64, 3, 1, 1, 1, 1, "zeros", 45, 80, 1),
+    (64, 64, 3, 2, 1, 1, 1, "zeros", 46, 84, 2),
+    (3, 64, 3, 1, 1, 1, 1, "zeros", 33, 47, 1),
+    (128, 64, 1, 1, 0, 1, 1, "zeros", 20, 40, 1),
+    (3, 32, 7, 2, 3, 1, 1, "zeros", 64, 96, 2),
+    (14, 64, 3, 1, 1, 1, 2, "zeros", 32, 32, 2),
+    (64, 64, 3, 1, 1, 1, 2, "zeros", 19, 33, 1),
+    (64, 64, 3, 1, 1, 1, 1, "reflect", 32, 40, 1),
+    (64, 216, 3, 1, 1, 1, 1, "zeros", 24, 32, 1),
+    (128, 256, 3, 1, 1, 1, 1, "zeros", 16, 32, 1),
+    (96, 128, 3, 1, 1, 1, 1, "zeros", 16, 20, 1),
+    (242, 96, 3, 1, 1, 1, 1, "zeros", 16, 24, 1),
+    (196, 96, 1, 1, 0, 1, 1, "zeros", 16, 24, 1),
+    (2, 64, 7, 1, 3, 1, 1, "zeros", 16, 24, 1),
+    (128, 2, 3, 1, 1, 1, 1, "zeros", 16, 24, 1),
+    (32, 8, 1, 1, 0, 1, 1, "zeros", 40, 64, 1),
+    (8, 8, 3, 2, 1, 1, 1, "zeros", 40, 64, 1),
+    (32, 64, 1, 2, 0, 1, 1, "zeros", 40, 64, 1),
+    (128, 128, 3, 1, 2, 2, 1, "zeros", 24, 32, 1),
+    (96, 64, 3, 1, 16, 16, 1, "zeros", 24, 40, 1),
+    (565, 128, 3, 1, 1, 1, 1, "zeros", 12, 20, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv2d_matches_torch_cpu(case):
+    from motif_amd.models.modules.layers import Conv2d
+    cin, cout, k, stride, pad, dil, groups, pm, H, W, N = case
+    m = Conv2d(cin, cout, k, stride, pad, dil, groups, True, pm)
+    with torch.no_grad():
+        m.weight.copy_(rnd(*m.weight.shape, seed=1, scale=1.0 / math.sqrt(cin * k * k / groups)))
+        m.bias.copy_(rnd(cout, seed=2, scale=0.1))
+    x = rnd(N, cin, H, W, seed=3)
+    xp = F.pad(x, (pad,) * 4, mode="reflect") if pm == "reflect" else x
+    ref = F.conv2d(xp, m.weight, m.bias, stride, 0 if pm == "reflect" else pad, dil, groups)
+    m = m.to(dev())
+    out = m(x.to(dev()))
+    close(out, ref, 2e-5, 2e-5, "conv")
+
+
+def test_conv2d_fused_epilogues_and_concat():
+    from motif_amd import ops
+    from motif_amd.models.modules.layers import Conv2d
+    m = Conv2d(96 + 40, 80, 3, 1, 1)
+    with torch.no_grad():
+        m.weight.copy_(rnd(*m.weight.shape, seed=1, scale=0.05))
+        m.bias.copy_(rnd(80, seed=2, scale=0.1))
+    a, b = rnd(2, 96, 20, 36, seed=3), rnd(2, 40, 20, 36, seed=4)
+    res = rnd(2, 80, 20, 36, seed=5)
+    base = F.conv2d(torch.cat([a, b], 1), m.weight, m.bias, 1, 1)
+    m = m.to(dev())
+    ad, bd, rd = a.to(dev()), b.to(dev()), res.to(dev())
+    close(m(ad, bd, act=ops.ACT_LRELU), F.leaky_relu(base, 0.1), 2e-5, 2e-5, "concat+lrelu")
+    close(m(ad, bd, act=ops.ACT_SIGMOID), torch.sigmoid(base), 2e-6, 0, "sigmoid")
+    close(m(ad, bd, act=ops.ACT_TANH), torch.tanh(base), 2e-6, 0, "tanh")
+    close(m(ad, bd, res=rd, res_mode=1), base + res, 2e-5, 2e-5, "res add")
+    close(m(ad, bd, act=ops.ACT_RELU, res=rd, res_mode=3), F.relu(F.relu(base) + res), 2e-5, 2e-5, "relu(relu+res)")
+    close(m(ad, bd, act=ops.ACT_SIGMOID, res=rd, res_mode=4), torch.sigmoid(base) * res, 2e-6, 0, "sigmoid*res")
+    split = torch.cat([torch.tanh(base[:, :48]), F.relu(base[:, 48:])], 1)
+    close(m(ad, bd, act=ops.ACT_TANH, act2=ops.ACT_RELU, act_split=48), split, 2e-5, 2e-5, "act split")
+    # strided batch views in and out
+    big = torch.zeros(2, 3, 96, 20, 36, device=dev())
+    big[:, 1] = ad
+    outbuf = torch.zeros(2, 100, 20, 36, device=dev())
+    m(big[:, 1], bd, out=outbuf[:, 10:90])
+    close(outbuf[:, 10:90], base, 2e-5, 2e-5, "strided views")
+    assert float(outbuf[:, :10].abs().max()) == 0 and float(outbuf[:, 90:].abs().max()) == 0
+
+
+# ------------------------------------------------------------------------------------------- DCNv2
+def test_dcn_matches_kernel_text_restatement():
+    from oracle import native
+    from motif_amd import ops
+    B, C, H, W, dg = 2, 64, 23, 37, 8
+    x = rnd(B, C, H, W, seed=1)
+    w = rnd(64, C, 3, 3, seed=2, scale=0.05)
+    bias = rnd(64, seed=3, scale=0.1)
+    off = rnd(B, 2 * dg * 9, H, W, seed=4, scale=3.0)
+    mask = torch.sigmoid(rnd(B, dg * 9, H, W, seed=5, scale=2.0))
+    ref = native.dcn_v2_forward(x, w, bias, off, mask, 3, 3, 1, 1, 1, 1, 1, 1, dg)
+    out = ops.dcn_v2_raw(x.to(dev()), off.to(dev()), mask.to(dev()), w.to(dev()), bias.to(dev()), 3, 3, 1, 1, 1, dg)
+    close(out, ref, 3e-5, 3e-5, "dcn")
+
+
+def test_dcn_zero_offset_identity_known_answer():
+    """The reference's own check (models/modules/DCNv2/test.py:32-67): zero offsets, mask 0.5, identity
+    centre-tap weights => 2*output == input."""
+    from motif_amd import ops
+    N, C, H, W, dg = 2, 4, 8, 8, 2
+    w = torch.zeros(C, C, 3, 3)
+    for p in range(C):
+        w[p, p, 1, 1] = 1.0
+    x = torch.randn(N, C, H, W, generator=torch.Generator().manual_seed(0))
+    off = torch.zeros(N, dg * 18, H, W)
+    mask = torch.full((N, dg * 9, H, W), 0.5)
+    out = ops.dcn_v2_raw(x.to(dev()), off.to(dev()), mask.to(dev()), w.to(dev()), torch.zeros(C, device=dev()), 3, 3, 1, 1, 1, dg)
+    assert float((x - 2 * out.cpu()).abs().max()) < 1e-10
+
+
+def test_dcn_sep_module_fused_offset_mask():
+    from oracle.motif_ref import DcnSep
+    from motif_amd.models.modules.DCNv2.dcn_v2 import DCN_sep
+    ref = DcnSep(64, 8)
+    with torch.no_grad():
+        for i, p in enumerate(ref.parameters()):
+            p.copy_(rnd(*p.shape, seed=10 + i, scale=0.05))
+    mine = DCN_sep(64, 64, 3, 1, 1, 1, 8)
+    mine.load_state_dict(ref.state_dict())
+    x, fea = rnd(1, 64, 20, 33, seed=1), rnd(1, 64, 20, 33, seed=2, scale=2.0)
+    with torch.no_grad():
+        r = ref(x, fea)
+    out = mine.to(dev())(x.to(dev()), fea.to(dev()))
+    close(out, r, 5e-5, 5e-5, "DCN_sep")
+
+
+# ------------------------------------------------------------------------------------------- splat
+def _flow(n, h, w, seed, mag=4.0):
+    f = rnd(n, 2, h, w, seed=seed, scale=mag)
+    f[:, :, :2, :] *= 10.0  # throw some sources far outside the frame
+    return f
+
+
+def test_splat_operator_form_vs_kernel_text():
+    from oracle import native
+    from motif_amd import ops
+    n, c, h, w = 3, 5, 37, 53
+    src, flow, z = rnd(n, c, h, w, seed=1), _flow(n, h, w, 2), rnd(n, 1, h, w, seed=3)
+    ez = z.exp()
+    ref = native.splat(torch.cat([src * ez, ez], 1), flow, "sum")
+    o = ops.splat(src.to(dev()), flow.to(dev()), z.to(dev()), want=("sum", "norm", "max", "cnt"))
+    close(o["sum"], ref[:, :-1], 2e-5, 1e-5, "splat sum")
+    close(o["norm"], ref[:, -1:], 2e-5, 1e-5, "splat norm")
+    cnt = native.splat(torch.ones(n, 1, h, w), flow, "count")
+    assert torch.equal(o["cnt"].cpu(), cnt), "hit count must be bit-exact (integer valued)"
+    # max: exact given the same e^z -> feed e^z as the plain input (z=None path)
+    mx = ops.splat(ez.to(dev()), flow.to(dev()), None, want=("max",))["max"]
+    assert torch.equal(mx.cpu(), native.splat(ez, flow, "max"))
+
+
+def test_splat_max_with_values_above_one_and_modules():
+    from oracle import native
+    from motif_amd.models.softsplat_cp import Softsplat
+    from motif_amd.models.softsplat_count_cp import Softsplat_Count
+    from motif_amd.models.softsplat_max_cp import Softsplat_Max
+    n, h, w = 2, 24, 40
+    img, flow = rnd(n, 1, h, w, seed=1).abs() * 5.0, _flow(n, h, w, 2, 1.5)
+    assert torch.equal(Softsplat_Max()(img.to(dev()), flow.to(dev())).cpu(), native.splat(img, flow, "max"))
+    assert torch.equal(Softsplat_Count()(img.to(dev()), flow.to(dev())).cpu(), native.splat(torch.ones_like(img), flow, "count"))
+    feat, z = rnd(n, 7, h, w, seed=4), rnd(n, 1, h, w, seed=5)
+    out, norm = Softsplat()(feat.to(dev()), flow.to(dev()), z.to(dev()))
+    ref = native.splat(torch.cat([feat * z.exp(), z.exp()], 1), flow, "sum")
+    close(out, ref[:, :-1], 2e-5, 1e-5)
+    close(norm, ref[:, -1:], 2e-5, 1e-5)
+
+
+def test_splat_empty_flow_is_identity_count_four_corners():
+    from motif_amd import ops
+    flow = torch.zeros(1, 2, 16, 64, device=dev())
+    o = ops.splat(None, flow, None, want=("cnt",))
+    # zero flow: weights (1,0,0,0) but all four corners are "touched" where in bounds
+    cnt = o["cnt"].cpu()[0, 0]
+    assert cnt[5, 5] == 4 and cnt[0, 0] == 1 and cnt[0, 5] == 2
+
+
+# ------------------------------------------------------------------------------------------- resampling
+@pytest.mark.parametrize("align", [False, True])
+@pytest.mark.parametrize("shape", [((18, 32), (72, 128)), ((72, 128), (18, 32)), ((9, 16), (18, 32)), ((16, 24), (128, 192)), ((23, 31), (47, 50))])
+def test_resize_bilinear(shape, align):
+    from motif_amd import ops
+    (h, w), (ho, wo) = shape
+    x = rnd(3, 2, h, w, seed=1)
+    ref = F.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=align) * 0.25
+    close(ops.resize_bilinear(x.to(dev()), (ho, wo), align, 0.25), ref, 2e-6, 0, "resize")
+
+
+def test_backwarp_and_reliability_maps():
+    from oracle.motif_ref import MotifRef, back_warp
+    from motif_amd import ops
+    B, H, W = 2, 24, 40
+    img, flow = rnd(4 * B, 3, H, W, seed=1), rnd(4 * B, 2, H, W, seed=2, scale=3.0)
+    close(ops.backwarp(img.to(dev()), flow.to(dev())), back_warp(img, flow), 3e-6, 0, "backwarp")
+    # reliability maps against the restatement's motion_and_reliability internals
+    fr = torch.rand(B, 4, 3, H, W, generator=torch.Generator().manual_seed(3))
+    fl = flow.clone()
+    fl[:B] = 0
+    fl[3 * B:] = 0
+    g = torch.tensor([[1 / 16, 1 / 8, 1 / 16], [1 / 8, 1 / 4, 1 / 8], [1 / 16, 1 / 8, 1 / 16]]).reshape(1, 1, 1, 3, 3)
+    fr0, fr1 = fr[:, 1], fr[:, 2]
+    warped = back_warp(torch.cat([fr0, fr1, fr0, fr1], 0), fl)
+    psi_photo = (torch.cat([fr0, fr0, fr1, fr1], 0) - warped).abs().mean(1)
+    f4 = fl.reshape(4, B, 2, H, W)
+    warped = back_warp(-torch.cat([f4[0], f4[2], f4[1], f4[3]], 0), fl)
+    psi_flow = (fl - warped).abs().mean(1)
+    sq, mean = torch.split(F.conv3d(F.pad(torch.cat([fl ** 2, fl], 1), (1, 1, 1, 1), mode="reflect").unsqueeze(1), g).squeeze(1), 2, dim=1)
+    psi_var = (sq - mean ** 2).clip(1e-9, None).sqrt().mean(1)
+    psies = torch.stack([psi_photo, psi_flow / 10.0, psi_var], 1)
+    dur = torch.tensor([[0, 0], [0, 8], [8, 0], [8, 8]], dtype=torch.float32).unsqueeze(1)
+    ff = torch.cat(((fl / 20.0).reshape(2, 2, B, -1, H, W).permute(0, 2, 1, 3, 4, 5).reshape(2 * B, 2, -1, H, W),
+                    psies.reshape(2, 2, B, -1, H, W).permute(0, 2, 1, 3, 4, 5).reshape(2 * B, 2, -1, H, W),
+                    dur.reshape(2, 4, 1, 1).unsqueeze(1).repeat(1, B, 1, H, W).reshape(2 * B, 2, 2, H, W) / 8.0), dim=2).reshape(2 * B, -1, H, W)
+    frd = fr.to(dev())
+    p, f = ops.reliability(frd[:, 1], frd[:, 2], fl.to(dev()), g.to(dev()), B, H, W)
+    close(p, psies, 5e-6, 1e-5, "psies")
+    close(f, ff, 5e-6, 1e-5, "flow_feat")
+
+
+def test_pwc_backward_warp():
+    from oracle.pwc_ref import backward_warp
+    from motif_amd import ops
+    img, flow = rnd(2, 5, 24, 40, seed=1), rnd(2, 2, 24, 40, seed=2, scale=6.0)
+    close(ops.pwc_backward_warp(img.to(dev()), flow.to(dev())), backward_warp(img, flow), 3e-6, 0, "pwc warp")
+
+
+# ------------------------------------------------------------------------------------------- norms / gates
+def test_instance_norm_modes():
+    from motif_amd import ops
+    x, res = rnd(2, 8, 45, 80, seed=1) * 3 + 0.5, rnd(2, 8, 45, 80, seed=2)
+    n = F.instance_norm(x)
+    xd, rd = x.to(dev()), res.to(dev())
+    close(ops.instance_norm(xd, 0), n, 3e-6, 1e-5)
+    close(ops.instance_norm(xd, 1), F.relu(n), 3e-6, 1e-5)
+    close(ops.instance_norm(xd, 2, res=rd), F.relu(res + F.relu(n)), 3e-6, 1e-5)
+
+
+def test_pool_transpose_gates_axpby():
+    from motif_amd import ops
+    x = rnd(2, 6, 16, 24, seed=1)
+    close(ops.avg_pool2(x.to(dev())), F.avg_pool2d(x, 2, stride=2), 1e-7)
+    close(ops.nchw_to_nhwc(x.to(dev())), x.permute(0, 2, 3, 1), 0)
+    x2 = rnd(1, 130, 7, 9, seed=2)
+    close(ops.nchw_to_nhwc(x2.to(dev())), x2.permute(0, 2, 3, 1), 0)
+    z, q, h = torch.sigmoid(rnd(2, 6, 16, 24, seed=2)), rnd(2, 6, 16, 24, seed=3), rnd(2, 6, 16, 24, seed=4)
+    close(ops.gru_update(z.to(dev()), q.to(dev()), h.to(dev())), (1 - z) * h + z * q, 1e-6)
+    cc, c = rnd(2, 16, 8, 12, seed=5, scale=3), rnd(2, 4, 8, 12, seed=6)
+    i, f, o, g = torch.split(cc, 4, 1)
+    cn = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+    hn = torch.sigmoid(o) * torch.tanh(cn)
+    h2, c2 = ops.lstm_gates(cc.to(dev()), c.to(dev()))
+    close(h2, hn, 2e-6)
+    close(c2, cn, 2e-6)
+    close(ops.axpby(x.to(dev()), (x * 2).to(dev()), 1.0, -1.0), -x, 0)
+
+
+def test_deconv4x4s2():
+    from motif_amd import ops
+    x, w, b = rnd(2, 37, 6, 10, seed=1), rnd(37, 2, 4, 4, seed=2, scale=0.1), rnd(2, seed=3)
+    close(ops.deconv4x4s2(x.to(dev()), w.to(dev()), b.to(dev())), F.conv_transpose2d(x, w, b, 2, 1), 1e-5, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------- correlations
+def test_raft_lookup_vs_alt_corr_restatement_and_corrblock():
+    from oracle import native
+    from motif_amd.models.core.corr import AlternateCorrBlock, alt_cuda_corr_forward
+    B, C, H, W = 2, 128, 16, 24
+    f1, f2 = rnd(B, C, H, W, seed=1), rnd(B, C, H, W, seed=2)
+    coords = torch.stack(torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")[::-1], 0).float()[None].repeat(B, 1, 1, 1)
+    coords = coords + rnd(B, 2, H, W, seed=3, scale=5.0)
+    f1h, f2h = f1.permute(0, 2, 3, 1).contiguous(), f2.permute(0, 2, 3, 1).contiguous()
+    ch = coords.permute(0, 2, 3, 1).reshape(B, 1, H, W, 2).contiguous()
+    ref, = native.alt_corr(f1h, f2h, ch, 3)
+    out, = alt_cuda_corr_forward(f1h.to(dev()), f2h.to(dev()), ch.to(dev()), 3)
+    close(out, ref, 2e-5, 1e-5, "alt_cuda_corr operator form")
+    # full 4-level block vs oracle lookup
+    from oracle.motif_ref import alt_corr_lookup
+    pyr = [f2]
+    for _ in range(3):
+        pyr.append(F.avg_pool2d(pyr[-1], 2, stride=2))
+    ref4 = alt_corr_lookup(f1, pyr, coords)
+    blk = AlternateCorrBlock(f1.to(dev()), f2.to(dev()), radius=3)
+    close(blk(coords.to(dev())), ref4, 2e-5, 1e-5, "4-level lookup")
+
+
+def test_corr81():
+    from oracle import native
+    from motif_amd import ops
+    a, b = rnd(2, 33, 12, 20, seed=1), rnd(2, 33, 12, 20, seed=2)
+    close(ops.corr81(a.to(dev()), b.to(dev())), native.corr81(a, b), 2e-6, 1e-5, "corr81")
+    close(ops.corr81(a.to(dev()), b.to(dev()), ops.ACT_LRELU), F.leaky_relu(native.corr81(a, b), 0.1), 2e-6, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------- SIREN MLPs
+def _tables(H, W, HH, WW):
+    from motif_amd.models.modules.Ours import gather_tables
+    return gather_tables(H, W, HH, WW, dev())
+
+
+@pytest.mark.parametrize("HW", [((8, 12), (32, 48)), ((7, 9), (14, 18))])
+def test_siren_kernels_vs_torch(HW):
+    from oracle.motif_ref import Siren as RefSiren
+    from motif_amd import ops
+    from motif_amd.models.modules.SIREN import Siren
+    from motif_amd.utils.synth_weights import fill_state_dict
+    (H, W), (HH, WW) = HW
+    Q = HH * WW
+    iy, ix, rel_y, rel_x = _tables(H, W, HH, WW)
+    iyc, ixc = iy.cpu().long(), ix.cpu().long()
+    gather = lambda t: t[:, :, iyc][:, :, :, ixc]                                   # [n,c,HH,WW]
+    rel = torch.stack([rel_y.cpu()[:, None].expand(HH, WW), rel_x.cpu()[None, :].expand(HH, WW)], 0)   # [2,HH,WW]
+    B, N = 2, 2
+
+    class Holder(torch.nn.Module):
+        def __init__(self, ref):
+            super().__init__()
+            self.flow_imnet = RefSiren(67, [64, 64, 256], 3) if ref else Siren(67, [64, 64, 256], 2, 3, True)
+            self.imnet = RefSiren(66, [64, 64, 256], 64) if ref else Siren(66, [64, 64, 256], 2, 64, True)
+            self.synth_net = RefSiren(198, [64, 64, 64, 256], 3) if ref else Siren(198, [64, 64, 64, 256], 3, 3, True)
+
+    ref, mine = fill_state_dict(Holder(True)), Holder(False)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev())
+    feat = rnd(2 * B, 64, H, W, seed=1, scale=0.3)
+    # imnet
+    inp = torch.cat([gather(feat), rel[None].expand(2 * B, -1, -1, -1)], 1)
+    with torch.no_grad():
+        r = ref.imnet(inp.reshape(2 * B, 66, Q).permute(0, 2, 1)).permute(0, 2, 1).reshape(2 * B, 64, HH, WW)
+    o = ops.siren_imnet(mine.imnet.packed(), feat.to(dev()), iy, ix, rel_y, rel_x, HH, WW)
+    close(o, r, 5e-6, 1e-4, "imnet")
+    # flow_imnet
+    times = torch.tensor([[0.0, 0.5], [0.25, 1.0]])
+    g = gather(feat).repeat(1, N, 1, 1).reshape(2 * B * N, 64, HH, WW)
+    t = times.reshape(B * N, 1, 1, 1).repeat(2, 1, HH, WW)
+    inp = torch.cat([g, t, rel[None].expand(2 * B * N, -1, -1, -1)], 1)
+    with torch.no_grad():
+        r = ref.flow_imnet(inp.reshape(2 * B * N, 67, Q).permute(0, 2, 1)).permute(0, 2, 1).reshape(2 * B * N, 3, HH, WW)
+    o = ops.siren_flow(mine.flow_imnet.packed(), feat.to(dev()), iy, ix, rel_y, rel_x, times.to(dev()), N, HH, WW)
+    close(o, r, 5e-6, 1e-4, "flow_imnet")
+    # synth (with the normalisation prologue): build an accumulator with zeros / ones / exact-equality cases
+    acc = rnd(B * N, 133, HH, WW, seed=5, scale=0.5)
+    acc[:, 130] = acc[:, 130].abs() * 2
+    acc[:, 130, :2] = 0.0
+    acc[:, 130, 2:4] = 1.0
+    acc[:, 131] = 1.0 + acc[:, 131].abs()
+    acc[:, 132] = torch.randint(0, 9, (B * N, HH, WW), generator=torch.Generator().manual_seed(6)).float()
+    res = rnd(B, 64, H, W, seed=7, scale=0.3)
+    wz = acc[:, 130:131].clone()
+    wz[wz == 0] = 1.0
+    out = acc[:, :130] / wz
+    cnt = acc[:, 132:133]
+    cnt_ = cnt.clone()
+    cnt_[cnt_ == 0.0] = 1.0
+    wz_ = wz.clone()
+    wz_[wz_ == 1.0] = 0.0
+    extra = torch.cat((acc[:, 131:132], cnt / 16.0, wz_ / cnt_), 1)
+    allin = torch.cat((out, extra, gather(res).repeat(1, N, 1, 1).reshape(B * N, 64, HH, WW), times.reshape(B * N, 1, 1, 1).repeat(1, 1, HH, WW)), 1)
+    si = ops.synth_input(acc.to(dev()), res.to(dev()), iy, ix, times.to(dev()), B, N, HH, WW)
+    close(si, allin, 1e-6, 1e-6, "synth input / normalisation")
+    with torch.no_grad():
+        r = ref.synth_net(allin.reshape(B * N, 198, Q).permute(0, 2, 1)).permute(0, 2, 1).reshape(B, N, 3, HH, WW).permute(1, 0, 2, 3, 4).clamp(0, 1)
+    o = ops.siren_synth(mine.synth_net.packed(), acc.to(dev()), res.to(dev()), iy, ix, times.to(dev()), B, N, HH, WW)
+    close(o, r, 2e-5, 1e-4, "synth")

@@ -1,0 +1,155 @@
+"""CPU: the oracle (oracle/) against the golden fixtures captured from the reference, and against the
+known-answer tests the reference holds for this path."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False))
+
+
+def check(g, key, t, atol=0.0):
+    t = t.detach().float().contiguous()
+    assert list(t.shape) == list(g[key + "__shape"])
+    if key in g:
+        ref, got = torch.from_numpy(g[key]), t
+    else:
+        ref, got = torch.from_numpy(g[key + "__vals"]), t.reshape(-1)[torch.from_numpy(g[key + "__idx"])]
+    assert float((got - ref).abs().max()) <= atol, (key, float((got - ref).abs().max()))
+    d = g[key + "__digest"]
+    assert abs(float(t.double().sum()) - d[0]) <= 1e-6 * max(1.0, abs(d[1])) + atol * d[2]
+
+
+@pytest.fixture(scope="module")
+def oracle_net():
+    from oracle.motif_ref import MotifRef
+    from motif_amd.utils.synth_weights import fill_state_dict
+    return fill_state_dict(MotifRef().eval())
+
+
+def test_state_dict_keys_match_reference(oracle_net):
+    keys = json.load(open(os.path.join(GOLD, "state_dict_keys.json")))
+    sd = oracle_net.state_dict()
+    assert set(sd) == set(keys) and len(keys) == 698
+    assert all(list(sd[k].shape) == keys[k] for k in keys)
+
+
+@pytest.mark.parametrize("case", ["lr32_s4_n3", "lr32x48_s4_n2_b2"])
+def test_restatement_reproduces_reference_outputs(oracle_net, case):
+    """Same torch build => bit-identical (make_golden.py reported max|diff| = 0 for every stage);
+    a small tolerance is allowed for a different CPU's conv kernels."""
+    g = load(case)
+    times = list(torch.from_numpy(g["times"]))
+    scale = [[int(g["scale"][0])], [int(g["scale"][1])]]
+    st = {}
+    with torch.no_grad():
+        out, flow, _ = oracle_net(torch.from_numpy(g["LQs"]), None, times, scale, use_GT=False, iter=4, stages=st)
+    tol = 0.0 if str(g["torch_version"]) == torch.__version__ else 1e-4
+    tol = max(tol, 2e-5)
+    check(g, "out", out, tol)
+    check(g, "flow", flow, tol)
+    check(g, "encoder", st["encoder"], tol)
+    check(g, "flow_imnet", st["flow_imnet"], tol)
+    check(g, "fwarp_count", st["fwarp_count"], 0.0 if tol <= 2e-5 else 16.0)
+
+
+def test_pwc_restatement_reproduces_reference_output():
+    from oracle.pwc_ref import PwcRef
+    from motif_amd.utils.synth_weights import fill_state_dict
+    g = load("pwc_96x128")
+    net = fill_state_dict(PwcRef().eval())
+    with torch.no_grad():
+        flow = net(torch.from_numpy(g["first"]), torch.from_numpy(g["second"]))
+    check(g, "flow", flow, 2e-5)
+
+
+def test_dcn_zero_offset_identity():
+    """Known-answer test of the reference: models/modules/DCNv2/test.py:32-67."""
+    from oracle import native
+    N, C, H, W, dg = 2, 4, 8, 8, 2
+    w = torch.zeros(C, C, 3, 3)
+    for p in range(C):
+        w[p, p, 1, 1] = 1.0
+    x = torch.randn(N, C, H, W, generator=torch.Generator().manual_seed(0))
+    out = native.dcn_v2_forward(x, w, torch.zeros(C), torch.zeros(N, dg * 18, H, W), torch.full((N, dg * 9, H, W), 0.5), 3, 3, 1, 1, 1, 1, 1, 1, dg)
+    assert float((x - 2 * out).abs().max()) < 1e-10
+
+
+def test_dcn_zero_offset_equals_plain_conv():
+    from oracle import native
+    x = torch.randn(1, 16, 9, 11, generator=torch.Generator().manual_seed(1))
+    w = torch.randn(8, 16, 3, 3, generator=torch.Generator().manual_seed(2)) * 0.1
+    b = torch.randn(8, generator=torch.Generator().manual_seed(3))
+    out = native.dcn_v2_forward(x, w, b, torch.zeros(1, 2 * 4 * 9, 9, 11), torch.ones(1, 4 * 9, 9, 11), 3, 3, 1, 1, 1, 1, 1, 1, 4)
+    assert float((out - F.conv2d(x, w, b, 1, 1)).abs().max()) < 1e-5
+
+
+def test_alt_corr_restatement_equals_in_repo_corrblock():
+    """alt_cuda_corr is third-party and unpinned; the reference's own CorrBlock (corr.py:8-56) computes the
+    same quantity: all-pairs correlation, avg-pool pyramid, bilinear_sampler (zero pad, align_corners=True)."""
+    from oracle.motif_ref import alt_corr_lookup
+    B, C, H, W, r = 1, 32, 16, 16, 3
+    g = torch.Generator().manual_seed(0)
+    f1, f2 = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    coords = torch.stack(torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")[::-1], 0).float()[None]
+    coords = coords + (torch.rand(B, 2, H, W, generator=g) - 0.5) * 8
+    pyr = [f2]
+    for _ in range(3):
+        pyr.append(F.avg_pool2d(pyr[-1], 2, stride=2))
+    mine = alt_corr_lookup(f1, pyr, coords, r)
+    # CorrBlock restated with plain torch ops
+    corr = torch.matmul(f1.view(B, C, H * W).transpose(1, 2), f2.view(B, C, H * W)).view(B * H * W, 1, H, W) / torch.sqrt(torch.tensor(C).float())
+    outs = []
+    c = coords.permute(0, 2, 3, 1)
+    for i in range(4):
+        d = torch.linspace(-r, r, 2 * r + 1)
+        delta = torch.stack(torch.meshgrid(d, d, indexing="ij"), dim=-1)
+        cl = c.reshape(B * H * W, 1, 1, 2) / 2 ** i + delta.view(1, 2 * r + 1, 2 * r + 1, 2)
+        hh, ww = corr.shape[-2:]
+        grid = torch.cat([2 * cl[..., :1] / (ww - 1) - 1, 2 * cl[..., 1:] / (hh - 1) - 1], -1)
+        outs.append(F.grid_sample(corr, grid, align_corners=True).view(B, H, W, -1))
+        corr = F.avg_pool2d(corr, 2, stride=2)
+    ref = torch.cat(outs, -1).permute(0, 3, 1, 2)
+    assert float((mine - ref).abs().max()) < 2e-5
+
+
+def test_splat_kernel_text_properties():
+    from oracle import native
+    n, c, h, w = 2, 3, 12, 17
+    g = torch.Generator().manual_seed(0)
+    src = torch.randn(n, c, h, w, generator=g)
+    # zero flow: identity for the sum, 4/2/1 hits per pixel for the count
+    z = torch.zeros(n, 2, h, w)
+    assert torch.equal(native.splat(src, z, "sum"), src)
+    cnt = native.splat(torch.ones(n, 1, h, w), z, "count")
+    assert cnt[0, 0, 3, 3] == 4 and cnt[0, 0, 0, 0] == 1 and cnt[0, 0, 0, 3] == 2
+    # integer shift moves mass exactly; everything pushed outside disappears
+    f = torch.zeros(n, 2, h, w)
+    f[:, 0] = 2.0
+    out = native.splat(src, f, "sum")
+    assert torch.equal(out[..., 2:], src[..., :-2]) and float(out[..., :2].abs().max()) == 0
+    far = torch.full((n, 2, h, w), 1000.0)
+    assert float(native.splat(src, far, "sum").abs().max()) == 0
+    # max starts from one (softsplat_max_cp.py:254)
+    assert float(native.splat(torch.full((n, 1, h, w), 0.25), z, "max").min()) == 1.0
+    # linearity of the sum splat
+    f = (torch.rand(n, 2, h, w, generator=g) - 0.5) * 6
+    a, b = torch.randn(n, c, h, w, generator=g), torch.randn(n, c, h, w, generator=g)
+    assert float((native.splat(a + b, f, "sum") - native.splat(a, f, "sum") - native.splat(b, f, "sum")).abs().max()) < 1e-5
+
+
+def test_corr81_center_channel_is_mean_product():
+    from oracle import native
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.randn(1, 20, 9, 11, generator=g), torch.randn(1, 20, 9, 11, generator=g)
+    out = native.corr81(a, b)
+    assert float((out[:, 40] - (a * b).mean(1)).abs().max()) < 1e-6
+    assert float((out[:, 41, :, :-1] - (a[..., :-1] * b[..., 1:]).mean(1)).abs().max()) < 1e-6
+    assert float(out[:, 41, :, -1].abs().max()) == 0
