@@ -25,102 +25,174 @@ struct ConvArgs {
     int CK, PH, PW, Kpad, tiles_x, ncg;
 };
 
-template <int NC>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+// Limits of one reduction chunk (host planner keeps to them): patch elements <= PATCH_MAX, packed weight
+// floats <= WCHUNK_MAX, so that a whole chunk can be prefetched into registers while the previous one is
+// being multiplied (global -> VGPR issue-early, VGPR -> LDS write-late; two LDS buffers, one barrier per chunk).
+#define PATCH_MAX 6144
+#define WCHUNK_MAX 8192
+
+template <int NC, int RPW>
+__global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = 64 * (8 / RPW);       // threads: one wave per RPW output rows of the 8-row tile
+    constexpr int WN = 32 * NC;               // weight slab row width
+    constexpr int NE_MAX = PATCH_MAX / NT;    // patch elements a thread prefetches per chunk
+    constexpr int NW_MAX = WCHUNK_MAX / 4 / NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
     const int g = blockIdx.y / a.ncg, cg = blockIdx.y % a.ncg;
     const int n = blockIdx.z;
     const int PHW = a.PH * a.PW;
     const int T = a.KH * a.KW;
-    const int KC = a.CK * T;                 // rows per full chunk (host guarantees even)
-    constexpr int WN = 32 * NC;              // weight slab row width
-    const int patch_elems = (a.CK * PHW + 3) & ~3;
-    float* patch = smem;
-    float* wl = smem + patch_elems;
-    int* koff = (int*)(wl + KC * WN);
-    int* goff = koff + KC;
+    const int KC = a.CK * T;                  // rows per full chunk (host guarantees even)
+    const int CKPHW = a.CK * PHW;
+    const int patch_elems = (CKPHW + 3) & ~3;
+    float* patch0 = smem;
+    float* wl0 = patch0 + 2 * patch_elems;
+    int* koff = (int*)(wl0 + 2 * KC * WN);
+    int* soff = koff + KC;
 
-    // one-off tables: patch position -> input offset (or -1), chunk row -> patch offset
+    // one-off tables.  soff[e]: chunk-local channel (bits 24..) | input offset inside a plane (0xFFFFFF = padding)
     const int iy0 = ty * 8 * a.stride - a.pad, ix0 = tx * 32 * a.stride - a.pad;
-    for (int p = tid; p < PHW; p += 256) {
-        int py = p / a.PW, px = p - py * a.PW;
+    for (int e = tid; e < CKPHW; e += NT) {
+        const int c = e / PHW, p = e - c * PHW;
+        const int py = p / a.PW, px = p - py * a.PW;
         int iy = iy0 + py, ix = ix0 + px;
         if (a.pad_mode == 1) {
             if (iy < 0) iy = -iy; else if (iy >= a.H) iy = 2 * (a.H - 1) - iy;
             if (ix < 0) ix = -ix; else if (ix >= a.W) ix = 2 * (a.W - 1) - ix;
         }
-        goff[p] = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? iy * a.W + ix : -1;
+        const int go = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? iy * a.W + ix : 0xFFFFFF;
+        soff[e] = (c << 24) | go;
     }
-    for (int kk = tid; kk < KC; kk += 256) {
-        int c = kk / T, t = kk - c * T;
-        int ky = t / a.KW, kx = t - ky * a.KW;
+    for (int kk = tid; kk < KC; kk += NT) {
+        const int c = kk / T, t = kk - c * T;
+        const int ky = t / a.KW, kx = t - ky * a.KW;
         koff[kk] = c * PHW + ky * a.dil * a.PW + kx * a.dil;
     }
 
-    f32x16 acc[NC][2];
+    f32x16 acc[NC][RPW];
 #pragma unroll
     for (int i = 0; i < NC; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < RPW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const long HW = (long)a.H * a.W;
+    const float* in0n = a.in0 + (long)n * a.in0_bs;
+    const float* in1n = a.in1 ? a.in1 + (long)n * a.in1_bs : nullptr;
     const float* wbase = a.wp + ((long)(g * a.ncg + cg) * a.Kpad) * WN;
-    const int pix0 = (2 * wave) * a.stride * a.PW + l31 * a.stride;
-    const int pix1 = pix0 + a.stride * a.PW;
+    int pix[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) pix[j] = (RPW * wave + j) * a.stride * a.PW + l31 * a.stride;
 
-    for (int c0 = 0; c0 < a.Cin_g; c0 += a.CK) {
-        __syncthreads();   // previous chunk's reads done (also orders the table writes the first time)
-        for (int c = 0; c < a.CK; ++c) {
-            const int ch = c0 + c;
-            const float* base = nullptr;
-            if (ch < a.Cin_g) {
-                const int gch = g * a.Cin_g + ch;
-                base = (gch < a.C0) ? a.in0 + (long)n * a.in0_bs + (long)gch * HW
-                                    : a.in1 + (long)n * a.in1_bs + (long)(gch - a.C0) * HW;
+    float pre[NE_MAX];
+    f32x4 wreg[NW_MAX];
+    __syncthreads();
+
+    auto issue = [&](int c0) {            // global -> registers for the chunk starting at channel c0
+#pragma unroll
+        for (int j = 0; j < NE_MAX; ++j) {
+            const int e = tid + NT * j;
+            float v = 0.f;
+            if (e < CKPHW) {
+                const int so = soff[e];
+                const int ch = c0 + (so >> 24), go = so & 0xFFFFFF;
+                if (ch < a.Cin_g && go != 0xFFFFFF) {
+                    const int gch = g * a.Cin_g + ch;
+                    const float* pl = (gch < a.C0) ? in0n + (long)gch * HW : in1n + (long)(gch - a.C0) * HW;
+                    v = pl[go];
+                }
             }
-            float* dst = patch + c * PHW;
-            for (int p = tid; p < PHW; p += 256) {
-                const int go = goff[p];
-                dst[p] = (base != nullptr && go >= 0) ? base[go] : 0.f;
-            }
+            pre[j] = v;
         }
         const int r0 = c0 * T;
-        int rows = a.Kpad - r0; if (rows > KC) rows = KC;     // even
-        {
-            const f32x4* src = (const f32x4*)(wbase + (long)r0 * WN);
-            f32x4* d4 = (f32x4*)wl;
-            const int n4 = rows * WN / 4;
-            for (int i = tid; i < n4; i += 256) d4[i] = src[i];
+        int rows = a.Kpad - r0; if (rows > KC) rows = KC;
+        const int n4 = rows * WN / 4;
+        const f32x4* src = (const f32x4*)(wbase + (long)r0 * WN);
+#pragma unroll
+        for (int j = 0; j < NW_MAX; ++j) {
+            const int i = tid + NT * j;
+            if (i < n4) wreg[j] = src[i];
         }
-        __syncthreads();
-        const int steps = rows >> 1;
-#pragma unroll 4
-        for (int s = 0; s < steps; ++s) {
+        return rows;
+    };
+    auto commit = [&](int buf, int rows) {   // registers -> LDS buffer `buf`
+        float* patch = patch0 + buf * patch_elems;
+        f32x4* w4 = (f32x4*)(wl0 + buf * KC * WN);
+#pragma unroll
+        for (int j = 0; j < NE_MAX; ++j) {
+            const int e = tid + NT * j;
+            if (e < CKPHW) patch[e] = pre[j];
+        }
+        const int n4 = rows * WN / 4;
+#pragma unroll
+        for (int j = 0; j < NW_MAX; ++j) {
+            const int i = tid + NT * j;
+            if (i < n4) w4[i] = wreg[j];
+        }
+    };
+
+    int rows_cur = issue(0);
+    commit(0, rows_cur);
+    __syncthreads();
+    int cur = 0;
+    for (int c0 = 0; c0 < a.Cin_g; c0 += a.CK) {
+        const bool more = c0 + a.CK < a.Cin_g;
+        int rows_next = 0;
+        if (more) rows_next = issue(c0 + a.CK);          // loads fly while this chunk is multiplied
+
+        const float* patch = patch0 + cur * patch_elems;
+        const float* wl = wl0 + cur * KC * WN + l31;
+        const int steps = rows_cur >> 1;
+        int s = 0;
+        for (; s + 4 <= steps; s += 4) {
+            int ko[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ko[u] = koff[2 * (s + u) + half];
+            float bv[4][RPW], av[4][NC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) bv[u][j] = patch[ko[u] + pix[j]];
+#pragma unroll
+                for (int i = 0; i < NC; ++i) av[u][i] = wl[(2 * (s + u) + half) * WN + i * 32];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < NC; ++i)
+#pragma unroll
+                    for (int j = 0; j < RPW; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+        }
+        for (; s < steps; ++s) {
             const int k = 2 * s + half;
-            const int ko = koff[k];
-            const float b0 = patch[ko + pix0];
-            const float b1 = patch[ko + pix1];
+            const int ko1 = koff[k];
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
-                const float av = wl[k * WN + i * 32 + l31];
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[i][1], 0, 0, 0);
+                const float av1 = wl[k * WN + i * 32];
+#pragma unroll
+                for (int j = 0; j < RPW; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, patch[ko1 + pix[j]], acc[i][j], 0, 0, 0);
             }
         }
+        if (more) commit(cur ^ 1, rows_next);
+        __syncthreads();
+        cur ^= 1;
+        rows_cur = rows_next;
     }
 
     // epilogue: C/D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*half (cout within tile)
     const int ox = tx * 32 + l31;
     if (ox < a.Wo) {
+        const long HWo = (long)a.Ho * a.Wo;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int oy = ty * 8 + 2 * wave + j;
+        for (int j = 0; j < RPW; ++j) {
+            const int oy = ty * 8 + RPW * wave + j;
             if (oy >= a.Ho) continue;
-            const long pix = (long)oy * a.Wo + ox;
+            const long pixo = (long)oy * a.Wo + ox;
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
 #pragma unroll
@@ -131,15 +203,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                     float v = acc[i][j][r];
                     if (a.bias) v += a.bias[co];
                     const int act = (a.act_split > 0 && co >= a.act_split) ? a.act2 : a.act;
-                    const long HWo = (long)a.Ho * a.Wo;
                     float rv = 0.f;
-                    if (a.res_mode) rv = a.res[(long)n * a.res_bs + (long)co * HWo + pix];
+                    if (a.res_mode) rv = a.res[(long)n * a.res_bs + (long)co * HWo + pixo];
                     if (a.res_mode == 1) v = act_apply(v + rv, act);
                     else if (a.res_mode == 2) v = act_apply(v, act) + rv;
                     else if (a.res_mode == 3) { v = act_apply(v, act) + rv; v = v > 0.f ? v : 0.f; }
                     else if (a.res_mode == 4) v = act_apply(v, act) * rv;
                     else v = act_apply(v, act);
-                    a.out[(long)n * a.out_bs + (long)co * HWo + pix] = v;
+                    a.out[(long)n * a.out_bs + (long)co * HWo + pixo] = v;
                 }
             }
         }
@@ -180,21 +251,28 @@ bool plan_conv(const MotifConvDesc* d, ConvPlan* p) {
     p->Ho = (d->H + 2 * d->pad - (d->dil * (d->KH - 1) + 1)) / d->stride + 1;
     p->Wo = (d->W + 2 * d->pad - (d->dil * (d->KW - 1) + 1)) / d->stride + 1;
     if (p->Ho <= 0 || p->Wo <= 0) return false;
+    if ((long)d->H * d->W >= 0xFFFFFF) return false;     // plane offsets are packed into 24 bits
     p->PH = 7 * d->stride + (d->KH - 1) * d->dil + 1;
     p->PW = 31 * d->stride + (d->KW - 1) * d->dil + 1;
-    // chunk: as many channels as fit ~40 KB of LDS, CK*T even
+    // chunk: as many channels as fit the register-prefetch limits and ~29 KB per LDS buffer, CK*T even
     const long PHW = (long)p->PH * p->PW;
-    int ck = 1;
-    const long budget = 40 * 1024;
-    for (int c = 1; c <= p->Cin_g + 1 && c <= 64; ++c) {
-        long bytes = (((long)c * PHW + 3) & ~3L) * 4 + (long)c * p->T * (p->WN * 4 + 4) + PHW * 4;
-        if (bytes > budget) break;
-        ck = c;
+    auto ok = [&](int c) {
+        return (long)c * PHW <= PATCH_MAX && (long)c * p->T * p->WN <= WCHUNK_MAX && c < 128 &&
+               ((long)c * PHW * 4 + (long)c * p->T * p->WN * 4) <= 30 * 1024;
+    };
+    int ck = 0;
+    for (int c = 1; c <= p->Cin_g + 1; ++c) {
+        if (!ok(c)) break;
+        if (((c * p->T) & 1) == 0) ck = c;
     }
-    if ((ck * p->T) & 1) { if (ck > 1) ck -= 1; else ck = 2; }
-    if (ck > p->Cin_g) { ck = p->Cin_g; if ((ck * p->T) & 1) ck += 1; }
+    if (ck == 0) {                       // relax the LDS soft cap, keep the hard register limits
+        for (int c = 1; c <= 2; ++c)
+            if (((c * p->T) & 1) == 0 && (long)c * PHW <= PATCH_MAX && (long)c * p->T * p->WN <= WCHUNK_MAX) { ck = c; break; }
+    }
+    if (ck == 0) return false;
     p->CK = ck;
-    p->lds = ((((size_t)ck * PHW + 3) & ~(size_t)3) + (size_t)ck * p->T * p->WN + (size_t)ck * p->T + PHW) * 4;
+    const size_t patch_elems = ((size_t)ck * PHW + 3) & ~(size_t)3;
+    p->lds = (2 * patch_elems + 2 * (size_t)ck * p->T * p->WN + (size_t)ck * p->T + (size_t)ck * PHW) * 4;
     return p->lds <= 160 * 1024;
 }
 }  // namespace
@@ -236,13 +314,23 @@ extern "C" int motif_conv2d_fwd(const MotifConvDesc* d, const float* in0, const 
     a.ncg = p.ncg;
     dim3 grid(a.tiles_x * tiles_y, d->groups * p.ncg, d->N);
     hipStream_t s = (hipStream_t)stream;
-    if (p.NC == 2) {
-        if (p.lds > 64 * 1024) hipFuncSetAttribute((const void*)conv_igemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
-        conv_igemm_kernel<2><<<grid, 256, p.lds, s>>>(a);
-    } else {
-        if (p.lds > 64 * 1024) hipFuncSetAttribute((const void*)conv_igemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
-        conv_igemm_kernel<1><<<grid, 256, p.lds, s>>>(a);
+    // small grids: one output row per wave (8 waves per tile) so that every SIMD still holds several waves
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
+    const long blocks = (long)grid.x * grid.y * grid.z;
+    const bool fine = blocks < 3L * cus;
+#define MOTIF_LAUNCH_CONV(NCV, RPWV)                                                                                         \
+    do {                                                                                                                     \
+        if (p.lds > 64 * 1024)                                                                                               \
+            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NCV, RPWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
+        conv_igemm_kernel<NCV, RPWV><<<grid, 64 * (8 / RPWV), p.lds, s>>>(a);                                               \
+    } while (0)
+    if (p.NC == 2) { if (fine) MOTIF_LAUNCH_CONV(2, 1); else MOTIF_LAUNCH_CONV(2, 2); }
+    else { if (fine) MOTIF_LAUNCH_CONV(1, 1); else MOTIF_LAUNCH_CONV(1, 2); }
+#undef MOTIF_LAUNCH_CONV
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

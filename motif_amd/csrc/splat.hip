@@ -101,48 +101,231 @@ extern "C" int motif_splat_fwd(const float* src, const float* flow, const float*
     return MOTIF_OK;
 }
 
-// ---------------------------------------------------------------- fused MoTIF form
-// grid.z = image (d,b,n); grid.y = channel slice; block = 4 rows x 64 columns of source pixels.
-// Channel slices: the 130 feature planes are split over grid.y so that more waves are in flight per
-// accumulator plane region; slice 0 additionally handles norm / max / count.
-#define SPLAT_SLICES 5   /* 130 = 5 * 26 */
-__global__ __launch_bounds__(256) void splat_motif_kernel(const float* __restrict__ imnet_out, const float* __restrict__ pred,
-                                                         const float* __restrict__ feat_lr, const int32_t* __restrict__ iy,
-                                                         const int32_t* __restrict__ ix, const float* __restrict__ alpha,
-                                                         float s20, float sr, float* acc,
-                                                         int B, int N, int H, int W, int HH, int WW, int tiles_x) {
-    const int img = blockIdx.z;                 // (d*B + b)*N + n
-    const int n = img % N, db = img / N, b = db % B;
+// ---------------------------------------------------------------- fused MoTIF form: owner-computes
+// Forward splatting is a scatter, but the predicted HR flow is locally bounded, so it can be turned
+// inside out: a workgroup OWNS a 16x64 tile of the accumulator, scans the source pixels of BOTH
+// directions within +-R of the tile, keeps those whose 2x2 footprint touches the tile (compacted into an
+// LDS list with a wave-aggregated append), accumulates 8 accumulator planes at a time in LDS (the padded
+// 18x66 tile absorbs footprint cells that spill over the border, so the inner loop has no bounds tests),
+// and writes each finished plane tile with plain coalesced stores.
+// LDS accumulation is 32.32 FIXED POINT with ds_add_u64: measured on MI355X (tools/ubench_atomics.hip)
+// ds_add_f32 retires one wave-instruction per ~194 cycles per CU, integer LDS atomics one per ~5 --
+// float LDS atomics are 40x slower than integer ones and slower than global_atomic_add_f32.  Each addend
+// (value*e^z, then *weight, both rounded to fp32 exactly as softsplat_cp.py:35-40 does) is converted
+// exactly up to 2^-32 (floor / fract / two cvt), summed as integers -- order independent, deterministic --
+// and rounded to fp32 once at write-out; the reference's own fp32 atomic sums vary run to run by more.
+// No global atomics, no zero-fill pass, and the two directions are summed in LDS.  A source whose
+// footprint leaves its own +-R neighbourhood ("far") is skipped here and scattered by
+// splat_far_kernel afterwards with global atomics -- both kernels evaluate the same predicate on the
+// same inputs, so every source is accounted exactly once.
+#define OT_H 16
+#define OT_W 64
+#define OT_CC 8
+#define OT_TPH (OT_H + 2)
+#define OT_TPW (OT_W + 2)
+#define OT_TP (OT_TPH * OT_TPW)
+#define OT_THREADS 1024
+
+struct MotifSplatArgs {
+    const float* imnet_out; const float* pred; const float* feat_lr;
+    const int32_t* iy; const int32_t* ix; const float* alpha;
+    float s20, sr; float* acc;
+    int B, N, H, W, HH, WW, R;
+};
+
+struct SrcGeom {
+    float p0, p1, e;
+    int x0, y0;
+    float wnw, wne, wsw, wse;
+    bool near_;
+};
+
+// geometry of one source pixel; `near_` = footprint within +-R of the source (float test: safe for huge flows)
+__device__ __forceinline__ SrcGeom src_geom(const MotifSplatArgs& a, int img, int x, int y, bool need_z) {
+    SrcGeom g;
+    const long Q = (long)a.HH * a.WW, p = (long)y * a.WW + x;
+    g.p0 = a.pred[((long)img * 3 + 0) * Q + p];
+    g.p1 = a.pred[((long)img * 3 + 1) * Q + p];
+    const float fx = (g.p0 * a.s20) * a.sr, fy = (g.p1 * a.s20) * a.sr;          // Ours.py:794
+    const float ox = (float)x + fx, oy = (float)y + fy;
+    const float flx = floorf(ox), fly = floorf(oy);
+    const float R = (float)a.R;
+    g.near_ = (flx >= (float)x - R) && (flx + 1.f <= (float)x + R) && (fly >= (float)y - R) && (fly + 1.f <= (float)y + R);
+    g.x0 = g.near_ ? (int)flx : 0;
+    g.y0 = g.near_ ? (int)fly : 0;
+    const float xe = flx + 1.f, ye = fly + 1.f;
+    g.wnw = (xe - ox) * (ye - oy);
+    g.wne = (ox - flx) * (ye - oy);
+    g.wsw = (xe - ox) * (oy - fly);
+    g.wse = (ox - flx) * (oy - fly);
+    g.e = 1.f;
+    if (need_z) {
+        const float p2 = a.pred[((long)img * 3 + 2) * Q + p];
+        g.e = expf((p2 > 0.f ? p2 : 0.f) * a.alpha[0]);
+    }
+    return g;
+}
+
+__device__ __forceinline__ void add_fix(unsigned long long* cell, float x) {
+    const float fl = floorf(x);
+    const unsigned lo = (unsigned)((x - fl) * 4294967296.0f);        // fract < 1, exact; cvt saturates
+    const int hi = (int)fl;
+    atomicAdd(cell, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)lo);
+}
+
+__device__ __forceinline__ float fix_to_float(unsigned long long v) {
+    return (float)((double)(long long)v * (1.0 / 4294967296.0));
+}
+
+__global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs a, int cap) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned long long* tile = (unsigned long long*)lds;            // [OT_CC][OT_TP] 32.32 fixed point
+    unsigned* list = (unsigned*)(tile + OT_CC * OT_TP);              // [cap]
+    __shared__ unsigned count;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bn = blockIdx.z, b = bn / a.N, n = bn % a.N;
+    const int tx0 = blockIdx.x * OT_W, ty0 = blockIdx.y * OT_H;
+    const long Q = (long)a.HH * a.WW, HWl = (long)a.H * a.W;
+    if (tid == 0) count = 0;
+    __syncthreads();
+
+    // ---- pass 1: compact the contributing sources of both directions
+    const int ry0 = max(ty0 - a.R, 0), ry1 = min(ty0 + OT_H - 1 + a.R, a.HH - 1);
+    const int rx0 = max(tx0 - a.R, 0), rx1 = min(tx0 + OT_W - 1 + a.R, a.WW - 1);
+    const int RH = ry1 - ry0 + 1, RW = rx1 - rx0 + 1;
+    const int xiters = (RW + 63) >> 6;
+    for (int d = 0; d < 2; ++d) {
+        const int img = (d * a.B + b) * a.N + n;
+        for (int row = wave; row < RH; row += OT_THREADS / 64) {
+            for (int it = 0; it < xiters; ++it) {
+                const int xc = it * 64 + lane;
+                bool hit = false;
+                if (xc < RW) {
+                    const SrcGeom g = src_geom(a, img, rx0 + xc, ry0 + row, false);
+                    hit = g.near_ && g.x0 >= tx0 - 1 && g.x0 <= tx0 + OT_W - 1 && g.y0 >= ty0 - 1 && g.y0 <= ty0 + OT_H - 1;
+                }
+                const unsigned long long m = __ballot(hit);
+                if (m) {
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(&count, (unsigned)__popcll(m));
+                    base = __shfl(base, 0);
+                    if (hit) list[base + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned)d << 16) | ((unsigned)row << 8) | (unsigned)xc;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int cnt = (int)count;
+
+    // ---- pass 2: 128 feature planes in 16 chunks of 8, then [128, 129, norm | max | count]
+    float* abase = a.acc + (long)bn * 133 * Q;
+    float* tmax = (float*)(tile + 3 * OT_TP);          // last chunk only: fp32 max plane, uint count plane
+    unsigned* tcnt = (unsigned*)(tmax + OT_TP);
+    for (int k = 0; k < 17; ++k) {
+        const bool last = (k == 16);
+        const int n64 = (last ? 3 : OT_CC) * OT_TP;
+        for (int i = tid; i < n64; i += OT_THREADS) tile[i] = 0ull;
+        if (last)
+            for (int i = tid; i < OT_TP; i += OT_THREADS) { tmax[i] = 1.0f; tcnt[i] = 0u; }
+        __syncthreads();
+        for (int e = tid; e < cnt; e += OT_THREADS) {
+            const unsigned ent = list[e];
+            const int d = ent >> 16, y = ry0 + ((ent >> 8) & 255), x = rx0 + (ent & 255);
+            const int db = d * a.B + b, img = db * a.N + n;
+            const SrcGeom g = src_geom(a, img, x, y, true);
+            const int off = (g.y0 - (ty0 - 1)) * OT_TPW + (g.x0 - (tx0 - 1));
+            const long p = (long)y * a.WW + x;
+            const long lr = (long)a.iy[y] * a.W + a.ix[x];
+            if (!last) {
+                float v[OT_CC];
+#pragma unroll
+                for (int cc = 0; cc < OT_CC; ++cc) {
+                    const int c = k * OT_CC + cc;
+                    if (c < 64) v[cc] = a.imnet_out[((long)db * 64 + c) * Q + p];
+                    else if (c == 64) v[cc] = g.p0;
+                    else if (c == 65) v[cc] = g.p1;
+                    else v[cc] = a.feat_lr[((long)db * 64 + (c - 66)) * HWl + lr];
+                }
+#pragma unroll
+                for (int cc = 0; cc < OT_CC; ++cc) {
+                    const float ve = v[cc] * g.e;
+                    unsigned long long* tc = tile + cc * OT_TP + off;
+                    add_fix(tc, ve * g.wnw);
+                    add_fix(tc + 1, ve * g.wne);
+                    add_fix(tc + OT_TPW, ve * g.wsw);
+                    add_fix(tc + OT_TPW + 1, ve * g.wse);
+                }
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    const float ve = (cc < 2) ? a.feat_lr[((long)db * 64 + 62 + cc) * HWl + lr] * g.e : g.e;
+                    unsigned long long* tc = tile + cc * OT_TP + off;
+                    add_fix(tc, ve * g.wnw);
+                    add_fix(tc + 1, ve * g.wne);
+                    add_fix(tc + OT_TPW, ve * g.wsw);
+                    add_fix(tc + OT_TPW + 1, ve * g.wse);
+                }
+                float* tm = tmax + off;
+                atomic_max_float(tm, g.e * g.wnw);
+                atomic_max_float(tm + 1, g.e * g.wne);
+                atomic_max_float(tm + OT_TPW, g.e * g.wsw);
+                atomic_max_float(tm + OT_TPW + 1, g.e * g.wse);
+                unsigned* tn = tcnt + off;
+                atomicAdd(tn, 1u);
+                atomicAdd(tn + 1, 1u);
+                atomicAdd(tn + OT_TPW, 1u);
+                atomicAdd(tn + OT_TPW + 1, 1u);
+            }
+        }
+        __syncthreads();
+        const int nplanes = last ? 5 : OT_CC;
+        for (int i = tid; i < nplanes * OT_H * OT_W; i += OT_THREADS) {
+            const int cc = i >> 10, rem = i & 1023, ly = rem >> 6, lx = rem & 63;
+            const int Y = ty0 + ly, X = tx0 + lx;
+            if (Y >= a.HH || X >= a.WW) continue;
+            const int cell = (ly + 1) * OT_TPW + lx + 1;
+            float v;
+            if (!last || cc < 3) v = fix_to_float(tile[cc * OT_TP + cell]);
+            else if (cc == 3) v = tmax[cell];
+            else v = (float)tcnt[cell];
+            abase[(long)(k * OT_CC + cc) * Q + (long)Y * a.WW + X] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// far sources (footprint outside their own +-R neighbourhood): rare; global atomics, after the owner pass
+__global__ __launch_bounds__(256) void splat_far_kernel(MotifSplatArgs a, int tiles_x) {
+    const int img = blockIdx.z;
+    const int n = img % a.N, db = img / a.N, b = db % a.B;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int X = tx * 64 + (threadIdx.x & 63), Y = ty * 4 + (threadIdx.x >> 6);
-    if (X >= WW || Y >= HH) return;
-    const long Q = (long)HH * WW, p = (long)Y * WW + X;
-    const float p0 = pred[((long)img * 3 + 0) * Q + p];
-    const float p1 = pred[((long)img * 3 + 1) * Q + p];
-    const float p2 = pred[((long)img * 3 + 2) * Q + p];
-    const float fx = (p0 * s20) * sr, fy = (p1 * s20) * sr;          // Ours.py:794
-    const float zz = (p2 > 0.f ? p2 : 0.f) * alpha[0];
-    const float e = expf(zz);
+    if (X >= a.WW || Y >= a.HH) return;
+    const SrcGeom g0 = src_geom(a, img, X, Y, false);
+    if (g0.near_) return;
+    const long Q = (long)a.HH * a.WW, p = (long)Y * a.WW + X, HWl = (long)a.H * a.W;
+    const float p0 = g0.p0, p1 = g0.p1;
+    const float p2 = a.pred[((long)img * 3 + 2) * Q + p];
+    const float e = expf((p2 > 0.f ? p2 : 0.f) * a.alpha[0]);
+    const float fx = (p0 * a.s20) * a.sr, fy = (p1 * a.s20) * a.sr;
     Scatter s;
-    s.init(corners_of(X, Y, fx, fy), HH, WW);
-    float* abase = acc + (long)(b * N + n) * 133 * Q;
-    const int slice = blockIdx.y;
-    const int c_lo = slice * (130 / SPLAT_SLICES), c_hi = c_lo + (130 / SPLAT_SLICES);
-    const long lr = (long)iy[Y] * W + ix[X];
-    const long HWl = (long)H * W;
-    for (int c = c_lo; c < c_hi; ++c) {
+    const float ox = (float)X + fx, oy = (float)Y + fy;
+    // far targets may be anywhere (or nowhere): clamp before the int conversion, bounds tests do the rest
+    if (!(ox > -4.f && ox < (float)a.WW + 4.f && oy > -4.f && oy < (float)a.HH + 4.f)) return;
+    s.init(corners_of(X, Y, fx, fy), a.HH, a.WW);
+    float* abase = a.acc + (long)(b * a.N + n) * 133 * Q;
+    const long lr = (long)a.iy[Y] * a.W + a.ix[X];
+    for (int c = 0; c < 130; ++c) {
         float v;
-        if (c < 64) v = imnet_out[((long)db * 64 + c) * Q + p];
+        if (c < 64) v = a.imnet_out[((long)db * 64 + c) * Q + p];
         else if (c == 64) v = p0;
         else if (c == 65) v = p1;
-        else v = feat_lr[((long)db * 64 + (c - 66)) * HWl + lr];
+        else v = a.feat_lr[((long)db * 64 + (c - 66)) * HWl + lr];
         s.add(abase + (long)c * Q, v * e);
     }
-    if (slice == 0) {
-        s.add(abase + 130L * Q, e);
-        s.max(abase + 131L * Q, e);
-        s.count(abase + 132L * Q, 1.0f);
-    }
+    s.add(abase + 130L * Q, e);
+    s.max(abase + 131L * Q, e);
+    s.count(abase + 132L * Q, 1.0f);
 }
 
 extern "C" int motif_splat_motif_fwd(const float* imnet_out, const float* pred, const float* feat_lr,
@@ -150,10 +333,17 @@ extern "C" int motif_splat_motif_fwd(const float* imnet_out, const float* pred, 
                                      float* acc, int B, int N, int H, int W, int HH, int WW, void* stream) {
     if (!imnet_out || !pred || !feat_lr || !iy || !ix || !alpha || !acc) return MOTIF_EINVAL;
     if (B < 1 || N < 1 || H < 1 || W < 1 || HH < 1 || WW < 1) return MOTIF_EINVAL;
+    MotifSplatArgs a{imnet_out, pred, feat_lr, iy, ix, alpha, 20.0f, flow_scale, acc, B, N, H, W, HH, WW, 16};
+    const int cap = 2 * (OT_H + 2 * a.R) * (OT_W + 2 * a.R);
+    const size_t lds = (size_t)OT_CC * OT_TP * 8 + (size_t)cap * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)splat_owner_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((WW + OT_W - 1) / OT_W, (HH + OT_H - 1) / OT_H, B * N);
+    splat_owner_kernel<<<grid, OT_THREADS, lds, (hipStream_t)stream>>>(a, cap);
+    MOTIF_LAUNCH_CHECK();
     const int tiles_x = (WW + 63) / 64, tiles_y = (HH + 3) / 4;
-    dim3 grid(tiles_x * tiles_y, SPLAT_SLICES, 2 * B * N);
-    splat_motif_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(imnet_out, pred, feat_lr, iy, ix, alpha, 20.0f, flow_scale,
-                                                              acc, B, N, H, W, HH, WW, tiles_x);
+    dim3 grid2(tiles_x * tiles_y, 1, 2 * B * N);
+    splat_far_kernel<<<grid2, 256, 0, (hipStream_t)stream>>>(a, tiles_x);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

@@ -258,8 +258,7 @@ def splat_motif(imnet_out, pred, feat_lr, iy, ix, alpha, flow_scale, B, N, HH, W
     _, _, h, w = feat_lr.shape
     if acc is None:
         acc = torch.empty(B * N, 133, HH, WW, dtype=torch.float32, device=pred.device)
-    acc.zero_()
-    acc[:, 131].fill_(1.0)
+    # no zero fill: the owner-computes kernel writes every accumulator cell (max plane starts at 1)
     check(lib.motif_splat_motif_fwd(_p(imnet_out), _p(pred), _p(feat_lr), _p(iy), _p(ix), _p(alpha.detach()), float(flow_scale), _p(acc),
                                     B, N, h, w, HH, WW, _stream()), "motif_splat_motif_fwd")
     return acc

@@ -388,3 +388,37 @@ def test_siren_kernels_vs_torch(HW):
         r = ref.synth_net(allin.reshape(B * N, 198, Q).permute(0, 2, 1)).permute(0, 2, 1).reshape(B, N, 3, HH, WW).permute(1, 0, 2, 3, 4).clamp(0, 1)
     o = ops.siren_synth(mine.synth_net.packed(), acc.to(dev()), res.to(dev()), iy, ix, times.to(dev()), B, N, HH, WW)
     close(o, r, 2e-5, 1e-4, "synth")
+
+
+# ------------------------------------------------------------------------------------------- fused MoTIF splat
+@pytest.mark.parametrize("far", [False, True])
+def test_splat_motif_owner_computes_vs_kernel_text(far):
+    """motif_splat_motif_fwd (owner-computes tiles + far-source fallback) == the reference composition
+    cat(feat*e^z, e^z) -> sum splat, max splat, count splat, both directions added (Ours.py:777-816)."""
+    from oracle import native
+    from motif_amd import ops
+    B, N, H, W, s = 2, 2, 12, 20, 4
+    HH, WW = H * s, W * s
+    Q = HH * WW
+    iy, ix, _, _ = _tables(H, W, HH, WW)
+    iyc, ixc = iy.cpu().long(), ix.cpu().long()
+    imnet_out = rnd(2 * B, 64, HH, WW, seed=1)
+    feat_lr = rnd(2 * B, 64, H, W, seed=2)
+    pred = rnd(2 * B * N, 3, HH, WW, seed=3, scale=0.05)
+    if far:
+        pred[:, :2, 5:9, 7:30] *= 12.0       # |flow| up to ~48 px > the 16 px owner halo -> fallback path
+        pred[0, 0, 20, 40] = 1e6              # absurd flow: must simply vanish
+    alpha = torch.tensor([-20.0])
+    flow = pred[:, :2] * 20.0 * (HH / H)
+    z = F.relu(pred[:, 2:3]) * alpha
+    ez = z.exp()
+    feat_low = feat_lr[:, :, iyc][:, :, :, ixc]
+    rep = lambda t: t.repeat(1, N, 1, 1).reshape(2 * B * N, -1, HH, WW)
+    feat_all = torch.cat([rep(imnet_out), pred[:, :2], rep(feat_low)], 1)
+    ssum = native.splat(torch.cat([feat_all * ez, ez], 1), flow, "sum").reshape(2, B * N, 131, HH, WW).sum(0)
+    smax = native.splat(ez, flow, "max").reshape(2, B * N, 1, HH, WW).max(0)[0]
+    scnt = native.splat(torch.ones_like(ez), flow, "count").reshape(2, B * N, 1, HH, WW).sum(0)
+    acc = ops.splat_motif(imnet_out.to(dev()), pred.to(dev()), feat_lr.to(dev()), iy, ix, alpha.to(dev()), HH / H, B, N, HH, WW).cpu()
+    assert torch.equal(acc[:, 132:133], scnt), "count plane must be exact"
+    close(acc[:, 131:132], smax, 1e-6, 1e-6, "max plane")
+    close(acc[:, :131], ssum, 3e-5, 1e-5, "sum planes")
