@@ -70,6 +70,15 @@ def instrumented_clip(model, sample):
     ms = sum(t for t, _ in big)
     fl = conv_flops([l for _, l in big])
     all_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
+    if os.environ.get("MOTIF_BENCH_SHAPES"):
+        shapes = {}
+        for (e0, e1, _), l in zip(events, log):
+            t = shapes.setdefault(l, [0, 0.0])
+            t[0] += 1
+            t[1] += e0.elapsed_time(e1)
+        print("# conv shapes: (N,Cout,Cin,groups,KH,KW,Ho,Wo) launches total_ms TFLOP/s", file=sys.stderr)
+        for l, (cnt, ms_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+            print("# %-40s %5d %9.3f %8.1f" % (l, cnt, ms_, conv_flops([l]) * cnt / (ms_ * 1e-3) / 1e12), file=sys.stderr)
     return dict(launches=len(big), ms=ms, flops=fl, all_conv_ms=all_ms, all_conv_flops=conv_flops(log), all_launches=len(log))
 
 

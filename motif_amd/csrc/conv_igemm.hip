@@ -14,6 +14,7 @@
 // dilation and group count on the path (3x3 s1/s2, 1x1, 7x7 s2, dilated PWC refiner, grouped).
 // Fused: channel concat of two inputs, bias, residual, activation (per channel range).
 #include "common.h"
+#include <stdlib.h>
 
 struct ConvArgs {
     const float* in0; const float* in1; const float* wp; const float* bias; const float* res; float* out;
@@ -23,6 +24,7 @@ struct ConvArgs {
     int KH, KW, stride, pad, dil, pad_mode;
     int act, act2, act_split, res_mode;
     int CK, PH, PW, Kpad, tiles_x, ncg;
+    int dbg;   // tuning aid: 1 = skip staging, 2 = skip MFMA loop
 };
 
 // Limits of one reduction chunk (host planner keeps to them): patch elements <= PATCH_MAX, packed weight
@@ -30,6 +32,15 @@ struct ConvArgs {
 // being multiplied (global -> VGPR issue-early, VGPR -> LDS write-late; two LDS buffers, one barrier per chunk).
 #define PATCH_MAX 6144
 #define WCHUNK_MAX 8192
+
+template <int ACT>
+__device__ __forceinline__ float act_c(float v) {
+    if constexpr (ACT == MOTIF_ACT_RELU) return v > 0.f ? v : 0.f;
+    else if constexpr (ACT == MOTIF_ACT_LRELU) return v > 0.f ? v : 0.1f * v;
+    else if constexpr (ACT == MOTIF_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    else if constexpr (ACT == MOTIF_ACT_TANH) return tanhf(v);
+    else return v;
+}
 
 template <int NC, int RPW>
 __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) {
@@ -50,25 +61,40 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
     float* patch0 = smem;
     float* wl0 = patch0 + 2 * patch_elems;
     int* koff = (int*)(wl0 + 2 * KC * WN);
-    int* soff = koff + KC;
+    float* bias_s = (float*)(koff + KC);      // [WN] bias of this cout group (zeros if none)
 
-    // one-off tables.  soff[e]: chunk-local channel (bits 24..) | input offset inside a plane (0xFFFFFF = padding)
+    const long HW = (long)a.H * a.W;
+    // chunk-invariant staging plan, in registers: element e = tid + NT*j of the [CK][PH][PW] patch comes from
+    // input offset eoff[j] = c*HW + iy*W + ix relative to the chunk's first channel plane (-1: padding),
+    // ech[j] = chunk-local channel (to cut off the tail chunk).  Integer divisions happen once per block.
     const int iy0 = ty * 8 * a.stride - a.pad, ix0 = tx * 32 * a.stride - a.pad;
-    for (int e = tid; e < CKPHW; e += NT) {
-        const int c = e / PHW, p = e - c * PHW;
-        const int py = p / a.PW, px = p - py * a.PW;
-        int iy = iy0 + py, ix = ix0 + px;
-        if (a.pad_mode == 1) {
-            if (iy < 0) iy = -iy; else if (iy >= a.H) iy = 2 * (a.H - 1) - iy;
-            if (ix < 0) ix = -ix; else if (ix >= a.W) ix = 2 * (a.W - 1) - ix;
+    int eoff[NE_MAX];
+    int ech[NE_MAX];
+#pragma unroll
+    for (int j = 0; j < NE_MAX; ++j) {
+        const int e = tid + NT * j;
+        eoff[j] = -1;
+        ech[j] = 1 << 20;
+        if (e < CKPHW) {
+            const int c = e / PHW, p = e - c * PHW;
+            const int py = p / a.PW, px = p - py * a.PW;
+            int iy = iy0 + py, ix = ix0 + px;
+            if (a.pad_mode == 1) {
+                if (iy < 0) iy = -iy; else if (iy >= a.H) iy = 2 * (a.H - 1) - iy;
+                if (ix < 0) ix = -ix; else if (ix >= a.W) ix = 2 * (a.W - 1) - ix;
+            }
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) eoff[j] = c * (int)HW + iy * a.W + ix;
+            ech[j] = c;
         }
-        const int go = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? iy * a.W + ix : 0xFFFFFF;
-        soff[e] = (c << 24) | go;
     }
     for (int kk = tid; kk < KC; kk += NT) {
         const int c = kk / T, t = kk - c * T;
         const int ky = t / a.KW, kx = t - ky * a.KW;
         koff[kk] = c * PHW + ky * a.dil * a.PW + kx * a.dil;
+    }
+    if (tid < WN) {
+        const int col = cg * WN + tid;
+        bias_s[tid] = (a.bias && col < a.Cout_g) ? a.bias[g * a.Cout_g + col] : 0.f;
     }
 
     f32x16 acc[NC][RPW];
@@ -79,7 +105,6 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const long HW = (long)a.H * a.W;
     const float* in0n = a.in0 + (long)n * a.in0_bs;
     const float* in1n = a.in1 ? a.in1 + (long)n * a.in1_bs : nullptr;
     const float* wbase = a.wp + ((long)(g * a.ncg + cg) * a.Kpad) * WN;
@@ -89,22 +114,15 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
 
     float pre[NE_MAX];
     f32x4 wreg[NW_MAX];
-    __syncthreads();
-
+    // the two-source concat never straddles a chunk when C0 % CK == 0 (host falls back to CK | C0 otherwise)
     auto issue = [&](int c0) {            // global -> registers for the chunk starting at channel c0
+        const int gch0 = g * a.Cin_g + c0;
+        const float* base = (gch0 < a.C0) ? in0n + (long)gch0 * HW : in1n + (long)(gch0 - a.C0) * HW;
+        const int cvalid = a.Cin_g - c0;                 // channels of this chunk that exist
 #pragma unroll
         for (int j = 0; j < NE_MAX; ++j) {
-            const int e = tid + NT * j;
             float v = 0.f;
-            if (e < CKPHW) {
-                const int so = soff[e];
-                const int ch = c0 + (so >> 24), go = so & 0xFFFFFF;
-                if (ch < a.Cin_g && go != 0xFFFFFF) {
-                    const int gch = g * a.Cin_g + ch;
-                    const float* pl = (gch < a.C0) ? in0n + (long)gch * HW : in1n + (long)(gch - a.C0) * HW;
-                    v = pl[go];
-                }
-            }
+            if (eoff[j] >= 0 && ech[j] < cvalid) v = base[eoff[j]];
             pre[j] = v;
         }
         const int r0 = c0 * T;
@@ -141,12 +159,13 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
     for (int c0 = 0; c0 < a.Cin_g; c0 += a.CK) {
         const bool more = c0 + a.CK < a.Cin_g;
         int rows_next = 0;
-        if (more) rows_next = issue(c0 + a.CK);          // loads fly while this chunk is multiplied
+        if (more && !(a.dbg & 1)) rows_next = issue(c0 + a.CK);          // loads fly while this chunk is multiplied
+        else if (more) { rows_next = a.Kpad - (c0 + a.CK) * T; if (rows_next > KC) rows_next = KC; }
 
         const float* patch = patch0 + cur * patch_elems;
         const float* wl = wl0 + cur * KC * WN + l31;
         const int steps = rows_cur >> 1;
-        int s = 0;
+        int s = (a.dbg & 2) ? steps : 0;
         for (; s + 4 <= steps; s += 4) {
             int ko[4];
 #pragma unroll
@@ -178,42 +197,76 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, patch[ko1 + pix[j]], acc[i][j], 0, 0, 0);
             }
         }
-        if (more) commit(cur ^ 1, rows_next);
+        if (more && !(a.dbg & 1)) commit(cur ^ 1, rows_next);
         __syncthreads();
         cur ^= 1;
         rows_cur = rows_next;
     }
 
-    // epilogue: C/D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*half (cout within tile)
+    // epilogue: C/D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*half (cout within tile).
+    // The activation / residual mode is block-uniform: dispatch once, keep the store loop branch-free.
     const int ox = tx * 32 + l31;
-    if (ox < a.Wo) {
-        const long HWo = (long)a.Ho * a.Wo;
+    if (ox >= a.Wo) return;
+    const long HWo = (long)a.Ho * a.Wo;
+    const int cobase = g * a.Cout_g + cg * WN;
+    const int climit = a.Cout_g - cg * WN;                 // valid couts in this group
+    auto run = [&](auto actf) {
 #pragma unroll
         for (int j = 0; j < RPW; ++j) {
             const int oy = ty * 8 + RPW * wave + j;
             if (oy >= a.Ho) continue;
             const long pixo = (long)oy * a.Wo + ox;
+            float* op = a.out + (long)n * a.out_bs + (long)cobase * HWo + pixo;
+            const float* rp = a.res_mode ? a.res + (long)n * a.res_bs + (long)cobase * HWo + pixo : nullptr;
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
+                float rv[16];
+                if (a.res_mode) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int col = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        rv[r] = (col < climit) ? rp[(long)col * HWo] : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int col = cg * WN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (col >= a.Cout_g) continue;
-                    const int co = g * a.Cout_g + col;
-                    float v = acc[i][j][r];
-                    if (a.bias) v += a.bias[co];
-                    const int act = (a.act_split > 0 && co >= a.act_split) ? a.act2 : a.act;
-                    float rv = 0.f;
-                    if (a.res_mode) rv = a.res[(long)n * a.res_bs + (long)co * HWo + pixo];
-                    if (a.res_mode == 1) v = act_apply(v + rv, act);
-                    else if (a.res_mode == 2) v = act_apply(v, act) + rv;
-                    else if (a.res_mode == 3) { v = act_apply(v, act) + rv; v = v > 0.f ? v : 0.f; }
-                    else if (a.res_mode == 4) v = act_apply(v, act) * rv;
-                    else v = act_apply(v, act);
-                    a.out[(long)n * a.out_bs + (long)co * HWo + pixo] = v;
+                    const int col = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[i][j][r] + bias_s[col];
+                    v = actf(v, a.res_mode ? rv[r] : 0.f, cobase + col);
+                    if (col < climit) op[(long)col * HWo] = v;
                 }
             }
         }
+    };
+    const int rm = a.res_mode;
+    if (a.act_split > 0) {
+        run([&](float v, float rv, int co) {
+            const int act = co >= a.act_split ? a.act2 : a.act;
+            if (rm == 1) return act_apply(v + rv, act);
+            float y = act_apply(v, act);
+            if (rm == 2) y += rv; else if (rm == 3) { y += rv; y = y > 0.f ? y : 0.f; } else if (rm == 4) y *= rv;
+            return y;
+        });
+    } else if (rm == 0) {
+        switch (a.act) {
+            case MOTIF_ACT_RELU: run([](float v, float, int) { return act_c<MOTIF_ACT_RELU>(v); }); break;
+            case MOTIF_ACT_LRELU: run([](float v, float, int) { return act_c<MOTIF_ACT_LRELU>(v); }); break;
+            case MOTIF_ACT_SIGMOID: run([](float v, float, int) { return act_c<MOTIF_ACT_SIGMOID>(v); }); break;
+            case MOTIF_ACT_TANH: run([](float v, float, int) { return act_c<MOTIF_ACT_TANH>(v); }); break;
+            default: run([](float v, float, int) { return v; }); break;
+        }
+    } else if (rm == 1 && a.act == MOTIF_ACT_NONE) {
+        run([](float v, float rv, int) { return v + rv; });
+    } else if (rm == 1 && a.act == MOTIF_ACT_LRELU) {
+        run([](float v, float rv, int) { return act_c<MOTIF_ACT_LRELU>(v + rv); });
+    } else {
+        const int act = a.act;
+        run([&](float v, float rv, int) {
+            if (rm == 1) return act_apply(v + rv, act);
+            float y = act_apply(v, act);
+            if (rm == 2) y += rv; else if (rm == 3) { y += rv; y = y > 0.f ? y : 0.f; } else if (rm == 4) y *= rv;
+            return y;
+        });
     }
 }
 
@@ -260,19 +313,26 @@ bool plan_conv(const MotifConvDesc* d, ConvPlan* p) {
         return (long)c * PHW <= PATCH_MAX && (long)c * p->T * p->WN <= WCHUNK_MAX && c < 128 &&
                ((long)c * PHW * 4 + (long)c * p->T * p->WN * 4) <= 30 * 1024;
     };
+    // with two concatenated sources a chunk must not straddle them: CK | C0 (single group only)
+    const bool two = d->C1 > 0;
+    if (two && d->groups != 1) return false;
     int ck = 0;
     for (int c = 1; c <= p->Cin_g + 1; ++c) {
         if (!ok(c)) break;
-        if (((c * p->T) & 1) == 0) ck = c;
+        if (((c * p->T) & 1) == 0 && (!two || d->C0 % c == 0)) ck = c;
     }
     if (ck == 0) {                       // relax the LDS soft cap, keep the hard register limits
         for (int c = 1; c <= 2; ++c)
-            if (((c * p->T) & 1) == 0 && (long)c * PHW <= PATCH_MAX && (long)c * p->T * p->WN <= WCHUNK_MAX) { ck = c; break; }
+            if (((c * p->T) & 1) == 0 && (!two || d->C0 % c == 0) && (long)c * PHW <= PATCH_MAX && (long)c * p->T * p->WN <= WCHUNK_MAX) { ck = c; break; }
     }
     if (ck == 0) return false;
+    if (const char* e = getenv("MOTIF_CONV_CK")) {            // tuning aid
+        const int f = atoi(e);
+        if (f > 0 && f <= ck && ((f * p->T) & 1) == 0) ck = f;
+    }
     p->CK = ck;
     const size_t patch_elems = ((size_t)ck * PHW + 3) & ~(size_t)3;
-    p->lds = (2 * patch_elems + 2 * (size_t)ck * p->T * p->WN + (size_t)ck * p->T + (size_t)ck * PHW) * 4;
+    p->lds = (2 * patch_elems + 2 * (size_t)ck * p->T * p->WN + (size_t)ck * p->T + (size_t)p->WN) * 4;
     return p->lds <= 160 * 1024;
 }
 }  // namespace
@@ -312,6 +372,8 @@ extern "C" int motif_conv2d_fwd(const MotifConvDesc* d, const float* in0, const 
     a.tiles_x = (p.Wo + 31) / 32;
     const int tiles_y = (p.Ho + 7) / 8;
     a.ncg = p.ncg;
+    a.dbg = 0;
+    if (const char* e = getenv("MOTIF_CONV_DBG")) a.dbg = atoi(e);
     dim3 grid(a.tiles_x * tiles_y, d->groups * p.ncg, d->N);
     hipStream_t s = (hipStream_t)stream;
     // small grids: one output row per wave (8 waves per tile) so that every SIMD still holds several waves
@@ -321,7 +383,8 @@ extern "C" int motif_conv2d_fwd(const MotifConvDesc* d, const float* in0, const 
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
     const long blocks = (long)grid.x * grid.y * grid.z;
-    const bool fine = blocks < 3L * cus;
+    bool fine = true;   // measured: one output row per wave (8 waves per tile) wins at every grid size
+    if (const char* e = getenv("MOTIF_CONV_RPW")) fine = (atoi(e) == 1);   // tuning aid
 #define MOTIF_LAUNCH_CONV(NCV, RPWV)                                                                                         \
     do {                                                                                                                     \
         if (p.lds > 64 * 1024)                                                                                               \

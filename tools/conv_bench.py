@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Time selected conv-engine shapes in isolation (also the target of rocprofv3 --pmc runs)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from motif_amd.models.modules.layers import Conv2d
+
+SHAPES = [  # N, Cin, Cout, k, stride, H, W
+    (3, 64, 64, 3, 1, 180, 320),
+    (1, 128, 64, 3, 1, 180, 320),
+    (1, 128, 64, 3, 1, 90, 160),
+    (1, 64, 216, 3, 1, 180, 320),
+    (1, 128, 64, 3, 1, 45, 80),
+    (2, 64, 64, 3, 1, 90, 160),
+    (8, 64, 64, 3, 1, 180, 320),
+]
+
+def main():
+    reps = int(os.environ.get("REPS", "20"))
+    only = os.environ.get("ONLY")
+    for i, (n, ci, co, k, s, h, w) in enumerate(SHAPES):
+        if only is not None and int(only) != i:
+            continue
+        m = Conv2d(ci, co, k, s, k // 2).cuda()
+        x = torch.randn(n, ci, h, w, device="cuda")
+        for _ in range(3):
+            y = m(x, act=1)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            y = m(x, act=1)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1000 / reps
+        fl = 2.0 * n * co * ci * k * k * (h // s) * (w // s)
+        print("shape %d %s: %.1f us  %.1f TFLOP/s" % (i, (n, ci, co, k, s, h, w), us, fl / us / 1e6), flush=True)
+
+if __name__ == "__main__":
+    main()
