@@ -59,13 +59,27 @@ def instrumented_clip(model, sample):
         log.append((x.shape[0], co, cig * plan.groups, plan.groups, kh, kw, out.shape[2], out.shape[3]))
         return out
 
+    orig_multi = ops.conv2d_multi
+
+    def timed_multi(plans, xs, x2s=None, *a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_multi(plans, xs, x2s, *a, **k)
+        e1.record()
+        co, cig, kh, kw = plans[0].weight.shape
+        events.append((e0, e1, co > 32 * plans[0].groups))
+        log.append((len(plans) * xs[0].shape[0], co, cig * plans[0].groups, plans[0].groups, kh, kw, out.shape[3], out.shape[4]))
+        return out
+
     ops.conv2d = timed_conv
+    ops.conv2d_multi = timed_multi
     try:
         model.feed_data(sample)
         model.test()
         torch.cuda.synchronize()
     finally:
         ops.conv2d = orig
+        ops.conv2d_multi = orig_multi
     big = [(e0.elapsed_time(e1), l) for (e0, e1, is_nc2), l in zip(events, log) if is_nc2]
     ms = sum(t for t, _ in big)
     fl = conv_flops([l for _, l in big])

@@ -110,6 +110,13 @@ int motif_conv2d_pack(const MotifConvDesc* d, const float* weight /*[Cout,Cin/gr
                       float* packed, void* stream);
 int motif_conv2d_fwd(const MotifConvDesc* d, const float* in0, const float* in1, const float* packed,
                      const float* bias /*may be NULL*/, const float* res /*may be NULL*/, float* out, void* stream);
+/* P (<= 4) independent convolutions of identical shape/hyper-parameters in ONE launch (the two alignment
+ * directions of PCD_Align and the h/c branches of the deformable ConvLSTM, Ours.py:107-172,289-290, are such
+ * sets): per-problem pointer arrays and batch strides (0 -> dense).  The desc's *_bs fields are ignored. */
+int motif_conv2d_fwd_multi(const MotifConvDesc* d, int P, const float* const* in0, const float* const* in1,
+                           const float* const* packed, const float* const* bias, const float* const* res,
+                           float* const* out, const long* in0_bs, const long* in1_bs, const long* res_bs,
+                           const long* out_bs, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * D2  modulated deformable convolution v2, forward.
@@ -122,6 +129,13 @@ int motif_dcn_v2_fwd(const float* input, const float* offset, const float* mask,
                      const float* bias, float* columns, float* out,
                      int B, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil,
                      int deformable_groups, long offset_bs, long mask_bs, int act, void* stream);
+/* P (<= 4) independent DCNs of identical shape in one launch pair; `columns` holds P*B*C*kh*kw*Ho*Wo floats;
+ * input_bs: per-problem batch stride of `input` (0 -> dense). */
+int motif_dcn_v2_fwd_multi(int P, const float* const* input, const long* input_bs, const float* const* offset,
+                           const float* const* mask, const float* const* packed, const float* const* bias,
+                           float* columns, float* const* out, int B, int C, int H, int W, int Cout, int kh, int kw,
+                           int stride, int pad, int dil, int deformable_groups, long offset_bs, long mask_bs,
+                           int act, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * C2  RAFT windowed correlation lookup.  Replaces alt_cuda_corr.forward (third-party, not vendored;

@@ -34,6 +34,9 @@ _SIGS = {
     "motif_conv2d_packed_size": (c_long, [POINTER(MotifConvDesc)]),
     "motif_conv2d_pack": (c_int, [POINTER(MotifConvDesc), P, P, P]),
     "motif_conv2d_fwd": (c_int, [POINTER(MotifConvDesc), P, P, P, P, P, P, P]),
+    "motif_conv2d_fwd_multi": (c_int, [POINTER(MotifConvDesc), c_int] + [POINTER(c_void_p)] * 6 + [POINTER(c_long)] * 4 + [P]),
+    "motif_dcn_v2_fwd_multi": (c_int, [c_int, POINTER(c_void_p), POINTER(c_long)] + [POINTER(c_void_p)] * 4 + [P, POINTER(c_void_p)]
+                               + [c_int] * 11 + [c_long, c_long, c_int, P]),
     "motif_dcn_v2_fwd": (c_int, [P, P, P, P, P, P, P] + [c_int] * 11 + [c_long, c_long, c_int, P]),
     "motif_raft_corr_lookup": (c_int, [P, P, P, c_float, P] + [c_int] * 7 + [c_int, c_int, c_float, P]),
     "motif_corr81_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -16,10 +16,13 @@
 #include "common.h"
 #include <stdlib.h>
 
+#define MOTIF_MAX_PROBLEMS 4
 struct ConvArgs {
-    const float* in0; const float* in1; const float* wp; const float* bias; const float* res; float* out;
-    long in0_bs, in1_bs, res_bs, out_bs;
-    int C0, H, W, Ho, Wo;
+    // up to MOTIF_MAX_PROBLEMS independent convolutions of identical shape in one launch (blockIdx.z = p*N + n)
+    const float* in0[MOTIF_MAX_PROBLEMS]; const float* in1[MOTIF_MAX_PROBLEMS]; const float* wp[MOTIF_MAX_PROBLEMS];
+    const float* bias[MOTIF_MAX_PROBLEMS]; const float* res[MOTIF_MAX_PROBLEMS]; float* out[MOTIF_MAX_PROBLEMS];
+    long in0_bs[MOTIF_MAX_PROBLEMS], in1_bs[MOTIF_MAX_PROBLEMS], res_bs[MOTIF_MAX_PROBLEMS], out_bs[MOTIF_MAX_PROBLEMS];
+    int N, C0, H, W, Ho, Wo;
     int Cin_g, Cout_g, Cout;
     int KH, KW, stride, pad, dil, pad_mode;
     int act, act2, act_split, res_mode;
@@ -52,7 +55,10 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
     const int g = blockIdx.y / a.ncg, cg = blockIdx.y % a.ncg;
-    const int n = blockIdx.z;
+    const int pz = blockIdx.z / a.N, n = blockIdx.z - pz * a.N;
+    const float* a_in0 = a.in0[pz]; const float* a_in1 = a.in1[pz]; const float* a_wp = a.wp[pz];
+    const float* a_bias = a.bias[pz]; const float* a_res = a.res[pz]; float* a_out = a.out[pz];
+    const long a_in0_bs = a.in0_bs[pz], a_in1_bs = a.in1_bs[pz], a_res_bs = a.res_bs[pz], a_out_bs = a.out_bs[pz];
     const int PHW = a.PH * a.PW;
     const int T = a.KH * a.KW;
     const int KC = a.CK * T;                  // rows per full chunk (host guarantees even)
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
     }
     if (tid < WN) {
         const int col = cg * WN + tid;
-        bias_s[tid] = (a.bias && col < a.Cout_g) ? a.bias[g * a.Cout_g + col] : 0.f;
+        bias_s[tid] = (a_bias && col < a.Cout_g) ? a_bias[g * a.Cout_g + col] : 0.f;
     }
 
     f32x16 acc[NC][RPW];
@@ -105,9 +111,9 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const float* in0n = a.in0 + (long)n * a.in0_bs;
-    const float* in1n = a.in1 ? a.in1 + (long)n * a.in1_bs : nullptr;
-    const float* wbase = a.wp + ((long)(g * a.ncg + cg) * a.Kpad) * WN;
+    const float* in0n = a_in0 + (long)n * a_in0_bs;
+    const float* in1n = a_in1 ? a_in1 + (long)n * a_in1_bs : nullptr;
+    const float* wbase = a_wp + ((long)(g * a.ncg + cg) * a.Kpad) * WN;
     int pix[RPW];
 #pragma unroll
     for (int j = 0; j < RPW; ++j) pix[j] = (RPW * wave + j) * a.stride * a.PW + l31 * a.stride;
@@ -216,8 +222,8 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
             const int oy = ty * 8 + RPW * wave + j;
             if (oy >= a.Ho) continue;
             const long pixo = (long)oy * a.Wo + ox;
-            float* op = a.out + (long)n * a.out_bs + (long)cobase * HWo + pixo;
-            const float* rp = a.res_mode ? a.res + (long)n * a.res_bs + (long)cobase * HWo + pixo : nullptr;
+            float* op = a_out + (long)n * a_out_bs + (long)cobase * HWo + pixo;
+            const float* rp = a.res_mode ? a_res + (long)n * a_res_bs + (long)cobase * HWo + pixo : nullptr;
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
                 float rv[16];
@@ -352,18 +358,26 @@ extern "C" int motif_conv2d_pack(const MotifConvDesc* d, const float* weight, fl
     return MOTIF_OK;
 }
 
-extern "C" int motif_conv2d_fwd(const MotifConvDesc* d, const float* in0, const float* in1, const float* packed,
-                                const float* bias, const float* res, float* out, void* stream) {
+extern "C" int motif_conv2d_fwd_multi(const MotifConvDesc* d, int P, const float* const* in0, const float* const* in1,
+                                      const float* const* packed, const float* const* bias, const float* const* res,
+                                      float* const* out, const long* in0_bs, const long* in1_bs, const long* res_bs,
+                                      const long* out_bs, void* stream) {
     ConvPlan p;
     if (!plan_conv(d, &p)) return MOTIF_ELIMIT;
-    if (!in0 || !packed || !out || (d->C1 > 0 && !in1) || (d->res_mode && !res) || d->N < 1) return MOTIF_EINVAL;
+    if (P < 1 || P > MOTIF_MAX_PROBLEMS || !in0 || !packed || !out || d->N < 1) return MOTIF_EINVAL;
     ConvArgs a;
-    a.in0 = in0; a.in1 = in1; a.wp = packed; a.bias = bias; a.res = res; a.out = out;
     const long HW = (long)d->H * d->W, HWo = (long)p.Ho * p.Wo;
-    a.in0_bs = d->in0_bs ? d->in0_bs : (long)d->C0 * HW;
-    a.in1_bs = d->in1_bs ? d->in1_bs : (long)d->C1 * HW;
-    a.res_bs = d->res_bs ? d->res_bs : (long)d->Cout * HWo;
-    a.out_bs = d->out_bs ? d->out_bs : (long)d->Cout * HWo;
+    for (int i = 0; i < MOTIF_MAX_PROBLEMS; ++i) {
+        const int j = i < P ? i : 0;
+        if (!in0[j] || !packed[j] || !out[j] || (d->C1 > 0 && (!in1 || !in1[j])) || (d->res_mode && (!res || !res[j]))) return MOTIF_EINVAL;
+        a.in0[i] = in0[j]; a.in1[i] = (in1 && d->C1 > 0) ? in1[j] : nullptr; a.wp[i] = packed[j];
+        a.bias[i] = bias ? bias[j] : nullptr; a.res[i] = (res && d->res_mode) ? res[j] : nullptr; a.out[i] = out[j];
+        a.in0_bs[i] = (in0_bs && in0_bs[j]) ? in0_bs[j] : (long)d->C0 * HW;
+        a.in1_bs[i] = (in1_bs && in1_bs[j]) ? in1_bs[j] : (long)d->C1 * HW;
+        a.res_bs[i] = (res_bs && res_bs[j]) ? res_bs[j] : (long)d->Cout * HWo;
+        a.out_bs[i] = (out_bs && out_bs[j]) ? out_bs[j] : (long)d->Cout * HWo;
+    }
+    a.N = d->N;
     a.C0 = d->C0; a.H = d->H; a.W = d->W; a.Ho = p.Ho; a.Wo = p.Wo;
     a.Cin_g = p.Cin_g; a.Cout_g = p.Cout_g; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil; a.pad_mode = d->pad_mode;
@@ -374,15 +388,8 @@ extern "C" int motif_conv2d_fwd(const MotifConvDesc* d, const float* in0, const 
     a.ncg = p.ncg;
     a.dbg = 0;
     if (const char* e = getenv("MOTIF_CONV_DBG")) a.dbg = atoi(e);
-    dim3 grid(a.tiles_x * tiles_y, d->groups * p.ncg, d->N);
+    dim3 grid(a.tiles_x * tiles_y, d->groups * p.ncg, d->N * P);
     hipStream_t s = (hipStream_t)stream;
-    // small grids: one output row per wave (8 waves per tile) so that every SIMD still holds several waves
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    }
-    const long blocks = (long)grid.x * grid.y * grid.z;
     bool fine = true;   // measured: one output row per wave (8 waves per tile) wins at every grid size
     if (const char* e = getenv("MOTIF_CONV_RPW")) fine = (atoi(e) == 1);   // tuning aid
 #define MOTIF_LAUNCH_CONV(NCV, RPWV)                                                                                         \
@@ -396,4 +403,11 @@ extern "C" int motif_conv2d_fwd(const MotifConvDesc* d, const float* in0, const 
 #undef MOTIF_LAUNCH_CONV
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
+}
+
+extern "C" int motif_conv2d_fwd(const MotifConvDesc* d, const float* in0, const float* in1, const float* packed,
+                                const float* bias, const float* res, float* out, void* stream) {
+    if (!d) return MOTIF_EINVAL;
+    const long bs0 = d->in0_bs, bs1 = d->in1_bs, bsr = d->res_bs, bso = d->out_bs;
+    return motif_conv2d_fwd_multi(d, 1, &in0, &in1, &packed, &bias, &res, &out, &bs0, &bs1, &bsr, &bso, stream);
 }

@@ -47,6 +47,43 @@ class TMB(nn.Module):
         self.f_process = nn.Sequential(Conv2d(64, 64, 3, 1, 1), nn.Identity(), Conv2d(64, 64, 3, 1, 1), nn.Identity())
 
 
+def convm(mods, xs, x2s=None, **kw):
+    """One launch for a list of same-shaped convolutions with different weights -> stacked [P,N,C,H,W]."""
+    return ops.conv2d_multi([m.plan() for m in mods], xs, x2s, **kw)
+
+
+def dcnm(mods, xs, feas, act=NONE):
+    oms = convm([m.conv_offset_mask for m in mods], feas, act=NONE, act2=ops.ACT_SIGMOID, act_split=2 * 8 * 9)
+    return ops.dcn_v2_multi([m.dplan() for m in mods], xs, list(oms), 8, act)
+
+
+def up2m(t, mul=1.0):
+    P, N, C, H, W = t.shape
+    return ops.resize_bilinear(t.view(P * N, C, H, W), (2 * H, 2 * W), False, mul).view(P, N, C, 2 * H, 2 * W)
+
+
+def pcd_align_multi(problems):
+    """problems: list (<= 4) of (PCD_Align module, "1"|"2", fea_a [L1,L2,L3], fea_b): the two alignment
+    directions of one module and the h/c branches of the deformable ConvLSTM are independent and of the
+    same shape, so each layer of `Ours.py:107-172` runs as ONE multi-problem launch.  -> [P,N,C,H,W]"""
+    g = lambda name: [getattr(m, name + "_" + s) for m, s, _, _ in problems]
+    A = lambda l: [p[2][l] for p in problems]
+    Bv = lambda l: [p[3][l] for p in problems]
+    o3 = convm(g("L3_offset_conv1"), A(2), Bv(2), act=LRELU)
+    o3 = convm(g("L3_offset_conv2"), list(o3), act=LRELU)
+    f3 = dcnm(g("L3_dcnpack"), A(2), list(o3), LRELU)
+    o2 = convm(g("L2_offset_conv1"), A(1), Bv(1), act=LRELU)
+    o2 = convm(g("L2_offset_conv2"), list(o2), list(up2m(o3, 2.0)), act=LRELU)
+    o2 = convm(g("L2_offset_conv3"), list(o2), act=LRELU)
+    f2 = dcnm(g("L2_dcnpack"), A(1), list(o2))
+    f2 = convm(g("L2_fea_conv"), list(f2), list(up2m(f3)), act=LRELU)
+    o1 = convm(g("L1_offset_conv1"), A(0), Bv(0), act=LRELU)
+    o1 = convm(g("L1_offset_conv2"), list(o1), list(up2m(o2, 2.0)), act=LRELU)
+    o1 = convm(g("L1_offset_conv3"), list(o1), act=LRELU)
+    f1 = dcnm(g("L1_dcnpack"), A(0), list(o1))
+    return convm(g("L1_fea_conv"), list(f1), list(up2m(f2)))
+
+
 class PCD_Align(nn.Module):
     """Pyramid / cascading / deformable alignment, 3 levels, both directions (`Ours.py:53-172`)."""
 
@@ -66,26 +103,29 @@ class PCD_Align(nn.Module):
             for n in ("A_l1", "B_l1", "A_l2", "B_l2", "A_l3", "B_l3"):
                 setattr(self, "TMB_" + n, TMB())
 
-    def _align(self, a, b, s):
-        g = lambda name: getattr(self, name + "_" + s)
-        o3 = g("L3_offset_conv1")(a[2], b[2], act=LRELU)
-        o3 = g("L3_offset_conv2")(o3, act=LRELU)
-        f3 = g("L3_dcnpack")(a[2], o3, act=LRELU)
-        o2 = g("L2_offset_conv1")(a[1], b[1], act=LRELU)
-        o2 = g("L2_offset_conv2")(o2, up2(o3, 2.0), act=LRELU)
-        o2 = g("L2_offset_conv3")(o2, act=LRELU)
-        f2 = g("L2_dcnpack")(a[1], o2)
-        f2 = g("L2_fea_conv")(f2, up2(f3), act=LRELU)
-        o1 = g("L1_offset_conv1")(a[0], b[0], act=LRELU)
-        o1 = g("L1_offset_conv2")(o1, up2(o2, 2.0), act=LRELU)
-        o1 = g("L1_offset_conv3")(o1, act=LRELU)
-        f1 = g("L1_dcnpack")(a[0], o1)
-        return g("L1_fea_conv")(f1, up2(f2))
-
     def forward(self, fea1, fea2, t=None, t_back=None):
         if t is not None or t_back is not None:
             raise NotImplementedError("temporal modulation is a training-time branch (Ours.py:393 passes None)")
-        return self._align(fea1, fea2, "1"), self._align(fea2, fea1, "2")     # the 128-ch concat is fused into `fusion`
+        y = pcd_align_multi([(self, "1", fea1, fea2), (self, "2", fea2, fea1)])
+        return y[0], y[1]                                     # the 128-ch concat is fused into `fusion`
+
+
+def easy_pcd_multi(mods, f1s, f2s):
+    """Easy_PCD.forward (`Ours.py:188-210`) for P <= 2 modules at once -> stacked [P,N,C,H,W]."""
+    b = f1s[0].shape[0]
+    l1 = [torch.stack([f1, f2], dim=1).flatten(0, 1) for f1, f2 in zip(f1s, f2s)]     # (b, n) order, Ours.py:192-194
+    l2 = convm([m.fea_L2_conv1 for m in mods], l1, act=LRELU)
+    l2 = convm([m.fea_L2_conv2 for m in mods], list(l2), act=LRELU)
+    l3 = convm([m.fea_L3_conv1 for m in mods], list(l2), act=LRELU)
+    l3 = convm([m.fea_L3_conv2 for m in mods], list(l3), act=LRELU)
+    pick = lambda t, i: t.view(b, 2, *t.shape[1:])[:, i]                              # batch-strided planar views
+    problems = []
+    for pi, m in enumerate(mods):
+        fa = [pick(l1[pi], 0), pick(l2[pi], 0), pick(l3[pi], 0)]
+        fb = [pick(l1[pi], 1), pick(l2[pi], 1), pick(l3[pi], 1)]
+        problems += [(m.pcd_align, "1", fa, fb), (m.pcd_align, "2", fb, fa)]
+    y = pcd_align_multi(problems)
+    return convm([m.fusion for m in mods], [y[2 * i] for i in range(len(mods))], [y[2 * i + 1] for i in range(len(mods))])
 
 
 class Easy_PCD(nn.Module):
@@ -99,15 +139,7 @@ class Easy_PCD(nn.Module):
         self.fusion = Conv2d(2 * nf, nf, 1, 1)
 
     def forward(self, f1, f2):
-        b = f1.shape[0]
-        l1 = torch.stack([f1, f2], dim=1).flatten(0, 1)                       # [2B,C,H,W], (b, n) order as Ours.py:192-194
-        l2 = self.fea_L2_conv2(self.fea_L2_conv1(l1, act=LRELU), act=LRELU)
-        l3 = self.fea_L3_conv2(self.fea_L3_conv1(l2, act=LRELU), act=LRELU)
-        pick = lambda t, i: t.view(b, 2, *t.shape[1:])[:, i]                  # batch-strided planar views
-        fea1 = [pick(l1, 0), pick(l2, 0), pick(l3, 0)]
-        fea2 = [pick(l1, 1), pick(l2, 1), pick(l3, 1)]
-        y1, y2 = self.pcd_align(fea1, fea2)
-        return self.fusion(y1, y2)
+        return easy_pcd_multi([self], [f1], [f2])[0]
 
 
 class ConvLSTMCell(nn.Module):
@@ -141,9 +173,8 @@ class DeformableConvLSTM(nn.Module):
         outs = []
         for i in range(t):
             xi = x[:, i]
-            h_temp = self.pcd_h(xi, h)
-            c_temp = self.pcd_c(xi, cs)
-            h, cs = self.cell_list[0](xi, [h_temp, c_temp])
+            hc = easy_pcd_multi([self.pcd_h, self.pcd_c], [xi, xi], [h, cs])        # h/c branches in one launch set
+            h, cs = self.cell_list[0](xi, [hc[0], hc[1]])
             outs.append(h)
         return outs
 
@@ -158,11 +189,12 @@ class BiDeformableConvLSTM(nn.Module):
 
     def forward(self, x):                          # [B,T,C,H,W] -> [B,T,C,H,W]
         b, t, c, h, w = x.shape
-        fwd = self.forward_net(x)
-        rev = self.forward_net(x.flip(1))[::-1]
+        # the forward and the time-reversed pass share weights and are independent (Ours.py:337-340):
+        # run them as one batch of 2B sequences
+        both = self.forward_net(torch.cat([x, x.flip(1)], dim=0))
         out = torch.empty(b, t, c, h, w, dtype=torch.float32, device=x.device)
         for i in range(t):
-            self.conv_1x1(fwd[i], rev[i], out=out[:, i])
+            self.conv_1x1(both[i][:b], both[t - 1 - i][b:], out=out[:, i])
         return out
 
 

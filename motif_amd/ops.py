@@ -102,6 +102,66 @@ def conv2d(plan, x, x2=None, act=ACT_NONE, res=None, res_mode=0, act2=ACT_NONE, 
     return out
 
 
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
+
+
+def conv2d_multi(plans, xs, x2s=None, act=ACT_NONE, ress=None, res_mode=0, act2=ACT_NONE, act_split=0):
+    """P <= 4 independent convolutions of identical shape in one launch -> stacked [P,N,Co,Ho,Wo]."""
+    lib = _lib.load()
+    P = len(plans)
+    xs = [x if _planar(x) else x.contiguous() for x in xs]
+    if x2s is not None:
+        x2s = [x if _planar(x) else x.contiguous() for x in x2s]
+    if ress is not None:
+        ress = [x if _planar(x) else x.contiguous() for x in ress]
+    n, c0, h, w = xs[0].shape
+    c1 = x2s[0].shape[1] if x2s is not None else 0
+    p0 = plans[0]
+    d = p0.desc(n, h, w, c0, c1)
+    d.act, d.act2, d.act_split, d.res_mode = act, act2, act_split, res_mode
+    kh, kw = p0.weight.shape[2:]
+    ho = (h + 2 * p0.pad - (p0.dil * (kh - 1) + 1)) // p0.stride + 1
+    wo = (w + 2 * p0.pad - (p0.dil * (kw - 1) + 1)) // p0.stride + 1
+    co = p0.weight.shape[0]
+    out = torch.empty(P, n, co, ho, wo, dtype=torch.float32, device=xs[0].device)
+    outs = list(out)
+    packs = [pl.packed() for pl in plans]
+    biases = [pl.bias.detach() if pl.bias is not None else None for pl in plans]
+    longs = lambda ts: (ctypes.c_long * P)(*[t.stride(0) for t in ts])
+    check(lib.motif_conv2d_fwd_multi(
+        ctypes.byref(d), P, _ptr_array(xs), _ptr_array(x2s) if x2s is not None else None, _ptr_array(packs),
+        _ptr_array(biases) if biases[0] is not None else None, _ptr_array(ress) if ress is not None else None, _ptr_array(outs),
+        longs(xs), longs(x2s) if x2s is not None else None, longs(ress) if ress is not None else None, longs(outs), _stream()),
+        "motif_conv2d_fwd_multi")
+    return out
+
+
+def dcn_v2_multi(dplans, xs, oms, dg=8, act=ACT_NONE, kh=3, kw=3, stride=1, pad=1, dil=1):
+    """P independent DCN_sep forwards (offset/mask tensors `oms` as produced by the fused conv_offset_mask)."""
+    lib = _lib.load()
+    P = len(dplans)
+    xs = [x if _planar(x) else x.contiguous() for x in xs]
+    oms = [_c(o) for o in oms]
+    b, c, h, w = xs[0].shape
+    co = dplans[0].weight.shape[0]
+    ho = (h + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+    wo = (w + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    t = kh * kw
+    cols = workspace(P * b * c * t * ho * wo, xs[0].device, "dcn_cols")
+    out = torch.empty(P, b, co, ho, wo, dtype=torch.float32, device=xs[0].device)
+    outs = list(out)
+    plans = [dp.plan() for dp in dplans]
+    packs = [pl.packed() for pl in plans]
+    biases = [dp.bias.detach() for dp in dplans]
+    masks = (ctypes.c_void_p * P)(*[o.data_ptr() + 4 * 2 * dg * t * ho * wo for o in oms])
+    bs = oms[0].stride(0)
+    check(lib.motif_dcn_v2_fwd_multi(P, _ptr_array(xs), (ctypes.c_long * P)(*[x.stride(0) for x in xs]), _ptr_array(oms), masks,
+                                     _ptr_array(packs), _ptr_array(biases), _p(cols), _ptr_array(outs), b, c, h, w, co, kh, kw,
+                                     stride, pad, dil, dg, bs, bs, act, _stream()), "motif_dcn_v2_fwd_multi")
+    return out
+
+
 class DcnPlan:
     """DCNv2 main weight viewed as a 1x1 conv over C*kh*kw column channels."""
 
