@@ -14,20 +14,42 @@
 // with the post-splat normalisation), and narrow heads (256 -> 3) run on the VALU, which has the same
 // fp32 rate as the f32 MFMA and no 32-row padding.
 #include "common.h"
+#include <stdlib.h>
 
 #define SIREN_THREADS 512
 #define SIREN_WAVES (SIREN_THREADS / 64)
+#ifndef SIREN_TP_IMNET
+#define SIREN_TP_IMNET 1
+#endif
+#ifndef SIREN_TP_FLOW
+#define SIREN_TP_FLOW 2
+#endif
+#ifndef SIREN_TP_SYNTH
+#define SIREN_TP_SYNTH 1
+#endif
 
-// ---------------------------------------------------------------- sin(x), Cody-Waite + cephes kernels
+// ---------------------------------------------------------------- sin(x)
+// Default: 2-term FMA Cody-Waite reduction by 2*pi, then the hardware v_sin_f32 on the small remainder.
+// Measured on MI355X against fp64 (tools/ubench_sin.hip): max abs error 3.8e-7 for |x| <= 300, independent
+// of the range (v_sin_f32 on the unreduced argument: 2.7e-6 at |x|<=30, 2.4e-5 at 300; ocml sinf 7e-8).
+// -DMOTIF_SIN_PRECISE selects a pi/2 reduction + cephes polynomials (1.2e-7) at ~4x the VALU cost.
 __device__ __forceinline__ float sin_cw(float x) {
+#ifndef MOTIF_SIN_PRECISE
+    // branch-free for every finite x: the fma keeps j*2pi_hi exact, so the reduction error is ~|j|*1e-14 and the
+    // result degrades only with the spacing of x itself; inf/nan give nan.
+    const float j = rintf(x * 0.15915494309189535f);
+    float r = fmaf(j, -6.2831854820251465f, x);
+    r = fmaf(j, 1.7484555e-7f, r);                       // -(2*pi - float(2*pi))
+    return __builtin_amdgcn_sinf(r * 0.15915494309189535f);
+#else
     float r;
     int q;
     if (__builtin_expect(fabsf(x) <= 3.0e4f, 1)) {
         const float j = rintf(x * 0.636619772367581343f);
-        r = fmaf(j, -1.57079637050628662109375f, x);   // exact product inside the fma
-        r = fmaf(j, 4.37113900018624283e-8f, r);        // -(pi/2 - float(pi/2))
+        r = fmaf(j, -1.57079637050628662109375f, x);
+        r = fmaf(j, 4.37113900018624283e-8f, r);
         q = (int)j;
-    } else {   // rare: reduce in fp64 (inf/nan propagate as nan)
+    } else {
         const double xd = (double)x;
         const double j = rint(xd * 0.63661977236758134308);
         double rd = fma(j, -1.57079632679489655800, xd);
@@ -40,6 +62,7 @@ __device__ __forceinline__ float sin_cw(float x) {
     const float cp = 1.0f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
     float v = (q & 1) ? cp : sp;
     return (q & 2) ? -v : v;
+#endif
 }
 
 __host__ __device__ constexpr int kmap(int s, int hf) { return 8 * (s >> 2) + 4 * hf + (s & 3); }
@@ -51,49 +74,64 @@ __host__ __device__ constexpr long mfma_layer_floats(int K, int M) { return (lon
 __host__ __device__ constexpr long valu_head_floats(int K, int M) { return (long)M * (pad8(K) / 8) * 8 + 4; }
 
 // ---------------------------------------------------------------- layer primitives
-template <int MT>
-__device__ __forceinline__ void init_bias(f32x16 (&acc)[MT], const float* bp, int hf) {
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = bp[(t * 16 + r) * 2 + hf];
-}
+// A wave processes TP = 2 pixel tiles (64 pixels) in lockstep: every A operand read from LDS feeds two
+// MFMAs, and while one tile's accumulators go through the sine (VALU) the other tile's MFMAs execute.
 
-// full layer: KS steps, MT output tiles, inputs h[KS] in registers
-template <int KS, int MT, int MTW>
-__device__ __forceinline__ void mfma_layer(const float (&h)[KS], f32x16 (&acc)[MT], const float* wp, int t0, int lane) {
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[(s * MTW + t0 + t) * 64 + lane], h[s], acc[t], 0, 0, 0);
-        if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler's LDS-read hoisting (VGPR pressure)
-    }
-}
-
-template <int MT>
-__device__ __forceinline__ void sine(const f32x16 (&acc)[MT], float (&h)[MT * 16]) {
+template <int TP, int MT>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[TP][MT], const float* bp, int hf) {
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            h[t * 16 + r] = sin_cw(30.0f * acc[t][r]);
-            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep at most 4 sin pipelines live
+            const float b = bp[(t * 16 + r) * 2 + hf];
+#pragma unroll
+            for (int p = 0; p < TP; ++p) acc[p][t][r] = b;
         }
 }
 
+// full layer: KS steps, MT output tiles, inputs h[TP][KS] in registers
+template <int KS, int MT, int MTW, int TP>
+__device__ __forceinline__ void mfma_layer(const float (&h)[TP][KS], f32x16 (&acc)[TP][MT], const float* wp, int t0, int lane) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const float w = wp[(s * MTW + t0 + t) * 64 + lane];
+#pragma unroll
+            for (int p = 0; p < TP; ++p) acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, h[p][s], acc[p][t], 0, 0, 0);
+        }
+        if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler's LDS-read hoisting (VGPR pressure)
+    }
+}
+
+template <int TP, int MT>
+__device__ __forceinline__ void sine(const f32x16 (&acc)[TP][MT], float (&h)[TP][MT * 16]) {
+#pragma unroll
+    for (int p = 0; p < TP; ++p)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                h[p][t * 16 + r] = sin_cw(30.0f * acc[p][t][r]);
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep at most 4 sin pipelines live
+            }
+}
+
 // VALU head partial: M outputs, inputs hc[32] are the k-steps [s0, s0+32) of a K-wide layer
-template <int M, int KQ>
-__device__ __forceinline__ void valu_head_partial(const float (&hc)[32], float (&sum)[M], const float* wv, int q0, int hf) {
+template <int M, int KQ, int TP>
+__device__ __forceinline__ void valu_head_partial(const float (&hc)[TP][32], float (&sum)[TP][M], const float* wv, int q0, int hf) {
 #pragma unroll
     for (int o = 0; o < M; ++o)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const f32x4 w = *(const f32x4*)(wv + ((o * KQ + q0 + q) * 2 + hf) * 4);
-            sum[o] = fmaf(w[0], hc[q * 4 + 0], sum[o]);
-            sum[o] = fmaf(w[1], hc[q * 4 + 1], sum[o]);
-            sum[o] = fmaf(w[2], hc[q * 4 + 2], sum[o]);
-            sum[o] = fmaf(w[3], hc[q * 4 + 3], sum[o]);
+#pragma unroll
+            for (int p = 0; p < TP; ++p) {
+                sum[p][o] = fmaf(w[0], hc[p][q * 4 + 0], sum[p][o]);
+                sum[p][o] = fmaf(w[1], hc[p][q * 4 + 1], sum[p][o]);
+                sum[p][o] = fmaf(w[2], hc[p][q * 4 + 2], sum[p][o]);
+                sum[p][o] = fmaf(w[3], hc[p][q * 4 + 3], sum[p][o]);
+            }
         }
 }
 
@@ -106,6 +144,7 @@ struct SirenArgs {
     const float* times;       // [B*N]
     float* out;
     int NB, N, B, H, W, HH, WW;   // NB = number of HR images processed
+    int stagger;                  // start offset of the second wave per SIMD, in s_sleep(127) units (~8k cycles)
 };
 
 enum { MODE_IMNET = 0, MODE_FLOW = 1, MODE_SYNTH = 2 };
@@ -133,7 +172,7 @@ template <int MODE> struct Layout {
     static constexpr long LDS_FLOATS = (MODE == MODE_IMNET) ? W3 : TOTAL;
 };
 
-template <int MODE>
+template <int MODE, int TP>
 __global__ __launch_bounds__(SIREN_THREADS) void siren_kernel(SirenArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using L = Layout<MODE>;
@@ -145,189 +184,272 @@ __global__ __launch_bounds__(SIREN_THREADS) void siren_kernel(SirenArgs a) {
     }
     __syncthreads();
 
+    // The two waves that share a SIMD run the same code from the same start and stay phase-locked: both in
+    // their MFMA stretch, then both in their sine (VALU) stretch, so the matrix and vector pipes never overlap
+    // (measured: MFMA busy 57 % + VALU busy 36 %).  Start the second wave of each SIMD half a tile late.
+    if (wave >= SIREN_WAVES / 2) {
+        const int naps = a.stagger;
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const long Q = (long)a.HH * a.WW;
     const long HWl = (long)a.H * a.W;
-    const int tiles_per_img = (int)((Q + 31) / 32);
-    const long total = (long)a.NB * tiles_per_img;
+    const int pairs_per_img = (int)((Q + 32 * TP - 1) / (32 * TP));
+    const long total = (long)a.NB * pairs_per_img;
 
     for (long work = (long)blockIdx.x * SIREN_WAVES + wave; work < total; work += (long)gridDim.x * SIREN_WAVES) {
-        const int img = (int)(work / tiles_per_img);
-        const long p = (long)(work % tiles_per_img) * 32 + l31;
-        const bool valid = p < Q;
-        const long pc = valid ? p : Q - 1;
-        const int Y = (int)(pc / a.WW), X = (int)(pc - (long)Y * a.WW);
-        const long lr = (long)a.iy[Y] * a.W + a.ix[X];
+        const int img = (int)(work / pairs_per_img);
+        const long pbase = (long)(work % pairs_per_img) * (32 * TP) + l31;
+        long pp[TP], pc[TP], lr[TP];
+        int Y[TP], X[TP];
+        bool valid[TP];
+#pragma unroll
+        for (int p = 0; p < TP; ++p) {
+            pp[p] = pbase + 32 * p;
+            valid[p] = pp[p] < Q;
+            pc[p] = valid[p] ? pp[p] : Q - 1;
+            Y[p] = (int)(pc[p] / a.WW);
+            X[p] = (int)(pc[p] - (long)Y[p] * a.WW);
+            lr[p] = (long)a.iy[Y[p]] * a.W + a.ix[X[p]];
+        }
 
         // ------------------------------------------------ layer 0: inputs fetched in B-operand form
-        f32x16 acc0[2];
-        init_bias<2>(acc0, lds + L::B0, hf);
+        f32x16 acc0[TP][2];
+        init_bias(acc0, lds + L::B0, hf);
         const float* w0 = lds + L::W0;
+        auto step0 = [&](int s, const float (&v)[TP]) {      // one k-step of layer 0 for both tiles
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float w = w0[(s * 2 + t) * 64 + lane];
+#pragma unroll
+                for (int p = 0; p < TP; ++p) acc0[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, v[p], acc0[p][t], 0, 0, 0);
+            }
+        };
         if constexpr (MODE == MODE_IMNET || MODE == MODE_FLOW) {
             // img = b2 (imnet) or b2*N + n (flow); source LR image = b2
             const int b2 = (MODE == MODE_FLOW) ? img / a.N : img;
-            const float* f = a.src_lr + (long)b2 * 64 * HWl + lr + (long)(4 * hf) * HWl;
-#pragma unroll 1
-            for (int q = 0; q < 8; ++q) {
-                float v[4];
+            const float* f[TP];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = f[(long)r * HWl];
-                f += 8 * HWl;
-                const float* wq = w0 + q * 4 * 2 * 64 + lane;
+            for (int p = 0; p < TP; ++p) f[p] = a.src_lr + (long)b2 * 64 * HWl + lr[p] + (long)(4 * hf) * HWl;
+            float v[4][TP];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int p = 0; p < TP; ++p) v[r][p] = f[p][(long)r * HWl];
+#pragma unroll 1
+            for (int q = 0; q < 8; ++q) {      // software pipelined: the gather of q+1 flies under the MFMAs of q
+                float vn[4][TP];
+#pragma unroll
+                for (int p = 0; p < TP; ++p) f[p] += 8 * HWl;
+                if (q < 7) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int p = 0; p < TP; ++p) vn[r][p] = f[p][(long)r * HWl];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) step0(q * 4 + r, v[r]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
-                        acc0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[(r * 2 + t) * 64], v[r], acc0[t], 0, 0, 0);
+                    for (int p = 0; p < TP; ++p) v[r][p] = vn[r][p];
             }
-            float e[4];
-            if constexpr (MODE == MODE_FLOW) {
-                e[0] = a.times[img % (a.B * a.N)]; e[1] = a.rel_y[Y]; e[2] = a.rel_x[X]; e[3] = 0.f;
-            } else {
-                e[0] = a.rel_y[Y]; e[1] = a.rel_x[X]; e[2] = 0.f; e[3] = 0.f;
+            float e[4][TP];
+#pragma unroll
+            for (int p = 0; p < TP; ++p) {
+                if constexpr (MODE == MODE_FLOW) {
+                    e[0][p] = a.times[img % (a.B * a.N)]; e[1][p] = a.rel_y[Y[p]]; e[2][p] = a.rel_x[X[p]]; e[3][p] = 0.f;
+                } else {
+                    e[0][p] = a.rel_y[Y[p]]; e[1][p] = a.rel_x[X[p]]; e[2][p] = 0.f; e[3][p] = 0.f;
+                }
             }
 #pragma unroll
             for (int s = 32; s < 36; ++s) {
-                const float v = hf ? 0.f : e[s - 32];
+                float v[TP];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[(s * 2 + t) * 64 + lane], v, acc0[t], 0, 0, 0);
+                for (int p = 0; p < TP; ++p) v[p] = hf ? 0.f : e[s - 32][p];
+                step0(s, v);
             }
         } else {
             // synth: img = b*N + n.  k<130: sum/wz ; 130: zmax ; 131: cnt/16 ; 132: wz_/cnt_ ;
             // 133..196: residual (gathered LR F01 of batch b) ; 197: t ; 198,199: zero pad
             const int b = img / a.N;
-            const float* A = a.acc + (long)img * 133 * Q + pc;
-            float wz = A[130 * Q];
-            const float cnt = A[132 * Q];
-            if (wz == 0.f) wz = 1.0f;                       // Ours.py:813
-            const float cnt_ = (cnt == 0.f) ? 1.0f : cnt;   // Ours.py:828
-            const float wz_ = (wz == 1.0f) ? 0.f : wz;      // Ours.py:830
-            const float* R = a.src_lr + (long)b * 64 * HWl + lr;
             const float tval = a.times[img];
+            const float* A[TP];
+            const float* R[TP];
+            float wz[TP], cnt[TP], cnt_[TP], wz_[TP];
+#pragma unroll
+            for (int p = 0; p < TP; ++p) {
+                A[p] = a.acc + (long)img * 133 * Q + pc[p];
+                R[p] = a.src_lr + (long)b * 64 * HWl + lr[p];
+                wz[p] = A[p][130 * Q];
+                cnt[p] = A[p][132 * Q];
+                if (wz[p] == 0.f) wz[p] = 1.0f;                           // Ours.py:813
+                cnt_[p] = (cnt[p] == 0.f) ? 1.0f : cnt[p];                // Ours.py:828
+                wz_[p] = (wz[p] == 1.0f) ? 0.f : wz[p];                   // Ours.py:830
+            }
             // q = 0..15: k = 8q + 4hf + r < 128, all accumulator planes
             {
-                const float* ap = A + (long)(4 * hf) * Q;
+                const float* ap[TP];
+#pragma unroll
+                for (int p = 0; p < TP; ++p) ap[p] = A[p] + (long)(4 * hf) * Q;
+                float v[4][TP];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int p = 0; p < TP; ++p) v[r][p] = ap[p][(long)r * Q];
 #pragma unroll 1
                 for (int q = 0; q < 16; ++q) {
-                    float v[4];
+                    float vn[4][TP];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = ap[(long)r * Q] / wz;
-                    ap += 8 * Q;
-                    const float* wq = w0 + q * 4 * 2 * 64 + lane;
+                    for (int p = 0; p < TP; ++p) ap[p] += 8 * Q;
+                    if (q < 15) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int p = 0; p < TP; ++p) vn[r][p] = ap[p][(long)r * Q];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float d[TP];
+#pragma unroll
+                        for (int p = 0; p < TP; ++p) d[p] = v[r][p] / wz[p];
+                        step0(q * 4 + r, d);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int t = 0; t < 2; ++t)
-                            acc0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[(r * 2 + t) * 64], v[r], acc0[t], 0, 0, 0);
+                        for (int p = 0; p < TP; ++p) v[r][p] = vn[r][p];
                 }
             }
             // q = 16 (k = 128..135) and q = 24 (k = 192..199) straddle input classes
-            auto general = [&](int k) -> float {
-                if (k < 130) return A[(long)k * Q] / wz;
-                if (k == 130) return A[131 * Q];
-                if (k == 131) return cnt / 16.0f;
-                if (k == 132) return wz_ / cnt_;
-                if (k <= 196) return R[(long)(k - 133) * HWl];
+            auto general = [&](int k, int p) -> float {
+                if (k < 130) return A[p][(long)k * Q] / wz[p];
+                if (k == 130) return A[p][131 * Q];
+                if (k == 131) return cnt[p] / 16.0f;
+                if (k == 132) return wz_[p] / cnt_[p];
+                if (k <= 196) return R[p][(long)(k - 133) * HWl];
                 if (k == 197) return tval;
                 return 0.f;
             };
 #pragma unroll
             for (int s = 64; s < 68; ++s) {
-                const float v = general(kmap(s, hf));
+                float v[TP];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[(s * 2 + t) * 64 + lane], v, acc0[t], 0, 0, 0);
+                for (int p = 0; p < TP; ++p) v[p] = general(kmap(s, hf), p);
+                step0(s, v);
             }
             // q = 17..23: k = 136..191, all residual channels k-133
             {
-                const float* rp = R + (long)(136 - 133 + 4 * hf) * HWl;
+                const float* rp[TP];
+#pragma unroll
+                for (int p = 0; p < TP; ++p) rp[p] = R[p] + (long)(136 - 133 + 4 * hf) * HWl;
+                float v[4][TP];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int p = 0; p < TP; ++p) v[r][p] = rp[p][(long)r * HWl];
 #pragma unroll 1
                 for (int q = 17; q < 24; ++q) {
-                    float v[4];
+                    float vn[4][TP];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = rp[(long)r * HWl];
-                    rp += 8 * HWl;
-                    const float* wq = w0 + q * 4 * 2 * 64 + lane;
+                    for (int p = 0; p < TP; ++p) rp[p] += 8 * HWl;
+                    if (q < 23) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int p = 0; p < TP; ++p) vn[r][p] = rp[p][(long)r * HWl];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) step0(q * 4 + r, v[r]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int t = 0; t < 2; ++t)
-                            acc0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[(r * 2 + t) * 64], v[r], acc0[t], 0, 0, 0);
+                        for (int p = 0; p < TP; ++p) v[r][p] = vn[r][p];
                 }
             }
 #pragma unroll
             for (int s = 96; s < 100; ++s) {
-                const float v = general(kmap(s, hf));
+                float v[TP];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[(s * 2 + t) * 64 + lane], v, acc0[t], 0, 0, 0);
+                for (int p = 0; p < TP; ++p) v[p] = general(kmap(s, hf), p);
+                step0(s, v);
             }
         }
-        float h1[32];
-        sine<2>(acc0, h1);
+        float h1[TP][32];
+        sine(acc0, h1);
 
         // ------------------------------------------------ 64 -> 64 (x2 for synth)
-        f32x16 acc1[2];
-        init_bias<2>(acc1, lds + L::B1, hf);
+        f32x16 acc1[TP][2];
+        init_bias(acc1, lds + L::B1, hf);
         mfma_layer<32, 2, 2>(h1, acc1, lds + L::W1, 0, lane);
-        float h2[32];
-        sine<2>(acc1, h2);
+        float h2[TP][32];
+        sine(acc1, h2);
         if constexpr (MODE == MODE_SYNTH) {
-            init_bias<2>(acc1, lds + L::B1b, hf);
+            init_bias(acc1, lds + L::B1b, hf);
             mfma_layer<32, 2, 2>(h2, acc1, lds + L::W1b, 0, lane);
-            sine<2>(acc1, h2);
+            sine(acc1, h2);
         }
 
         // ------------------------------------------------ 64 -> 256 in four 64-wide chunks, each fed to the head
         if constexpr (Net<MODE>::HEAD == 3) {
-            float sum[3] = {0.f, 0.f, 0.f};
+            float sum[TP][3];
+#pragma unroll
+            for (int p = 0; p < TP; ++p) sum[p][0] = sum[p][1] = sum[p][2] = 0.f;
 #pragma unroll 1
             for (int c = 0; c < 4; ++c) {
-                f32x16 acc2[2];
-                init_bias<2>(acc2, lds + L::B2 + c * 64, hf);
+                f32x16 acc2[TP][2];
+                init_bias(acc2, lds + L::B2 + c * 64, hf);
                 mfma_layer<32, 2, 8>(h2, acc2, lds + L::W2, 2 * c, lane);
-                float hc[32];
-                sine<2>(acc2, hc);
+                float hc[TP][32];
+                sine(acc2, hc);
                 valu_head_partial<3, 32>(hc, sum, lds + L::W3, 8 * c, hf);
             }
             const float* hb = lds + L::W3 + 3 * 32 * 8;
 #pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                sum[o] += __shfl_xor(sum[o], 32);
-                sum[o] += hb[o];
-            }
-            if (valid && hf == 0) {
-                if constexpr (MODE == MODE_FLOW) {
+            for (int p = 0; p < TP; ++p) {
 #pragma unroll
-                    for (int o = 0; o < 3; ++o) a.out[((long)img * 3 + o) * Q + p] = sum[o];
-                } else {
-                    const int b = img / a.N, n = img % a.N;
+                for (int o = 0; o < 3; ++o) {
+                    sum[p][o] += __shfl_xor(sum[p][o], 32);
+                    sum[p][o] += hb[o];
+                }
+                if (valid[p] && hf == 0) {
+                    if constexpr (MODE == MODE_FLOW) {
 #pragma unroll
-                    for (int o = 0; o < 3; ++o) {
-                        float v = sum[o];
-                        v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
-                        a.out[(((long)n * a.B + b) * 3 + o) * Q + p] = v;
+                        for (int o = 0; o < 3; ++o) a.out[((long)img * 3 + o) * Q + pp[p]] = sum[p][o];
+                    } else {
+                        const int b = img / a.N, n = img % a.N;
+#pragma unroll
+                        for (int o = 0; o < 3; ++o) {
+                            float v = sum[p][o];
+                            v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+                            a.out[(((long)n * a.B + b) * 3 + o) * Q + pp[p]] = v;
+                        }
                     }
                 }
             }
         } else {
-            f32x16 acc3[2];
+            f32x16 acc3[TP][2];
             const float* w3g = a.packed + L::W3;                       // streamed from L2
             const float* b3g = w3g + 128L * 2 * 64;
-            init_bias<2>(acc3, b3g, hf);
+            init_bias(acc3, b3g, hf);
 #pragma unroll 1
             for (int c = 0; c < 4; ++c) {
-                f32x16 acc2[2];
-                init_bias<2>(acc2, lds + L::B2 + c * 64, hf);
+                f32x16 acc2[TP][2];
+                init_bias(acc2, lds + L::B2 + c * 64, hf);
                 mfma_layer<32, 2, 8>(h2, acc2, lds + L::W2, 2 * c, lane);
-                float hc[32];
-                sine<2>(acc2, hc);
+                float hc[TP][32];
+                sine(acc2, hc);
                 mfma_layer<32, 2, 2>(hc, acc3, w3g + (long)c * 32 * 2 * 64, 0, lane);
             }
-            if (valid) {
+#pragma unroll
+            for (int p = 0; p < TP; ++p) {
+                if (!valid[p]) continue;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                        a.out[((long)img * 64 + m) * Q + p] = acc3[t][r];
+                        a.out[((long)img * 64 + m) * Q + pp[p]] = acc3[p][t][r];
                     }
             }
         }
@@ -401,21 +523,24 @@ extern "C" long motif_siren_pack(const float* const* w, const float* const* b, c
     return total;
 }
 
-template <int MODE>
-static int launch_siren(const SirenArgs& a, void* stream) {
+template <int MODE, int TP>
+static int launch_siren(const SirenArgs& a_in, void* stream) {
     using L = Layout<MODE>;
     const size_t lds = (size_t)L::LDS_FLOATS * 4;
     static_assert(L::LDS_FLOATS * 4 <= 160 * 1024, "packed network must fit the 160 KB LDS");
     static_assert(L::LDS_FLOATS % 4 == 0, "blob prefix must be float4 sized");
-    hipError_t e = hipFuncSetAttribute((const void*)siren_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SirenArgs a = a_in;
+    a.stagger = 2;
+    if (const char* e = getenv("MOTIF_SIREN_STAGGER")) a.stagger = atoi(e);
+    hipError_t e = hipFuncSetAttribute((const void*)siren_kernel<MODE, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const long Q = (long)a.HH * a.WW;
-    const long tiles = (long)a.NB * ((Q + 31) / 32);
+    const long tiles = (long)a.NB * ((Q + 32 * TP - 1) / (32 * TP));
     long blocks = (tiles + SIREN_WAVES - 1) / SIREN_WAVES;
     if (blocks > cus) blocks = cus;
-    siren_kernel<MODE><<<(int)blocks, SIREN_THREADS, lds, (hipStream_t)stream>>>(a);
+    siren_kernel<MODE, TP><<<(int)blocks, SIREN_THREADS, lds, (hipStream_t)stream>>>(a);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }
@@ -425,7 +550,7 @@ extern "C" int motif_siren_imnet_fwd(const float* packed, const float* feat_lr, 
                                      int B2, int H, int W, int HH, int WW, void* stream) {
     if (!packed || !feat_lr || !iy || !ix || !rel_y || !rel_x || !out || B2 < 1) return MOTIF_EINVAL;
     SirenArgs a{packed, feat_lr, nullptr, iy, ix, rel_y, rel_x, nullptr, out, B2, 1, B2, H, W, HH, WW};
-    return launch_siren<MODE_IMNET>(a, stream);
+    return launch_siren<MODE_IMNET, SIREN_TP_IMNET>(a, stream);
 }
 
 extern "C" int motif_siren_flow_fwd(const float* packed, const float* flowfeat_lr, const int32_t* iy, const int32_t* ix,
@@ -433,7 +558,7 @@ extern "C" int motif_siren_flow_fwd(const float* packed, const float* flowfeat_l
                                     int B2, int N, int H, int W, int HH, int WW, void* stream) {
     if (!packed || !flowfeat_lr || !iy || !ix || !rel_y || !rel_x || !times || !pred || B2 < 2 || (B2 & 1) || N < 1) return MOTIF_EINVAL;
     SirenArgs a{packed, flowfeat_lr, nullptr, iy, ix, rel_y, rel_x, times, pred, B2 * N, N, B2 / 2, H, W, HH, WW};
-    return launch_siren<MODE_FLOW>(a, stream);
+    return launch_siren<MODE_FLOW, SIREN_TP_FLOW>(a, stream);
 }
 
 extern "C" int motif_siren_synth_fwd(const float* packed, const float* acc, const float* residual_lr,
@@ -441,7 +566,7 @@ extern "C" int motif_siren_synth_fwd(const float* packed, const float* acc, cons
                                      int B, int N, int H, int W, int HH, int WW, void* stream) {
     if (!packed || !acc || !residual_lr || !iy || !ix || !times || !frames || B < 1 || N < 1) return MOTIF_EINVAL;
     SirenArgs a{packed, residual_lr, acc, iy, ix, nullptr, nullptr, times, frames, B * N, N, B, H, W, HH, WW};
-    return launch_siren<MODE_SYNTH>(a, stream);
+    return launch_siren<MODE_SYNTH, SIREN_TP_SYNTH>(a, stream);
 }
 
 // parity aid: the 198-channel synth input, materialised (never used on the product path)
