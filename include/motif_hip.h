@@ -147,6 +147,12 @@ int motif_raft_corr_lookup(const float* fmap1, const float* fmap2, const float* 
                            float* out, int B, int H1, int W1, int H2, int W2, int C, int r,
                            int out_C, int ch_off, float div, void* stream);
 
+/* all (<= 4) pyramid levels of AlternateCorrBlock.__call__ (corr.py:70-87) in one launch: level i samples
+ * fmap2[i] [B,H2[i],W2[i],C] at coords/2^i and writes channels [49*i, 49*i+49) of out [B,out_C,H1,W1]. */
+int motif_raft_corr_lookup_pyramid(const float* fmap1, const float* const* fmap2, const int* H2, const int* W2, int levels,
+                                   const float* coords, float* out, int B, int H1, int W1, int C, int r,
+                                   int out_C, float div, void* stream);
+
 /* C4  PWC-Net 9x9 cost volume.  Replaces kernel_Correlation_rearrange + kernel_Correlation_updateOutput
  * (OpticalFlow/correlation.py:17-112,294-348): out[b,(dy+4)*9+(dx+4),y,x] = mean_c f1*f2(y+dy,x+dx). */
 int motif_corr81_fwd(const float* first, const float* second, float* out, int B, int C, int H, int W,
@@ -173,6 +179,8 @@ int motif_reliability_fwd(const float* fr0, const float* fr1, long fr_bs, const 
 /* InstanceNorm2d (eps 1e-5, no affine) + optional relu, optional residual: out = relu?(res + relu?(norm(x)))
  * mode 0: norm; 1: relu(norm); 2: relu(res + relu(norm))   (models/core/extractor.py:60-116,246-248) */
 int motif_instance_norm(const float* x, const float* res, float* out, int NC, int HW, int mode, void* stream);
+/* same, with a caller-owned fp64 workspace of NC*(2+64) doubles: large planes are split over many workgroups */
+int motif_instance_norm_ws(const float* x, const float* res, float* out, double* workspace, int NC, int HW, int mode, void* stream);
 int motif_avg_pool2(const float* in, float* out, int NC, int H, int W, void* stream);   /* F.avg_pool2d(x,2,2) */
 int motif_nchw_to_nhwc(const float* in, float* out, int N, int C, int HW, void* stream);
 /* ConvGRU update (update.py:24-31): h' = (1-z)*h + z*q */

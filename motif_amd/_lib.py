@@ -39,12 +39,14 @@ _SIGS = {
                                + [c_int] * 11 + [c_long, c_long, c_int, P]),
     "motif_dcn_v2_fwd": (c_int, [P, P, P, P, P, P, P] + [c_int] * 11 + [c_long, c_long, c_int, P]),
     "motif_raft_corr_lookup": (c_int, [P, P, P, c_float, P] + [c_int] * 7 + [c_int, c_int, c_float, P]),
+    "motif_raft_corr_lookup_pyramid": (c_int, [P, POINTER(c_void_p), POINTER(c_int), POINTER(c_int), c_int, P, P] + [c_int] * 6 + [c_float, P]),
     "motif_corr81_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_resize_bilinear": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     "motif_backwarp": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "motif_pwc_backward_warp": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "motif_reliability_fwd": (c_int, [P, P, c_long, P, P, P, P, c_int, c_int, c_int, P]),
     "motif_instance_norm": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "motif_instance_norm_ws": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "motif_avg_pool2": (c_int, [P, P, c_int, c_int, c_int, P]),
     "motif_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, P]),
     "motif_gru_update": (c_int, [P, P, P, P, c_long, P]),

@@ -7,13 +7,21 @@
 // loads, f1 broadcast).  The (2r+1)^2 = 49 window values are the bilinear blends of neighbouring lanes
 // (three ds_bpermute shuffles), staged per block in LDS as [49][64 queries] and written with coalesced
 // 256-byte rows into the [B,196,H,W] correlation tensor the update block consumes.
-__global__ __launch_bounds__(256) void raft_lookup_kernel(const float* __restrict__ fmap1, const float* __restrict__ fmap2,
-                                                         const float* __restrict__ coords, float coord_scale,
-                                                         float* __restrict__ out, int H1, int W1, int H2, int W2, int C,
-                                                         int out_C, int ch_off, float div) {
+struct LookupArgs {
+    const float* fmap1; const float* fmap2[4]; const float* coords;
+    float coord_scale[4]; float* out;
+    int H1, W1, H2[4], W2[4], C, out_C, ch_off[4];
+    float div;
+};
+
+// grid: x = 64-query tiles, y = batch, z = pyramid level (all levels of AlternateCorrBlock in one launch)
+__global__ __launch_bounds__(256) void raft_lookup_kernel(LookupArgs a) {
     __shared__ float tile[49][65];
-    const int b = blockIdx.y;
-    const long HW1 = (long)H1 * W1;
+    const int b = blockIdx.y, lv = blockIdx.z;
+    const float* __restrict__ fmap2 = a.fmap2[lv];
+    const int H2 = a.H2[lv], W2 = a.W2[lv], C = a.C;
+    const float cs = a.coord_scale[lv];
+    const long HW1 = (long)a.H1 * a.W1;
     const long q0 = (long)blockIdx.x * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gy = lane >> 3, gx = lane & 7;
@@ -21,19 +29,20 @@ __global__ __launch_bounds__(256) void raft_lookup_kernel(const float* __restric
         const int ql = wave * 16 + i;
         const long q = q0 + ql;
         if (q >= HW1) break;                                    // wave-uniform
-        const float x = coords[((long)b * 2) * HW1 + q] * coord_scale;
-        const float y = coords[((long)b * 2 + 1) * HW1 + q] * coord_scale;
+        const float x = a.coords[((long)b * 2) * HW1 + q] * cs;
+        const float y = a.coords[((long)b * 2 + 1) * HW1 + q] * cs;
         const float fx = floorf(x), fy = floorf(y);
         const float dx = x - fx, dy = y - fy;
         const int h2 = (int)fy - 3 + gy, w2 = (int)fx - 3 + gx;
         float s = 0.f;
         if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
-            const f32x4* f1 = (const f32x4*)(fmap1 + ((long)b * HW1 + q) * C);
+            const f32x4* f1 = (const f32x4*)(a.fmap1 + ((long)b * HW1 + q) * C);
             const f32x4* f2 = (const f32x4*)(fmap2 + (((long)b * H2 + h2) * W2 + w2) * C);
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
             for (int c = 0; c < C / 4; ++c) {
-                const f32x4 a = f1[c], v = f2[c];
-                s0 = fmaf(a[0], v[0], s0); s1 = fmaf(a[1], v[1], s1); s2 = fmaf(a[2], v[2], s2); s3 = fmaf(a[3], v[3], s3);
+                const f32x4 u = f1[c], v = f2[c];
+                s0 = fmaf(u[0], v[0], s0); s1 = fmaf(u[1], v[1], s1); s2 = fmaf(u[2], v[2], s2); s3 = fmaf(u[3], v[3], s3);
             }
             s = (s0 + s1) + (s2 + s3);
         }
@@ -43,15 +52,35 @@ __global__ __launch_bounds__(256) void raft_lookup_kernel(const float* __restric
             v += s_e * (1.f - dy) * dx;
             v += s_s * dy * (1.f - dx);
             v += s_se * dy * dx;
-            tile[gx * 7 + gy][ql] = v / div;                    // channel = ix*(2r+1) + iy
+            tile[gx * 7 + gy][ql] = v / a.div;                  // channel = ix*(2r+1) + iy
         }
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < 49 * 64; idx += 256) {
         const int ch = idx >> 6, ql = idx & 63;
         const long q = q0 + ql;
-        if (q < HW1) out[((long)b * out_C + ch_off + ch) * HW1 + q] = tile[ch][ql];
+        if (q < HW1) a.out[((long)b * a.out_C + a.ch_off[lv] + ch) * HW1 + q] = tile[ch][ql];
     }
+}
+
+extern "C" int motif_raft_corr_lookup_pyramid(const float* fmap1, const float* const* fmap2, const int* H2, const int* W2, int levels,
+                                              const float* coords, float* out, int B, int H1, int W1, int C, int r,
+                                              int out_C, float div, void* stream) {
+    if (!fmap1 || !fmap2 || !coords || !out || !H2 || !W2 || B < 1 || levels < 1 || levels > 4) return MOTIF_EINVAL;
+    if (r != 3 || (C & 3)) return MOTIF_ELIMIT;
+    LookupArgs a;
+    a.fmap1 = fmap1; a.coords = coords; a.out = out; a.H1 = H1; a.W1 = W1; a.C = C; a.out_C = out_C; a.div = div;
+    for (int i = 0; i < 4; ++i) {
+        const int j = i < levels ? i : 0;
+        if (!fmap2[j]) return MOTIF_EINVAL;
+        a.fmap2[i] = fmap2[j]; a.H2[i] = H2[j]; a.W2[i] = W2[j];
+        a.coord_scale[i] = 1.0f / (float)(1 << j);              // coords / 2**i (corr.py:81)
+        a.ch_off[i] = j * (2 * r + 1) * (2 * r + 1);
+    }
+    dim3 grid(cdiv((long)H1 * W1, 64), B, levels);
+    raft_lookup_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
 }
 
 extern "C" int motif_raft_corr_lookup(const float* fmap1, const float* fmap2, const float* coords, float coord_scale,
@@ -59,8 +88,11 @@ extern "C" int motif_raft_corr_lookup(const float* fmap1, const float* fmap2, co
                                       int out_C, int ch_off, float div, void* stream) {
     if (!fmap1 || !fmap2 || !coords || !out || B < 1) return MOTIF_EINVAL;
     if (r != 3 || (C & 3)) return MOTIF_ELIMIT;
-    dim3 grid(cdiv((long)H1 * W1, 64), B);
-    raft_lookup_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(fmap1, fmap2, coords, coord_scale, out, H1, W1, H2, W2, C, out_C, ch_off, div);
+    LookupArgs a;
+    a.fmap1 = fmap1; a.coords = coords; a.out = out; a.H1 = H1; a.W1 = W1; a.C = C; a.out_C = out_C; a.div = div;
+    for (int i = 0; i < 4; ++i) { a.fmap2[i] = fmap2; a.H2[i] = H2; a.W2[i] = W2; a.coord_scale[i] = coord_scale; a.ch_off[i] = ch_off; }
+    dim3 grid(cdiv((long)H1 * W1, 64), B, 1);
+    raft_lookup_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

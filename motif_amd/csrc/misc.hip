@@ -203,9 +203,70 @@ __global__ __launch_bounds__(1024) void instance_norm_kernel(const float* __rest
     }
 }
 
+// Large planes, few of them (RAFT's 1/2-resolution layers: 8 planes of 230k pixels per image): three
+// grid-wide passes with the plane split over `S` blocks; partial sums in fp64 through a tiny workspace so
+// the two-pass mean/variance stays as accurate as the single-block kernel.
+__global__ __launch_bounds__(256) void in_partial_kernel(const float* __restrict__ x, const double* __restrict__ stats,
+                                                        double* __restrict__ part, int HW, int S, int pass) {
+    __shared__ float sh[16];
+    const int plane = blockIdx.y, sb = blockIdx.x;
+    const long base = (long)plane * HW;
+    const int per = (HW + S - 1) / S, i0 = sb * per, i1 = min(HW, i0 + per);
+    float mean = 0.f;
+    if (pass == 1) mean = (float)(stats[plane * 2] / (double)HW);
+    float s = 0.f;
+    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const float d = x[base + i] - mean;
+        s += pass == 0 ? d : d * d;
+    }
+    const float t = block_sum(s, sh);
+    if (threadIdx.x == 0) part[(long)plane * S + sb] = (double)t;
+}
+
+__global__ void in_reduce_kernel(const double* __restrict__ part, double* __restrict__ stats, int NC, int S, int pass) {
+    const int plane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (plane >= NC) return;
+    double t = 0.0;
+    for (int i = 0; i < S; ++i) t += part[(long)plane * S + i];
+    stats[plane * 2 + pass] = t;
+}
+
+__global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                      const double* __restrict__ stats, float* __restrict__ out, int HW, int mode) {
+    const int plane = blockIdx.y;
+    const long base = (long)plane * HW;
+    const float mean = (float)(stats[plane * 2] / (double)HW);
+    const float var = (float)(stats[plane * 2 + 1] / (double)HW);
+    const float inv = 1.0f / sqrtf(var + 1e-5f);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+        float v = (x[base + i] - mean) * inv;
+        if (mode >= 1) v = v > 0.f ? v : 0.f;
+        if (mode == 2) { v += res[base + i]; v = v > 0.f ? v : 0.f; }
+        out[base + i] = v;
+    }
+}
+
 extern "C" int motif_instance_norm(const float* x, const float* res, float* out, int NC, int HW, int mode, void* stream) {
     if (!x || !out || NC < 1 || HW < 1 || (mode == 2 && !res)) return MOTIF_EINVAL;
     instance_norm_kernel<<<NC, 1024, 0, (hipStream_t)stream>>>(x, res, out, HW, mode);
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}
+
+extern "C" int motif_instance_norm_ws(const float* x, const float* res, float* out, double* workspace, int NC, int HW, int mode, void* stream) {
+    if (!x || !out || NC < 1 || HW < 1 || (mode == 2 && !res)) return MOTIF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int S = 1024 / NC;                       // aim at ~1024 blocks
+    if (S > HW / 4096) S = HW / 4096;
+    if (!workspace || S < 2) return motif_instance_norm(x, res, out, NC, HW, mode, stream);
+    if (S > 64) S = 64;
+    double* stats = workspace;               // [NC][2]
+    double* part = workspace + 2L * NC;      // [NC][S]
+    for (int pass = 0; pass < 2; ++pass) {
+        in_partial_kernel<<<dim3(S, NC), 256, 0, s>>>(x, stats, part, HW, S, pass);
+        in_reduce_kernel<<<cdiv(NC, 64), 64, 0, s>>>(part, stats, NC, S, pass);
+    }
+    in_apply_kernel<<<dim3(S, NC), 256, 0, s>>>(x, res, stats, out, HW, mode);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

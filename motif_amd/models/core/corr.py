@@ -37,6 +37,4 @@ class AlternateCorrBlock:
         n = (2 * self.radius + 1) ** 2
         out = torch.empty(b, self.num_levels * n, h, w, dtype=torch.float32, device=coords.device)
         div = float(torch.sqrt(torch.tensor(self.dim).float()))
-        for i in range(self.num_levels):
-            ops.raft_corr_lookup(self.f1, self.f2[i], coords, 1.0 / 2 ** i, out, i * n, div, self.radius)
-        return out
+        return ops.raft_corr_lookup_pyramid(self.f1, self.f2, coords, out, div, self.radius)

@@ -378,7 +378,9 @@ def instance_norm(x, mode=0, res=None):
     x = _c(x)
     n, c, h, w = x.shape
     out = torch.empty_like(x)
-    check(lib.motif_instance_norm(_p(x), _p(_c(res)) if res is not None else None, _p(out), n * c, h * w, mode, _stream()), "motif_instance_norm")
+    ws = workspace((n * c * 66) * 2, x.device, "instnorm")          # fp64 scratch, viewed as raw bytes by the library
+    check(lib.motif_instance_norm_ws(_p(x), _p(_c(res)) if res is not None else None, _p(out), ctypes.c_void_p(ws.data_ptr()),
+                                     n * c, h * w, mode, _stream()), "motif_instance_norm_ws")
     return out
 
 
@@ -406,6 +408,17 @@ def raft_corr_lookup(fmap1_nhwc, fmap2_nhwc, coords, coord_scale, out, ch_off, d
     _, h2, w2, _ = fmap2_nhwc.shape
     check(lib.motif_raft_corr_lookup(_p(fmap1_nhwc), _p(fmap2_nhwc), _p(_c(coords)), float(coord_scale), _p(out),
                                      b, h1, w1, h2, w2, c, r, out.shape[1], ch_off, float(div), _stream()), "motif_raft_corr_lookup")
+    return out
+
+
+def raft_corr_lookup_pyramid(fmap1_nhwc, fmap2_levels, coords, out, div, r=3):
+    lib = _lib.load()
+    b, h1, w1, c = fmap1_nhwc.shape
+    n = len(fmap2_levels)
+    hs = (ctypes.c_int * n)(*[f.shape[1] for f in fmap2_levels])
+    ws = (ctypes.c_int * n)(*[f.shape[2] for f in fmap2_levels])
+    check(lib.motif_raft_corr_lookup_pyramid(_p(fmap1_nhwc), _ptr_array(fmap2_levels), hs, ws, n, _p(_c(coords)), _p(out),
+                                             b, h1, w1, c, r, out.shape[1], float(div), _stream()), "motif_raft_corr_lookup_pyramid")
     return out
 
 
