@@ -339,6 +339,8 @@ class LunaTokis(nn.Module):
         self.alpha = nn.Parameter(torch.ones(1) * -20.0)
         self.shuffle = Conv2d(channel, channel, 1, 1, 0)
         self.skip_zero_pairs = True
+        self.overlap_raft = True
+        self._side_stream = None
         self._cache_key, self._cache = None, None
 
     # ----------------------------------------------------------------------------- t-independent stage
@@ -357,24 +359,35 @@ class LunaTokis(nn.Module):
         pair = torch.stack([fr0, fr1], dim=1)                                   # [B,2,3,H,W]
         hr = ops.resize_bilinear(pair.reshape(B * 2, 3, H, W), (HH, WW), False).view(B, 2, 3, HH, WW)
         a, b = hr[:, 0], hr[:, 1]
-        if self.skip_zero_pairs:
-            i1 = torch.cat([a, b], 0) * 255.0                                   # pairs 01, 10
-            i2 = torch.cat([b, a], 0) * 255.0
-            f = self.flow_predictor(i1, i2, iters=iters, last_only=True)[-1]
-            f = ops.resize_bilinear(f, (H, W), False, H / HH)
-            flow = torch.zeros(4 * B, 2, H, W, dtype=torch.float32, device=x.device)
-            flow[B:3 * B].copy_(f)
-        else:
-            i1 = torch.cat([a, a, b, b], 0) * 255.0
-            i2 = torch.cat([a, b, a, b], 0) * 255.0
-            f = self.flow_predictor(i1, i2, iters=iters, last_only=True)[-1]
-            flow = ops.resize_bilinear(f, (H, W), False, H / HH)
-            flow[:B] *= 0.0
-            flow[3 * B:] *= 0.0
-        psies, flow_feat_in = ops.reliability(fr0, fr1, flow, self.g_filter, B, H, W)
+        # RAFT + reliability maps are independent of the encoder until `flow_process`: run them on a side
+        # stream so their many small, latency-bound launches hide under the encoder's MFMA-bound convolutions
+        main = torch.cuda.current_stream()
+        side = self._side_stream if self.overlap_raft else main
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            if self.skip_zero_pairs:
+                i1 = torch.cat([a, b], 0) * 255.0                               # pairs 01, 10
+                i2 = torch.cat([b, a], 0) * 255.0
+                f = self.flow_predictor(i1, i2, iters=iters, last_only=True)[-1]
+                f = ops.resize_bilinear(f, (H, W), False, H / HH)
+                flow = torch.zeros(4 * B, 2, H, W, dtype=torch.float32, device=x.device)
+                flow[B:3 * B].copy_(f)
+            else:
+                i1 = torch.cat([a, a, b, b], 0) * 255.0
+                i2 = torch.cat([a, b, a, b], 0) * 255.0
+                f = self.flow_predictor(i1, i2, iters=iters, last_only=True)[-1]
+                flow = ops.resize_bilinear(f, (H, W), False, H / HH)
+                flow[:B] *= 0.0
+                flow[3 * B:] *= 0.0
+            psies, flow_feat_in = ops.reliability(fr0, fr1, flow, self.g_filter, B, H, W)
+            for t in (flow, psies, flow_feat_in):
+                t.record_stream(main)
         feat = self.encoder(pair, None)                                        # [B,3,64,H,W]
         residual = feat[:, 1].contiguous()
         feat01 = torch.cat((feat[:, 0], feat[:, 2]), 0)                         # [2B,64,H,W]
+        main.wait_stream(side)
         flow_feat = self._flow_encoder(flow_feat_in)                            # [2B,64,H,W]
         iy, ix, rel_y, rel_x = gather_tables(H, W, HH, WW, x.device)
         imnet_out = ops.siren_imnet(self.imnet.packed(), feat01, iy, ix, rel_y, rel_x, HH, WW)
