@@ -183,8 +183,12 @@ def main():
         if not a.no_roofline:
             r = instrumented_clip(model, clips[0])
             ach = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+            if os.path.exists(tj):          # PMC run of the same kernel (separate --pmc passes), see the file's note
+                traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
             line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                                "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                                 "kernel": "conv_igemm_kernel<2>", "launches_per_clip": r["launches"],
                                 "avg_launch_us": 1000.0 * r["ms"] / max(r["launches"], 1),
                                 "avg_launch_gflop": r["flops"] / max(r["launches"], 1) / 1e9,
