@@ -162,3 +162,31 @@ def test_pwcnet_matches_reference_golden():
     with torch.no_grad():
         flow = net(torch.from_numpy(g["first"]).cuda(), torch.from_numpy(g["second"]).cuda())
     golden_cmp(g, "flow", flow, 2e-4, 1e-3)
+
+
+def test_non_integer_scale_and_cache_invalidation():
+    """scale 2.5 exercises the literal nearest-gather tables (no i//s shortcut); the HIP path must agree with
+    the CPU oracle (the restatement pinned bit-exact to the reference), and the t-independent cache must be
+    dropped when the clip tensor is modified in place or replaced."""
+    from oracle.motif_ref import MotifRef
+    from motif_amd.data.synthetic import synthetic_sample
+    from motif_amd.utils.synth_weights import fill_state_dict
+    net = build_net()
+    s = synthetic_sample(64, 64, 2.5, 2, seed=7)
+    assert s["scale"] == [[160], [160]]
+    x = s["LQs"].cuda()
+    times = [t.cuda() for t in s["time"]]
+    with torch.no_grad():
+        out, flow, _ = net(x, None, times, s["scale"], use_GT=False, iter=4)
+        ref, rflow, _ = fill_state_dict(MotifRef().eval())(s["LQs"], None, s["time"], s["scale"], use_GT=False, iter=4)
+    assert out.shape == ref.shape == (2, 1, 3, 160, 160)
+    assert psnr(out.cpu(), ref) >= 60.0
+    assert float((flow.cpu() - rflow).abs().max()) < 2e-3
+    # same tensor object, new content: version counter changes -> recompute
+    with torch.no_grad():
+        key0 = net._cache_key
+        x.mul_(0.5)
+        out2, _, _ = net(x, None, times, s["scale"], use_GT=False, iter=4)
+        assert net._cache_key != key0
+        ref2, _, _ = fill_state_dict(MotifRef().eval())(s["LQs"] * 0.5, None, s["time"], s["scale"], use_GT=False, iter=4)
+    assert psnr(out2.cpu(), ref2) >= 60.0
