@@ -73,6 +73,9 @@ def instrumented_clip(model, sample):
 
     ops.conv2d = timed_conv
     ops.conv2d_multi = timed_multi
+    net = model.netG
+    overlap = getattr(net, "overlap_raft", False)
+    net.overlap_raft = False          # per-kernel durations: no concurrent side stream while instrumenting
     try:
         model.feed_data(sample)
         model.test()
@@ -80,6 +83,7 @@ def instrumented_clip(model, sample):
     finally:
         ops.conv2d = orig
         ops.conv2d_multi = orig_multi
+        net.overlap_raft = overlap
     big = [(e0.elapsed_time(e1), l) for (e0, e1, is_nc2), l in zip(events, log) if is_nc2]
     ms = sum(t for t, _ in big)
     fl = conv_flops([l for _, l in big])

@@ -45,7 +45,8 @@ __device__ __forceinline__ float act_c(float v) {
     else return v;
 }
 
-template <int NC, int RPW>
+// SPEC 1: 3x3, stride 1, dilation 1 (patch pitch 34): tap offsets are immediates, the MFMA loop has no VALU.
+template <int NC, int RPW, int SPEC>
 __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = 64 * (8 / RPW);       // threads: one wave per RPW output rows of the 8-row tile
@@ -93,10 +94,11 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
             ech[j] = c;
         }
     }
-    for (int kk = tid; kk < KC; kk += NT) {
-        const int c = kk / T, t = kk - c * T;
+    // K order inside a chunk: (channel pair, tap, half) -- an MFMA step takes tap t of channel 2cp from the lower
+    // half-wave and of channel 2cp+1 from the upper one, so the patch offset of a step is half*PHW + tapoff[t].
+    for (int t = tid; t < T; t += NT) {
         const int ky = t / a.KW, kx = t - ky * a.KW;
-        koff[kk] = c * PHW + ky * a.dil * a.PW + kx * a.dil;
+        koff[t] = ky * a.dil * a.PW + kx * a.dil;
     }
     if (tid < WN) {
         const int col = cg * WN + tid;
@@ -168,39 +170,64 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
         if (more && !(a.dbg & 1)) rows_next = issue(c0 + a.CK);          // loads fly while this chunk is multiplied
         else if (more) { rows_next = a.Kpad - (c0 + a.CK) * T; if (rows_next > KC) rows_next = KC; }
 
-        const float* patch = patch0 + cur * patch_elems;
-        const float* wl = wl0 + cur * KC * WN + l31;
-        const int steps = rows_cur >> 1;
-        int s = (a.dbg & 2) ? steps : 0;
-        for (; s + 4 <= steps; s += 4) {
-            int ko[4];
+        const float* patch = patch0 + cur * patch_elems + half * PHW;
+        const float* wl = wl0 + cur * KC * WN + half * WN + l31;
+        const int ncp = (a.dbg & 2) ? 0 : rows_cur / (2 * T);          // channel pairs in this chunk
+        if constexpr (SPEC == 1) {
+            for (int cp = 0; cp < ncp; ++cp) {
+                const float* bc = patch + cp * 2 * PHW;
+                const float* wc = wl + cp * 18 * WN;
+                float bv[9][RPW], av[9][NC];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) ko[u] = koff[2 * (s + u) + half];
-            float bv[4][RPW], av[4][NC];
+                for (int t = 0; t < 9; ++t) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+                    for (int j = 0; j < RPW; ++j) bv[t][j] = bc[(t / 3) * 34 + (t % 3) + pix[j]];
 #pragma unroll
-                for (int j = 0; j < RPW; ++j) bv[u][j] = patch[ko[u] + pix[j]];
+                    for (int i = 0; i < NC; ++i) av[t][i] = wc[t * 2 * WN + i * 32];
+                }
 #pragma unroll
-                for (int i = 0; i < NC; ++i) av[u][i] = wl[(2 * (s + u) + half) * WN + i * 32];
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int i = 0; i < NC; ++i)
+#pragma unroll
+                        for (int j = 0; j < RPW; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][i], bv[t][j], acc[i][j], 0, 0, 0);
             }
+        } else {
+            for (int cp = 0; cp < ncp; ++cp) {
+                const float* bc = patch + cp * 2 * PHW;
+                const float* wc = wl + cp * 2 * T * WN;
+                int t = 0;
+                for (; t + 4 <= T; t += 4) {
+                    int ko[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < 4; ++u) ko[u] = koff[t + u];
+                    float bv[4][RPW], av[4][NC];
 #pragma unroll
-                for (int i = 0; i < NC; ++i)
+                    for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                    for (int j = 0; j < RPW; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
-        }
-        for (; s < steps; ++s) {
-            const int k = 2 * s + half;
-            const int ko1 = koff[k];
+                        for (int j = 0; j < RPW; ++j) bv[u][j] = bc[ko[u] + pix[j]];
 #pragma unroll
-            for (int i = 0; i < NC; ++i) {
-                const float av1 = wl[k * WN + i * 32];
+                        for (int i = 0; i < NC; ++i) av[u][i] = wc[(t + u) * 2 * WN + i * 32];
+                    }
 #pragma unroll
-                for (int j = 0; j < RPW; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, patch[ko1 + pix[j]], acc[i][j], 0, 0, 0);
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int i = 0; i < NC; ++i)
+#pragma unroll
+                            for (int j = 0; j < RPW; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+                }
+                for (; t < T; ++t) {
+                    const int ko1 = koff[t];
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) {
+                        const float av1 = wc[t * 2 * WN + i * 32];
+#pragma unroll
+                        for (int j = 0; j < RPW; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bc[ko1 + pix[j]], acc[i][j], 0, 0, 0);
+                    }
+                }
             }
         }
         if (more && !(a.dbg & 1)) commit(cur ^ 1, rows_next);
@@ -277,18 +304,22 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
 }
 
 // weight [Cout, Cin_g, KH, KW] -> packed [groups][ncg][Kpad][32*NC], zero padded
-__global__ void conv_pack_kernel(const float* w, float* wp, int Cout_g, int K, int Kpad, int ncg, int WN, long total) {
+// weight [Cout, Cin_g, KH, KW] -> packed [groups][ncg][Kpad][32*NC] with row r = ((cp*T + t)*2 + half) holding
+// k = (channel 2cp+half, tap t); zero padded (odd channel counts get a zero partner channel)
+__global__ void conv_pack_kernel(const float* w, float* wp, int Cout_g, int Cin_g, int T, int Kpad, int ncg, int WN, long total) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     int j = (int)(i % WN);
-    long t = i / WN;
-    int k = (int)(t % Kpad);
-    t /= Kpad;
-    int cgi = (int)(t % ncg);
-    int g = (int)(t / ncg);
+    long tt = i / WN;
+    int r = (int)(tt % Kpad);
+    tt /= Kpad;
+    int cgi = (int)(tt % ncg);
+    int g = (int)(tt / ncg);
     int col = cgi * WN + j;
+    const int half = r & 1, q = r >> 1, t = q % T, cp = q / T;
+    const int c = 2 * cp + half;
     float v = 0.f;
-    if (col < Cout_g && k < K) v = w[((long)(g * Cout_g + col)) * K + k];
+    if (col < Cout_g && c < Cin_g) v = w[((long)(g * Cout_g + col)) * Cin_g * T + (long)c * T + t];
     wp[i] = v;
 }
 
@@ -303,7 +334,7 @@ bool plan_conv(const MotifConvDesc* d, ConvPlan* p) {
     p->Cout_g = d->Cout / d->groups;
     p->T = d->KH * d->KW;
     p->K = p->Cin_g * p->T;
-    p->Kpad = (p->K + 1) & ~1;
+    p->Kpad = 2 * p->T * ((p->Cin_g + 1) / 2);     // channel pairs x taps x 2
     p->NC = p->Cout_g > 32 ? 2 : 1;
     p->WN = 32 * p->NC;
     p->ncg = (p->Cout_g + p->WN - 1) / p->WN;
@@ -325,16 +356,16 @@ bool plan_conv(const MotifConvDesc* d, ConvPlan* p) {
     int ck = 0;
     for (int c = 1; c <= p->Cin_g + 1; ++c) {
         if (!ok(c)) break;
-        if (((c * p->T) & 1) == 0 && (!two || d->C0 % c == 0)) ck = c;
+        if ((c & 1) == 0 && (!two || d->C0 % c == 0)) ck = c;
     }
     if (ck == 0) {                       // relax the LDS soft cap, keep the hard register limits
         for (int c = 1; c <= 2; ++c)
-            if (((c * p->T) & 1) == 0 && (!two || d->C0 % c == 0) && (long)c * PHW <= PATCH_MAX && (long)c * p->T * p->WN <= WCHUNK_MAX) { ck = c; break; }
+            if ((c & 1) == 0 && (!two || d->C0 % c == 0) && (long)c * PHW <= PATCH_MAX && (long)c * p->T * p->WN <= WCHUNK_MAX) { ck = c; break; }
     }
     if (ck == 0) return false;
     if (const char* e = getenv("MOTIF_CONV_CK")) {            // tuning aid
         const int f = atoi(e);
-        if (f > 0 && f <= ck && ((f * p->T) & 1) == 0) ck = f;
+        if (f > 0 && f <= ck && (f & 1) == 0 && (!two || d->C0 % f == 0)) ck = f;
     }
     p->CK = ck;
     const size_t patch_elems = ((size_t)ck * PHW + 3) & ~(size_t)3;
@@ -353,7 +384,7 @@ extern "C" int motif_conv2d_pack(const MotifConvDesc* d, const float* weight, fl
     ConvPlan p;
     if (!plan_conv(d, &p) || !weight || !packed) return MOTIF_EINVAL;
     long total = (long)d->groups * p.ncg * p.Kpad * p.WN;
-    conv_pack_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(weight, packed, p.Cout_g, p.K, p.Kpad, p.ncg, p.WN, total);
+    conv_pack_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(weight, packed, p.Cout_g, p.Cin_g, p.T, p.Kpad, p.ncg, p.WN, total);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }
@@ -390,16 +421,15 @@ extern "C" int motif_conv2d_fwd_multi(const MotifConvDesc* d, int P, const float
     if (const char* e = getenv("MOTIF_CONV_DBG")) a.dbg = atoi(e);
     dim3 grid(a.tiles_x * tiles_y, d->groups * p.ncg, d->N * P);
     hipStream_t s = (hipStream_t)stream;
-    bool fine = true;   // measured: one output row per wave (8 waves per tile) wins at every grid size
-    if (const char* e = getenv("MOTIF_CONV_RPW")) fine = (atoi(e) == 1);   // tuning aid
-#define MOTIF_LAUNCH_CONV(NCV, RPWV)                                                                                         \
+    const bool spec = d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1 && !getenv("MOTIF_CONV_NOSPEC");
+#define MOTIF_LAUNCH_CONV(NCV, SPECV)                                                                                        \
     do {                                                                                                                     \
         if (p.lds > 64 * 1024)                                                                                               \
-            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NCV, RPWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
-        conv_igemm_kernel<NCV, RPWV><<<grid, 64 * (8 / RPWV), p.lds, s>>>(a);                                               \
+            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NCV, 1, SPECV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
+        conv_igemm_kernel<NCV, 1, SPECV><<<grid, 512, p.lds, s>>>(a);                                                      \
     } while (0)
-    if (p.NC == 2) { if (fine) MOTIF_LAUNCH_CONV(2, 1); else MOTIF_LAUNCH_CONV(2, 2); }
-    else { if (fine) MOTIF_LAUNCH_CONV(1, 1); else MOTIF_LAUNCH_CONV(1, 2); }
+    if (p.NC == 2) { if (spec) MOTIF_LAUNCH_CONV(2, 1); else MOTIF_LAUNCH_CONV(2, 0); }
+    else { if (spec) MOTIF_LAUNCH_CONV(1, 1); else MOTIF_LAUNCH_CONV(1, 0); }
 #undef MOTIF_LAUNCH_CONV
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;

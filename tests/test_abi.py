@@ -49,7 +49,7 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     d.stride, d.pad, d.dil, d.groups = 1, 1, 1, 4            # 6 channels not divisible by 4 groups
     assert lib.motif_conv2d_packed_size(ctypes.byref(d)) < 0
     d.groups = 2
-    assert lib.motif_conv2d_packed_size(ctypes.byref(d)) == 2 * 1 * 28 * 32   # groups*ncg*Kpad*WN, K=3*9=27 -> 28
+    assert lib.motif_conv2d_packed_size(ctypes.byref(d)) == 2 * 1 * 36 * 32   # groups*ncg*Kpad*WN, Kpad = 2*T*ceil(3/2) = 36
     assert lib.motif_splat_fwd(None, None, None, None, None, None, None, 1, 1, 1, 1, None) < 0
     assert lib.motif_siren_pack(None, None, (ctypes.c_int * 5)(67, 64, 64, 256, 3), 4, None, None) == 26244
 
