@@ -137,6 +137,14 @@ int motif_dcn_v2_fwd_multi(int P, const float* const* input, const long* input_b
                            int stride, int pad, int dil, int deformable_groups, long offset_bs, long mask_bs,
                            int act, void* stream);
 
+/* Fused form for the configuration MoTIF uses (3x3, stride 1, pad 1, dilation 1, Ours.py:65-94): the deformable
+ * im2col goes straight into LDS and is consumed by the MFMA loop -- no `columns` workspace.  `packed3x3` =
+ * motif_conv2d_pack of the [Cout,C,3,3] weight with a 3x3 descriptor.  Returns MOTIF_ELIMIT for other shapes. */
+int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, const long* input_bs, const float* const* offset,
+                                 const float* const* mask, const float* const* packed3x3, const float* const* bias,
+                                 float* const* out, int B, int C, int H, int W, int Cout, int deformable_groups,
+                                 long offset_bs, long mask_bs, int act, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * C2  RAFT windowed correlation lookup.  Replaces alt_cuda_corr.forward (third-party, not vendored;
  * call site models/core/corr.py:78-83).  fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C] channels-last,

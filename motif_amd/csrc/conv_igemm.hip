@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
     // epilogue: C/D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*half (cout within tile).
     // The activation / residual mode is block-uniform: dispatch once, keep the store loop branch-free.
     const int ox = tx * 32 + l31;
-    if (ox >= a.Wo) return;
+    if (ox >= a.Wo || (a.dbg & 4)) return;
     const long HWo = (long)a.Ho * a.Wo;
     const int cobase = g * a.Cout_g + cg * WN;
     const int climit = a.Cout_g - cg * WN;                 // valid couts in this group

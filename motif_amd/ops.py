@@ -5,6 +5,7 @@ hand-written HIP kernel in libmotif_hip.so.  All tensors must be CUDA (ROCm) fp3
 eager fallback -- a missing library or a non-GPU tensor raises.
 """
 import ctypes
+import os
 
 import torch
 
@@ -148,9 +149,20 @@ def dcn_v2_multi(dplans, xs, oms, dg=8, act=ACT_NONE, kh=3, kw=3, stride=1, pad=
     ho = (h + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
     wo = (w + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
     t = kh * kw
-    cols = workspace(P * b * c * t * ho * wo, xs[0].device, "dcn_cols")
     out = torch.empty(P, b, co, ho, wo, dtype=torch.float32, device=xs[0].device)
     outs = list(out)
+    fused = (kh == 3 and kw == 3 and stride == 1 and pad == 1 and dil == 1 and (c // dg) % 4 == 0
+             and act in (ACT_NONE, ACT_LRELU, ACT_RELU) and not os.environ.get("MOTIF_DCN_UNFUSED"))
+    if fused:
+        packs = [dp.plan3x3().packed() for dp in dplans]
+        biases = [dp.bias.detach() for dp in dplans]
+        masks = (ctypes.c_void_p * P)(*[o.data_ptr() + 4 * 2 * dg * t * ho * wo for o in oms])
+        bs = oms[0].stride(0)
+        check(lib.motif_dcn_v2_fused_fwd_multi(P, _ptr_array(xs), (ctypes.c_long * P)(*[x.stride(0) for x in xs]), _ptr_array(oms), masks,
+                                               _ptr_array(packs), _ptr_array(biases), _ptr_array(outs), b, c, h, w, co, dg, bs, bs, act,
+                                               _stream()), "motif_dcn_v2_fused_fwd_multi")
+        return out
+    cols = workspace(P * b * c * t * ho * wo, xs[0].device, "dcn_cols")
     plans = [dp.plan() for dp in dplans]
     packs = [pl.packed() for pl in plans]
     biases = [dp.bias.detach() for dp in dplans]
@@ -168,6 +180,12 @@ class DcnPlan:
     def __init__(self, weight, bias):
         self.weight, self.bias = weight, bias
         self._plan, self._key = None, None
+
+    def plan3x3(self):
+        """The weight as an ordinary 3x3 conv plan (K order (channel pair, tap, half)) for the fused DCN kernel."""
+        if getattr(self, "_p3", None) is None or self._p3.weight is not self.weight:
+            self._p3 = ConvPlan(self.weight, self.bias, 1, 1, 1, 1, 0)
+        return self._p3
 
     def plan(self):
         w = self.weight

@@ -422,3 +422,27 @@ def test_splat_motif_owner_computes_vs_kernel_text(far):
     assert torch.equal(acc[:, 132:133], scnt), "count plane must be exact"
     close(acc[:, 131:132], smax, 1e-6, 1e-6, "max plane")
     close(acc[:, :131], ssum, 3e-5, 1e-5, "sum planes")
+
+
+def test_dcn_fused_multi_vs_kernel_text():
+    """Fused DCN (deformable im2col in LDS + MFMA, multi-problem) == the kernel-text restatement, including
+    offsets that leave the image, the (-1, 0) border band, and odd image sizes."""
+    from oracle import native
+    from motif_amd import ops
+    B, C, H, W, dg, P = 2, 64, 21, 45, 8, 3
+    outs_ref, plans, xs, oms = [], [], [], []
+    for pi in range(P):
+        x = rnd(B, C, H, W, seed=10 * pi + 1)
+        w = rnd(64, C, 3, 3, seed=10 * pi + 2, scale=0.05)
+        bias = rnd(64, seed=10 * pi + 3, scale=0.1)
+        off = rnd(B, 2 * dg * 9, H, W, seed=10 * pi + 4, scale=4.0)
+        off[:, :, :3] *= 8.0                                   # far outside the image
+        off[:, ::2, 5, :] = -0.5 - torch.arange(W) * 0.0       # sample rows in the (-1, 0) band for row 5 taps
+        mlog = rnd(B, dg * 9, H, W, seed=10 * pi + 5, scale=2.0)
+        outs_ref.append(F.leaky_relu(native.dcn_v2_forward(x, w, bias, off, torch.sigmoid(mlog), 3, 3, 1, 1, 1, 1, 1, 1, dg), 0.1))
+        plans.append(ops.DcnPlan(w.to(dev()), bias.to(dev())))
+        xs.append(x.to(dev()))
+        oms.append(torch.cat([off, torch.sigmoid(mlog)], 1).to(dev()))
+    out = ops.dcn_v2_multi(plans, xs, oms, dg, ops.ACT_LRELU)
+    for pi in range(P):
+        close(out[pi], outs_ref[pi], 3e-5, 3e-5, "fused dcn problem %d" % pi)
