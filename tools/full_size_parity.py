@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Full-size (BASELINE config 2) parity of the HIP path against the CPU oracle: one clip, LR 180x320 -> 720x1280.
+Slow on the CPU side (minutes); run by hand, result recorded in DESIGN.md."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from motif_amd.data.synthetic import synthetic_sample
+from motif_amd.models.modules.Ours import LunaTokis
+from motif_amd.utils.synth_weights import fill_state_dict
+from motif_amd.utils import util
+from oracle.motif_ref import MotifRef
+
+def main():
+    times = [float(t) for t in os.environ.get("TIMES", "0.5").split(",")]
+    s = synthetic_sample(180, 320, 4, 7)
+    tl = [torch.full((1, 1), t) for t in times]
+    net = fill_state_dict(LunaTokis()).cuda().eval()
+    with torch.no_grad():
+        out, flow, _ = net(s["LQs"].cuda(), None, [t.cuda() for t in tl], s["scale"], use_GT=False, iter=4)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    with torch.no_grad():
+        ref, rflow, _ = fill_state_dict(MotifRef().eval())(s["LQs"], None, tl, s["scale"], use_GT=False, iter=4)
+    dt = time.time() - t0
+    o = out.cpu()
+    mse = float(((o.double() - ref.double()) ** 2).mean())
+    gt = s["GT"][0, 1:1 + len(times)]
+    pm = util.y_psnr_per_frame(gt, o[:, 0]); pr = util.y_psnr_per_frame(gt, ref[:, 0])
+    print("c2 full size, %d timestamp(s): oracle %.1f s on %d threads" % (len(times), dt, torch.get_num_threads()))
+    print("PSNR(build, oracle) = %.2f dB   Linf = %.3e   flow Linf = %.3e px(LR units)" % (10 * np.log10(1.0 / mse), float((o - ref).abs().max()), float((flow.cpu() - rflow).abs().max())))
+    print("Y-PSNR vs seeded GT: build %s  oracle %s  |delta| max %.5f dB" % (pm, pr, float(np.abs(pm - pr).max())))
+
+if __name__ == "__main__":
+    main()
