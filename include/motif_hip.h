@@ -71,20 +71,23 @@ int motif_splat_motif_fwd(const float* imnet_out, const float* pred, const float
 long motif_siren_pack(const float* const* w, const float* const* b, const int* dims, int n_layers,
                       float* packed, void* stream);
 
-/* imnet: in = [feat_lr[d*B+b](64 gathered) | rel_y | rel_x] -> out [2B,64,Q] planar. */
+/* `pre` (all three): 0 = `*_lr` holds the raw LR feature (64 ch) and the whole first layer runs per HR pixel;
+ * 1 = `*_lr` holds the LR-resolution partial pre-activation W0[:, gathered 64 channels] . feature + b0 (a 1x1
+ * convolution done once per clip -- it depends neither on the HR pixel nor on t), which seeds the accumulator.
+ * imnet: in = [feat_lr[d*B+b](64 gathered) | rel_y | rel_x] -> out [2B,64,Q] planar. */
 int motif_siren_imnet_fwd(const float* packed, const float* feat_lr, const int32_t* iy, const int32_t* ix,
                           const float* rel_y, const float* rel_x, float* out,
-                          int B2, int H, int W, int HH, int WW, void* stream);
+                          int B2, int H, int W, int HH, int WW, int pre, void* stream);
 /* flow_imnet: in = [flow_feat_lr(64 gathered) | t | rel_y | rel_x] -> pred [B2*N,3,Q] planar,
  * image index i = b2*N + n, t taken from times[(i) % (B*N)] laid out [B,N] (Ours.py:727-733). */
 int motif_siren_flow_fwd(const float* packed, const float* flowfeat_lr, const int32_t* iy, const int32_t* ix,
                          const float* rel_y, const float* rel_x, const float* times, float* pred,
-                         int B2, int N, int H, int W, int HH, int WW, void* stream);
+                         int B2, int N, int H, int W, int HH, int WW, int pre, void* stream);
 /* synth: post-splat normalise (Ours.py:811-836) + [out(130) | extra(3) | residual_lr(64 gathered) | t]
  * -> synth_net -> clamp(0,1) -> frames [N,B,3,HH,WW].  acc as produced by motif_splat_motif_fwd. */
 int motif_siren_synth_fwd(const float* packed, const float* acc, const float* residual_lr,
                           const int32_t* iy, const int32_t* ix, const float* times, float* frames,
-                          int B, int N, int H, int W, int HH, int WW, void* stream);
+                          int B, int N, int H, int W, int HH, int WW, int pre, void* stream);
 /* debugging/parity aid: materialise the 198-channel synth input [B*N,198,HH,WW] (Ours.py:839-844). */
 int motif_synth_input_fwd(const float* acc, const float* residual_lr, const int32_t* iy, const int32_t* ix,
                           const float* times, float* out, int B, int N, int H, int W, int HH, int WW, void* stream);

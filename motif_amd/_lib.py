@@ -27,9 +27,9 @@ _SIGS = {
     "motif_splat_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "motif_splat_motif_fwd": (c_int, [P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_siren_pack": (c_long, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), c_int, P, P]),
-    "motif_siren_imnet_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "motif_siren_flow_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "motif_siren_synth_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "motif_siren_imnet_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "motif_siren_flow_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "motif_siren_synth_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_synth_input_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_conv2d_packed_size": (c_long, [POINTER(MotifConvDesc)]),
     "motif_conv2d_pack": (c_int, [POINTER(MotifConvDesc), P, P, P]),

@@ -172,7 +172,11 @@ template <int MODE> struct Layout {
     static constexpr long LDS_FLOATS = (MODE == MODE_IMNET) ? W3 : TOTAL;
 };
 
-template <int MODE, int TP>
+// PRE: the LR-resolution part of layer 0 (W0[:, gathered channels] . feature + b0) was precomputed at LR
+// resolution by a 1x1 convolution (it does not depend on the HR pixel or on t); `src_lr` then holds that partial
+// pre-activation and seeds the accumulator instead of the bias, and only the remaining input channels go
+// through MFMA steps.
+template <int MODE, int TP, bool PRE>
 __global__ __launch_bounds__(SIREN_THREADS) void siren_kernel(SirenArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using L = Layout<MODE>;
@@ -214,7 +218,19 @@ __global__ __launch_bounds__(SIREN_THREADS) void siren_kernel(SirenArgs a) {
 
         // ------------------------------------------------ layer 0: inputs fetched in B-operand form
         f32x16 acc0[TP][2];
-        init_bias(acc0, lds + L::B0, hf);
+        if constexpr (PRE) {
+            const int ilr = (MODE == MODE_FLOW || MODE == MODE_SYNTH) ? img / a.N : img;
+#pragma unroll
+            for (int p = 0; p < TP; ++p) {
+                const float* gp = a.src_lr + (long)ilr * 64 * HWl + lr[p] + (long)(4 * hf) * HWl;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc0[p][t][r] = gp[(long)(32 * t + (r & 3) + 8 * (r >> 2)) * HWl];
+            }
+        } else {
+            init_bias(acc0, lds + L::B0, hf);
+        }
         const float* w0 = lds + L::W0;
         auto step0 = [&](int s, const float (&v)[TP]) {      // one k-step of layer 0 for both tiles
 #pragma unroll
@@ -227,31 +243,33 @@ __global__ __launch_bounds__(SIREN_THREADS) void siren_kernel(SirenArgs a) {
         if constexpr (MODE == MODE_IMNET || MODE == MODE_FLOW) {
             // img = b2 (imnet) or b2*N + n (flow); source LR image = b2
             const int b2 = (MODE == MODE_FLOW) ? img / a.N : img;
-            const float* f[TP];
-#pragma unroll
-            for (int p = 0; p < TP; ++p) f[p] = a.src_lr + (long)b2 * 64 * HWl + lr[p] + (long)(4 * hf) * HWl;
-            float v[4][TP];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int p = 0; p < TP; ++p) v[r][p] = f[p][(long)r * HWl];
-#pragma unroll 1
-            for (int q = 0; q < 8; ++q) {      // software pipelined: the gather of q+1 flies under the MFMAs of q
-                float vn[4][TP];
-#pragma unroll
-                for (int p = 0; p < TP; ++p) f[p] += 8 * HWl;
-                if (q < 7) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int p = 0; p < TP; ++p) vn[r][p] = f[p][(long)r * HWl];
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) step0(q * 4 + r, v[r]);
-#pragma unroll
+            if constexpr (!PRE) {
+                const float* f[TP];
+    #pragma unroll
+                for (int p = 0; p < TP; ++p) f[p] = a.src_lr + (long)b2 * 64 * HWl + lr[p] + (long)(4 * hf) * HWl;
+                float v[4][TP];
+    #pragma unroll
                 for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int p = 0; p < TP; ++p) v[r][p] = vn[r][p];
+    #pragma unroll
+                    for (int p = 0; p < TP; ++p) v[r][p] = f[p][(long)r * HWl];
+    #pragma unroll 1
+                for (int q = 0; q < 8; ++q) {      // software pipelined: the gather of q+1 flies under the MFMAs of q
+                    float vn[4][TP];
+    #pragma unroll
+                    for (int p = 0; p < TP; ++p) f[p] += 8 * HWl;
+                    if (q < 7) {
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r)
+    #pragma unroll
+                            for (int p = 0; p < TP; ++p) vn[r][p] = f[p][(long)r * HWl];
+                    }
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) step0(q * 4 + r, v[r]);
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r)
+    #pragma unroll
+                        for (int p = 0; p < TP; ++p) v[r][p] = vn[r][p];
+                }
             }
             float e[4][TP];
 #pragma unroll
@@ -327,7 +345,7 @@ __global__ __launch_bounds__(SIREN_THREADS) void siren_kernel(SirenArgs a) {
                 if (k == 130) return A[p][131 * Q];
                 if (k == 131) return cnt[p] / 16.0f;
                 if (k == 132) return wz_[p] / cnt_[p];
-                if (k <= 196) return R[p][(long)(k - 133) * HWl];
+                if (k <= 196) return PRE ? 0.f : R[p][(long)(k - 133) * HWl];
                 if (k == 197) return tval;
                 return 0.f;
             };
@@ -338,33 +356,35 @@ __global__ __launch_bounds__(SIREN_THREADS) void siren_kernel(SirenArgs a) {
                 for (int p = 0; p < TP; ++p) v[p] = general(kmap(s, hf), p);
                 step0(s, v);
             }
-            // q = 17..23: k = 136..191, all residual channels k-133
-            {
-                const float* rp[TP];
-#pragma unroll
-                for (int p = 0; p < TP; ++p) rp[p] = R[p] + (long)(136 - 133 + 4 * hf) * HWl;
-                float v[4][TP];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int p = 0; p < TP; ++p) v[r][p] = rp[p][(long)r * HWl];
-#pragma unroll 1
-                for (int q = 17; q < 24; ++q) {
-                    float vn[4][TP];
-#pragma unroll
-                    for (int p = 0; p < TP; ++p) rp[p] += 8 * HWl;
-                    if (q < 23) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-#pragma unroll
-                            for (int p = 0; p < TP; ++p) vn[r][p] = rp[p][(long)r * HWl];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) step0(q * 4 + r, v[r]);
-#pragma unroll
+            if constexpr (!PRE) {
+                // q = 17..23: k = 136..191, all residual channels k-133
+                {
+                    const float* rp[TP];
+    #pragma unroll
+                    for (int p = 0; p < TP; ++p) rp[p] = R[p] + (long)(136 - 133 + 4 * hf) * HWl;
+                    float v[4][TP];
+    #pragma unroll
                     for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int p = 0; p < TP; ++p) v[r][p] = vn[r][p];
+    #pragma unroll
+                        for (int p = 0; p < TP; ++p) v[r][p] = rp[p][(long)r * HWl];
+    #pragma unroll 1
+                    for (int q = 17; q < 24; ++q) {
+                        float vn[4][TP];
+    #pragma unroll
+                        for (int p = 0; p < TP; ++p) rp[p] += 8 * HWl;
+                        if (q < 23) {
+    #pragma unroll
+                            for (int r = 0; r < 4; ++r)
+    #pragma unroll
+                                for (int p = 0; p < TP; ++p) vn[r][p] = rp[p][(long)r * HWl];
+                        }
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) step0(q * 4 + r, v[r]);
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r)
+    #pragma unroll
+                            for (int p = 0; p < TP; ++p) v[r][p] = vn[r][p];
+                    }
                 }
             }
 #pragma unroll
@@ -523,7 +543,7 @@ extern "C" long motif_siren_pack(const float* const* w, const float* const* b, c
     return total;
 }
 
-template <int MODE, int TP>
+template <int MODE, int TP, bool PRE>
 static int launch_siren(const SirenArgs& a_in, void* stream) {
     using L = Layout<MODE>;
     const size_t lds = (size_t)L::LDS_FLOATS * 4;
@@ -532,7 +552,7 @@ static int launch_siren(const SirenArgs& a_in, void* stream) {
     SirenArgs a = a_in;
     a.stagger = 2;
     if (const char* e = getenv("MOTIF_SIREN_STAGGER")) a.stagger = atoi(e);
-    hipError_t e = hipFuncSetAttribute((const void*)siren_kernel<MODE, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)siren_kernel<MODE, TP, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -540,33 +560,33 @@ static int launch_siren(const SirenArgs& a_in, void* stream) {
     const long tiles = (long)a.NB * ((Q + 32 * TP - 1) / (32 * TP));
     long blocks = (tiles + SIREN_WAVES - 1) / SIREN_WAVES;
     if (blocks > cus) blocks = cus;
-    siren_kernel<MODE, TP><<<(int)blocks, SIREN_THREADS, lds, (hipStream_t)stream>>>(a);
+    siren_kernel<MODE, TP, PRE><<<(int)blocks, SIREN_THREADS, lds, (hipStream_t)stream>>>(a);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }
 
 extern "C" int motif_siren_imnet_fwd(const float* packed, const float* feat_lr, const int32_t* iy, const int32_t* ix,
                                      const float* rel_y, const float* rel_x, float* out,
-                                     int B2, int H, int W, int HH, int WW, void* stream) {
+                                     int B2, int H, int W, int HH, int WW, int pre, void* stream) {
     if (!packed || !feat_lr || !iy || !ix || !rel_y || !rel_x || !out || B2 < 1) return MOTIF_EINVAL;
     SirenArgs a{packed, feat_lr, nullptr, iy, ix, rel_y, rel_x, nullptr, out, B2, 1, B2, H, W, HH, WW};
-    return launch_siren<MODE_IMNET, SIREN_TP_IMNET>(a, stream);
+    return pre ? launch_siren<MODE_IMNET, SIREN_TP_IMNET, true>(a, stream) : launch_siren<MODE_IMNET, SIREN_TP_IMNET, false>(a, stream);
 }
 
 extern "C" int motif_siren_flow_fwd(const float* packed, const float* flowfeat_lr, const int32_t* iy, const int32_t* ix,
                                     const float* rel_y, const float* rel_x, const float* times, float* pred,
-                                    int B2, int N, int H, int W, int HH, int WW, void* stream) {
+                                    int B2, int N, int H, int W, int HH, int WW, int pre, void* stream) {
     if (!packed || !flowfeat_lr || !iy || !ix || !rel_y || !rel_x || !times || !pred || B2 < 2 || (B2 & 1) || N < 1) return MOTIF_EINVAL;
     SirenArgs a{packed, flowfeat_lr, nullptr, iy, ix, rel_y, rel_x, times, pred, B2 * N, N, B2 / 2, H, W, HH, WW};
-    return launch_siren<MODE_FLOW, SIREN_TP_FLOW>(a, stream);
+    return pre ? launch_siren<MODE_FLOW, SIREN_TP_FLOW, true>(a, stream) : launch_siren<MODE_FLOW, SIREN_TP_FLOW, false>(a, stream);
 }
 
 extern "C" int motif_siren_synth_fwd(const float* packed, const float* acc, const float* residual_lr,
                                      const int32_t* iy, const int32_t* ix, const float* times, float* frames,
-                                     int B, int N, int H, int W, int HH, int WW, void* stream) {
+                                     int B, int N, int H, int W, int HH, int WW, int pre, void* stream) {
     if (!packed || !acc || !residual_lr || !iy || !ix || !times || !frames || B < 1 || N < 1) return MOTIF_EINVAL;
     SirenArgs a{packed, residual_lr, acc, iy, ix, nullptr, nullptr, times, frames, B * N, N, B, H, W, HH, WW};
-    return launch_siren<MODE_SYNTH, SIREN_TP_SYNTH>(a, stream);
+    return pre ? launch_siren<MODE_SYNTH, SIREN_TP_SYNTH, true>(a, stream) : launch_siren<MODE_SYNTH, SIREN_TP_SYNTH, false>(a, stream);
 }
 
 // parity aid: the 198-channel synth input, materialised (never used on the product path)

@@ -50,6 +50,16 @@ class Siren(nn.Module):
             out.append((lin.weight, lin.bias))
         return out
 
+    def l0_plan(self, lo, hi):
+        """1x1-conv plan of W0[:, lo:hi] with bias b0: the part of the first layer whose inputs are gathered LR
+        features, evaluated once per clip at LR resolution (`pre=1` mode of the MLP kernels)."""
+        w, b = self.net[0].linear.weight, self.net[0].linear.bias
+        key = (w.data_ptr(), w._version, b._version, lo, hi, str(w.device))
+        if getattr(self, "_l0_key", None) != key:
+            ws = w.detach()[:, lo:hi].contiguous().view(w.shape[0], hi - lo, 1, 1)
+            self._l0_plan, self._l0_key = ops.ConvPlan(ws, b), key
+        return self._l0_plan
+
     def packed(self):
         key = tuple((w.data_ptr(), w._version, b._version, str(w.device)) for w, b in self.linears())
         if key != self._key:

@@ -270,33 +270,33 @@ def siren_pack(linears):
     return blob
 
 
-def siren_imnet(blob, feat_lr, iy, ix, rel_y, rel_x, HH, WW):
+def siren_imnet(blob, feat_lr, iy, ix, rel_y, rel_x, HH, WW, pre=False):
     lib = _lib.load()
     feat_lr = _c(feat_lr)
     b2, c, h, w = feat_lr.shape
     out = torch.empty(b2, 64, HH, WW, dtype=torch.float32, device=feat_lr.device)
     check(lib.motif_siren_imnet_fwd(_p(blob), _p(feat_lr), _p(iy), _p(ix), _p(rel_y), _p(rel_x), _p(out),
-                                    b2, h, w, HH, WW, _stream()), "motif_siren_imnet_fwd")
+                                    b2, h, w, HH, WW, int(pre), _stream()), "motif_siren_imnet_fwd")
     return out
 
 
-def siren_flow(blob, flowfeat_lr, iy, ix, rel_y, rel_x, times, N, HH, WW):
+def siren_flow(blob, flowfeat_lr, iy, ix, rel_y, rel_x, times, N, HH, WW, pre=False):
     lib = _lib.load()
     flowfeat_lr = _c(flowfeat_lr)
     b2, c, h, w = flowfeat_lr.shape
     pred = torch.empty(b2 * N, 3, HH, WW, dtype=torch.float32, device=flowfeat_lr.device)
     check(lib.motif_siren_flow_fwd(_p(blob), _p(flowfeat_lr), _p(iy), _p(ix), _p(rel_y), _p(rel_x), _p(_c(times)), _p(pred),
-                                   b2, N, h, w, HH, WW, _stream()), "motif_siren_flow_fwd")
+                                   b2, N, h, w, HH, WW, int(pre), _stream()), "motif_siren_flow_fwd")
     return pred
 
 
-def siren_synth(blob, acc, residual_lr, iy, ix, times, B, N, HH, WW):
+def siren_synth(blob, acc, residual_lr, iy, ix, times, B, N, HH, WW, pre=False):
     lib = _lib.load()
     residual_lr = _c(residual_lr)
     _, _, h, w = residual_lr.shape
     frames = torch.empty(N, B, 3, HH, WW, dtype=torch.float32, device=acc.device)
     check(lib.motif_siren_synth_fwd(_p(blob), _p(acc), _p(residual_lr), _p(iy), _p(ix), _p(_c(times)), _p(frames),
-                                    B, N, h, w, HH, WW, _stream()), "motif_siren_synth_fwd")
+                                    B, N, h, w, HH, WW, int(pre), _stream()), "motif_siren_synth_fwd")
     return frames
 
 

@@ -353,6 +353,8 @@ def test_siren_kernels_vs_torch(HW):
         r = ref.imnet(inp.reshape(2 * B, 66, Q).permute(0, 2, 1)).permute(0, 2, 1).reshape(2 * B, 64, HH, WW)
     o = ops.siren_imnet(mine.imnet.packed(), feat.to(dev()), iy, ix, rel_y, rel_x, HH, WW)
     close(o, r, 5e-6, 1e-4, "imnet")
+    l0 = ops.conv2d(mine.imnet.l0_plan(0, 64), feat.to(dev()))          # LR partial of layer 0, then pre=1
+    close(ops.siren_imnet(mine.imnet.packed(), l0, iy, ix, rel_y, rel_x, HH, WW, pre=True), r, 5e-6, 1e-4, "imnet pre")
     # flow_imnet
     times = torch.tensor([[0.0, 0.5], [0.25, 1.0]])
     g = gather(feat).repeat(1, N, 1, 1).reshape(2 * B * N, 64, HH, WW)
@@ -362,6 +364,8 @@ def test_siren_kernels_vs_torch(HW):
         r = ref.flow_imnet(inp.reshape(2 * B * N, 67, Q).permute(0, 2, 1)).permute(0, 2, 1).reshape(2 * B * N, 3, HH, WW)
     o = ops.siren_flow(mine.flow_imnet.packed(), feat.to(dev()), iy, ix, rel_y, rel_x, times.to(dev()), N, HH, WW)
     close(o, r, 5e-6, 1e-4, "flow_imnet")
+    l0 = ops.conv2d(mine.flow_imnet.l0_plan(0, 64), feat.to(dev()))
+    close(ops.siren_flow(mine.flow_imnet.packed(), l0, iy, ix, rel_y, rel_x, times.to(dev()), N, HH, WW, pre=True), r, 5e-6, 1e-4, "flow pre")
     # synth (with the normalisation prologue): build an accumulator with zeros / ones / exact-equality cases
     acc = rnd(B * N, 133, HH, WW, seed=5, scale=0.5)
     acc[:, 130] = acc[:, 130].abs() * 2 + 1e-3
@@ -388,6 +392,8 @@ def test_siren_kernels_vs_torch(HW):
         r = ref.synth_net(allin.reshape(B * N, 198, Q).permute(0, 2, 1)).permute(0, 2, 1).reshape(B, N, 3, HH, WW).permute(1, 0, 2, 3, 4).clamp(0, 1)
     o = ops.siren_synth(mine.synth_net.packed(), acc.to(dev()), res.to(dev()), iy, ix, times.to(dev()), B, N, HH, WW)
     close(o, r, 2e-5, 1e-4, "synth")
+    l0 = ops.conv2d(mine.synth_net.l0_plan(133, 197), res.to(dev()))
+    close(ops.siren_synth(mine.synth_net.packed(), acc.to(dev()), l0, iy, ix, times.to(dev()), B, N, HH, WW, pre=True), r, 2e-5, 1e-4, "synth pre")
 
 
 # ------------------------------------------------------------------------------------------- fused MoTIF splat
