@@ -106,6 +106,12 @@ typedef struct MotifConvDesc {
     int res_mode;             /* 0 none; 1 out=act(acc+res); 2 out=act(acc)+res; 3 out=relu(act(acc)+res);
                                  4 out=act(acc)*res */
     long in0_bs, in1_bs, res_bs, out_bs;  /* batch strides in elements (0 -> dense default) */
+    int mma;                  /* arithmetic of the contraction: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32);
+                                 6 = fp32-equivalent on the bf16 matrix cores (3-way bf16 split, 6 products, fp32
+                                 accumulate); 3 = 2-way split, 3 products (16-bit mantissa); 1 = plain bf16.
+                                 Non-zero values apply to 3x3/stride-1 layers with > 32 couts and >= 16 input
+                                 channels per group, every other layer runs mode 0.  The packed weight format
+                                 depends on it: pack and forward must be given the same value. */
 } MotifConvDesc;
 
 long motif_conv2d_packed_size(const MotifConvDesc* d);

@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libmotif_hip.so")
+SO_PATH = os.environ.get("MOTIF_HIP_LIB") or os.path.join(_HERE, "libmotif_hip.so")   # env: instrumented debug builds
 _lib = None
 
 
@@ -17,7 +17,7 @@ class MotifConvDesc(Structure):
                 ("Cout", c_int), ("KH", c_int), ("KW", c_int),
                 ("stride", c_int), ("pad", c_int), ("dil", c_int), ("groups", c_int),
                 ("pad_mode", c_int), ("act", c_int), ("act2", c_int), ("act_split", c_int), ("res_mode", c_int),
-                ("in0_bs", c_long), ("in1_bs", c_long), ("res_bs", c_long), ("out_bs", c_long)]
+                ("in0_bs", c_long), ("in1_bs", c_long), ("res_bs", c_long), ("out_bs", c_long), ("mma", c_int)]
 
 
 P = c_void_p

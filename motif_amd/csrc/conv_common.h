@@ -1,0 +1,153 @@
+// Shared by the convolution engines: launch arguments and the fused epilogue (bias, residual, activation, store).
+#pragma once
+#include "common.h"
+#include <type_traits>
+
+#define MOTIF_MAX_PROBLEMS 4
+struct ConvArgs {
+    // up to MOTIF_MAX_PROBLEMS independent convolutions of identical shape in one launch (blockIdx.z = p*N + n)
+    const float* in0[MOTIF_MAX_PROBLEMS]; const float* in1[MOTIF_MAX_PROBLEMS]; const float* wp[MOTIF_MAX_PROBLEMS];
+    const float* bias[MOTIF_MAX_PROBLEMS]; const float* res[MOTIF_MAX_PROBLEMS]; float* out[MOTIF_MAX_PROBLEMS];
+    long in0_bs[MOTIF_MAX_PROBLEMS], in1_bs[MOTIF_MAX_PROBLEMS], res_bs[MOTIF_MAX_PROBLEMS], out_bs[MOTIF_MAX_PROBLEMS];
+    int N, C0, H, W, Ho, Wo;
+    int Cin_g, Cout_g, Cout;
+    int KH, KW, stride, pad, dil, pad_mode;
+    int act, act2, act_split, res_mode;
+    int CK, PH, PW, Kpad, tiles_x, ncg;
+    int dbg;   // tuning aid: 1 = skip staging, 2 = skip MFMA loop
+};
+
+// Limits of one reduction chunk (host planner keeps to them): patch elements <= PATCH_MAX, packed weight
+// floats <= WCHUNK_MAX, so that a whole chunk can be prefetched into registers while the previous one is
+// being multiplied (global -> VGPR issue-early, VGPR -> LDS write-late; two LDS buffers, one barrier per chunk).
+#define PATCH_MAX 6144
+#define WCHUNK_MAX 8192
+
+template <int ACT>
+__device__ __forceinline__ float act_c(float v) {
+    if constexpr (ACT == MOTIF_ACT_RELU) return v > 0.f ? v : 0.f;
+    else if constexpr (ACT == MOTIF_ACT_LRELU) return v > 0.f ? v : 0.1f * v;
+    else if constexpr (ACT == MOTIF_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    else if constexpr (ACT == MOTIF_ACT_TANH) return tanhf(v);
+    else return v;
+}
+
+// Epilogue of one wave: acc[i][j] = 32 couts (tile i of the block's cout group) x 32 pixels of output row oy0+j,
+// column ox.  `a_*` are the per-problem pointers/strides, bias_s the LDS copy of the cout group's bias.
+template <int NC, int RPW>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NC][RPW], const float* bias_s, int n, int g, int cg,
+                                              int oy0, int ox, int half, const float* a_res, long a_res_bs, float* a_out,
+                                              long a_out_bs) {
+    constexpr int WN = 32 * NC;
+    // epilogue: C/D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*half (cout within tile).
+    // The activation / residual mode is block-uniform: dispatch once, keep the store loop branch-free.
+    if (ox >= a.Wo || (a.dbg & 4)) return;
+    const long HWo = (long)a.Ho * a.Wo;
+    const int cobase = g * a.Cout_g + cg * WN;
+    const int climit = a.Cout_g - cg * WN;                 // valid couts in this group
+    // fast path (block-uniform): a full cout group and 32-bit element offsets.  Bias comes from LDS as 8 vector reads,
+    // the residual values of a tile are requested together, and every access is uniform-base + one per-lane offset.
+    const bool fast = climit >= WN && HWo < (1L << 28);
+    auto run = [&](auto actf, auto res_tag) {
+        constexpr bool RES = decltype(res_tag)::value;
+        if (fast) {
+            float bv[NC][16];
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 b4 = *(const f32x4*)(bias_s + i * 32 + 8 * q + 4 * half);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) bv[i][4 * q + u] = b4[u];
+                }
+            float* ob = a_out + (long)n * a_out_bs + (long)cobase * HWo;
+            const float* rb = RES ? a_res + (long)n * a_res_bs + (long)cobase * HWo : nullptr;
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                const int oy = oy0 + j;
+                if (oy >= a.Ho) continue;
+                const unsigned lane_off = (unsigned)(oy * a.Wo + ox) + 4u * half * (unsigned)HWo;
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    float rv[16];
+                    if constexpr (RES) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) rv[r] = (rb + (long)(i * 32 + (r & 3) + 8 * (r >> 2)) * HWo)[lane_off];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int colu = i * 32 + (r & 3) + 8 * (r >> 2);
+                        const float v = actf(acc[i][j][r] + bv[i][r], RES ? rv[r] : 0.f, cobase + colu + 4 * half);
+                        (ob + (long)colu * HWo)[lane_off] = v;
+                    }
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int oy = oy0 + j;
+            if (oy >= a.Ho) continue;
+            const long pixo = (long)oy * a.Wo + ox;
+            float* op = a_out + (long)n * a_out_bs + (long)cobase * HWo + pixo;
+            const float* rp = RES ? a_res + (long)n * a_res_bs + (long)cobase * HWo + pixo : nullptr;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                float rv[16];
+                if constexpr (RES) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int col = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        rv[r] = (col < climit) ? rp[(long)col * HWo] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[i][j][r] + bias_s[col];
+                    v = actf(v, RES ? rv[r] : 0.f, cobase + col);
+                    if (col < climit) op[(long)col * HWo] = v;
+                }
+            }
+        }
+    };
+    auto run_rm = [&](auto actf) {
+        if (a.res_mode) run(actf, std::true_type{}); else run(actf, std::false_type{});
+    };
+    const int rm = a.res_mode;
+    if (a.act_split > 0) {
+        run_rm([&](float v, float rv, int co) {
+            const int act = co >= a.act_split ? a.act2 : a.act;
+            if (rm == 1) return act_apply(v + rv, act);
+            float y = act_apply(v, act);
+            if (rm == 2) y += rv; else if (rm == 3) { y += rv; y = y > 0.f ? y : 0.f; } else if (rm == 4) y *= rv;
+            return y;
+        });
+    } else if (rm == 0) {
+        switch (a.act) {
+            case MOTIF_ACT_RELU: run([](float v, float, int) { return act_c<MOTIF_ACT_RELU>(v); }, std::false_type{}); break;
+            case MOTIF_ACT_LRELU: run([](float v, float, int) { return act_c<MOTIF_ACT_LRELU>(v); }, std::false_type{}); break;
+            case MOTIF_ACT_SIGMOID: run([](float v, float, int) { return act_c<MOTIF_ACT_SIGMOID>(v); }, std::false_type{}); break;
+            case MOTIF_ACT_TANH: run([](float v, float, int) { return act_c<MOTIF_ACT_TANH>(v); }, std::false_type{}); break;
+            default: run([](float v, float, int) { return v; }, std::false_type{}); break;
+        }
+    } else if (rm == 1 && a.act == MOTIF_ACT_NONE) {
+        run([](float v, float rv, int) { return v + rv; }, std::true_type{});
+    } else if (rm == 1 && a.act == MOTIF_ACT_LRELU) {
+        run([](float v, float rv, int) { return act_c<MOTIF_ACT_LRELU>(v + rv); }, std::true_type{});
+    } else {
+        const int act = a.act;
+        run_rm([&](float v, float rv, int) {
+            if (rm == 1) return act_apply(v + rv, act);
+            float y = act_apply(v, act);
+            if (rm == 2) y += rv; else if (rm == 3) { y += rv; y = y > 0.f ? y : 0.f; } else if (rm == 4) y *= rv;
+            return y;
+        });
+    }
+}
+
+// split engine (conv_split.hip)
+bool motif_conv_split_eligible(const MotifConvDesc* d);
+long motif_conv_split_packed_floats(const MotifConvDesc* d);
+int motif_conv_split_pack(const MotifConvDesc* d, const float* weight, float* packed, hipStream_t s);
+int motif_conv_split_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s);

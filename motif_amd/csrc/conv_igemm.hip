@@ -13,37 +13,8 @@
 // The (c,ky,kx)->patch-offset map is a small LDS table so ONE kernel serves every kernel size, stride,
 // dilation and group count on the path (3x3 s1/s2, 1x1, 7x7 s2, dilated PWC refiner, grouped).
 // Fused: channel concat of two inputs, bias, residual, activation (per channel range).
-#include "common.h"
+#include "conv_common.h"
 #include <stdlib.h>
-
-#define MOTIF_MAX_PROBLEMS 4
-struct ConvArgs {
-    // up to MOTIF_MAX_PROBLEMS independent convolutions of identical shape in one launch (blockIdx.z = p*N + n)
-    const float* in0[MOTIF_MAX_PROBLEMS]; const float* in1[MOTIF_MAX_PROBLEMS]; const float* wp[MOTIF_MAX_PROBLEMS];
-    const float* bias[MOTIF_MAX_PROBLEMS]; const float* res[MOTIF_MAX_PROBLEMS]; float* out[MOTIF_MAX_PROBLEMS];
-    long in0_bs[MOTIF_MAX_PROBLEMS], in1_bs[MOTIF_MAX_PROBLEMS], res_bs[MOTIF_MAX_PROBLEMS], out_bs[MOTIF_MAX_PROBLEMS];
-    int N, C0, H, W, Ho, Wo;
-    int Cin_g, Cout_g, Cout;
-    int KH, KW, stride, pad, dil, pad_mode;
-    int act, act2, act_split, res_mode;
-    int CK, PH, PW, Kpad, tiles_x, ncg;
-    int dbg;   // tuning aid: 1 = skip staging, 2 = skip MFMA loop
-};
-
-// Limits of one reduction chunk (host planner keeps to them): patch elements <= PATCH_MAX, packed weight
-// floats <= WCHUNK_MAX, so that a whole chunk can be prefetched into registers while the previous one is
-// being multiplied (global -> VGPR issue-early, VGPR -> LDS write-late; two LDS buffers, one barrier per chunk).
-#define PATCH_MAX 6144
-#define WCHUNK_MAX 8192
-
-template <int ACT>
-__device__ __forceinline__ float act_c(float v) {
-    if constexpr (ACT == MOTIF_ACT_RELU) return v > 0.f ? v : 0.f;
-    else if constexpr (ACT == MOTIF_ACT_LRELU) return v > 0.f ? v : 0.1f * v;
-    else if constexpr (ACT == MOTIF_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
-    else if constexpr (ACT == MOTIF_ACT_TANH) return tanhf(v);
-    else return v;
-}
 
 // SPEC 1: 3x3, stride 1, dilation 1 (patch pitch 34): tap offsets are immediates, the MFMA loop has no VALU.
 template <int NC, int RPW, int SPEC>
@@ -68,7 +39,7 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
     float* patch0 = smem;
     float* wl0 = patch0 + 2 * patch_elems;
     int* koff = (int*)(wl0 + 2 * KC * WN);
-    float* bias_s = (float*)(koff + KC);      // [WN] bias of this cout group (zeros if none)
+    float* bias_s = (float*)(koff + ((KC + 3) & ~3));      // [WN] bias of this cout group (zeros if none), 16-byte aligned
 
     const long HW = (long)a.H * a.W;
     // chunk-invariant staging plan, in registers: element e = tid + NT*j of the [CK][PH][PW] patch comes from
@@ -100,10 +71,8 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
         const int ky = t / a.KW, kx = t - ky * a.KW;
         koff[t] = ky * a.dil * a.PW + kx * a.dil;
     }
-    if (tid < WN) {
-        const int col = cg * WN + tid;
-        bias_s[tid] = (a_bias && col < a.Cout_g) ? a_bias[g * a.Cout_g + col] : 0.f;
-    }
+    float bias_v = 0.f;                       // requested now, parked in LDS before the first barrier
+    if (tid < WN && a_bias && cg * WN + tid < a.Cout_g) bias_v = a_bias[g * a.Cout_g + cg * WN + tid];
 
     f32x16 acc[NC][RPW];
 #pragma unroll
@@ -162,6 +131,7 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
 
     int rows_cur = issue(0);
     commit(0, rows_cur);
+    if (tid < WN) bias_s[tid] = bias_v;
     __syncthreads();
     int cur = 0;
     for (int c0 = 0; c0 < a.Cin_g; c0 += a.CK) {
@@ -236,71 +206,7 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
         rows_cur = rows_next;
     }
 
-    // epilogue: C/D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*half (cout within tile).
-    // The activation / residual mode is block-uniform: dispatch once, keep the store loop branch-free.
-    const int ox = tx * 32 + l31;
-    if (ox >= a.Wo || (a.dbg & 4)) return;
-    const long HWo = (long)a.Ho * a.Wo;
-    const int cobase = g * a.Cout_g + cg * WN;
-    const int climit = a.Cout_g - cg * WN;                 // valid couts in this group
-    auto run = [&](auto actf) {
-#pragma unroll
-        for (int j = 0; j < RPW; ++j) {
-            const int oy = ty * 8 + RPW * wave + j;
-            if (oy >= a.Ho) continue;
-            const long pixo = (long)oy * a.Wo + ox;
-            float* op = a_out + (long)n * a_out_bs + (long)cobase * HWo + pixo;
-            const float* rp = a.res_mode ? a_res + (long)n * a_res_bs + (long)cobase * HWo + pixo : nullptr;
-#pragma unroll
-            for (int i = 0; i < NC; ++i) {
-                float rv[16];
-                if (a.res_mode) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int col = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        rv[r] = (col < climit) ? rp[(long)col * HWo] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int col = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    float v = acc[i][j][r] + bias_s[col];
-                    v = actf(v, a.res_mode ? rv[r] : 0.f, cobase + col);
-                    if (col < climit) op[(long)col * HWo] = v;
-                }
-            }
-        }
-    };
-    const int rm = a.res_mode;
-    if (a.act_split > 0) {
-        run([&](float v, float rv, int co) {
-            const int act = co >= a.act_split ? a.act2 : a.act;
-            if (rm == 1) return act_apply(v + rv, act);
-            float y = act_apply(v, act);
-            if (rm == 2) y += rv; else if (rm == 3) { y += rv; y = y > 0.f ? y : 0.f; } else if (rm == 4) y *= rv;
-            return y;
-        });
-    } else if (rm == 0) {
-        switch (a.act) {
-            case MOTIF_ACT_RELU: run([](float v, float, int) { return act_c<MOTIF_ACT_RELU>(v); }); break;
-            case MOTIF_ACT_LRELU: run([](float v, float, int) { return act_c<MOTIF_ACT_LRELU>(v); }); break;
-            case MOTIF_ACT_SIGMOID: run([](float v, float, int) { return act_c<MOTIF_ACT_SIGMOID>(v); }); break;
-            case MOTIF_ACT_TANH: run([](float v, float, int) { return act_c<MOTIF_ACT_TANH>(v); }); break;
-            default: run([](float v, float, int) { return v; }); break;
-        }
-    } else if (rm == 1 && a.act == MOTIF_ACT_NONE) {
-        run([](float v, float rv, int) { return v + rv; });
-    } else if (rm == 1 && a.act == MOTIF_ACT_LRELU) {
-        run([](float v, float rv, int) { return act_c<MOTIF_ACT_LRELU>(v + rv); });
-    } else {
-        const int act = a.act;
-        run([&](float v, float rv, int) {
-            if (rm == 1) return act_apply(v + rv, act);
-            float y = act_apply(v, act);
-            if (rm == 2) y += rv; else if (rm == 3) { y += rv; y = y > 0.f ? y : 0.f; } else if (rm == 4) y *= rv;
-            return y;
-        });
-    }
+    conv_epilogue<NC, RPW>(a, acc, bias_s, n, g, cg, ty * 8 + RPW * wave, tx * 32 + l31, half, a_res, a_res_bs, a_out, a_out_bs);
 }
 
 // weight [Cout, Cin_g, KH, KW] -> packed [groups][ncg][Kpad][32*NC], zero padded
@@ -369,18 +275,23 @@ bool plan_conv(const MotifConvDesc* d, ConvPlan* p) {
     }
     p->CK = ck;
     const size_t patch_elems = ((size_t)ck * PHW + 3) & ~(size_t)3;
-    p->lds = (2 * patch_elems + 2 * (size_t)ck * p->T * p->WN + (size_t)ck * p->T + (size_t)p->WN) * 4;
+    p->lds = (2 * patch_elems + 2 * (size_t)ck * p->T * p->WN + (((size_t)ck * p->T + 3) & ~(size_t)3) + (size_t)p->WN) * 4;
     return p->lds <= 160 * 1024;
 }
 }  // namespace
 
 extern "C" long motif_conv2d_packed_size(const MotifConvDesc* d) {
+    if (motif_conv_split_eligible(d)) return motif_conv_split_packed_floats(d);
     ConvPlan p;
     if (!plan_conv(d, &p)) return MOTIF_EINVAL;
     return (long)d->groups * p.ncg * p.Kpad * p.WN;
 }
 
 extern "C" int motif_conv2d_pack(const MotifConvDesc* d, const float* weight, float* packed, void* stream) {
+    if (motif_conv_split_eligible(d)) {
+        if (!weight || !packed) return MOTIF_EINVAL;
+        return motif_conv_split_pack(d, weight, packed, (hipStream_t)stream);
+    }
     ConvPlan p;
     if (!plan_conv(d, &p) || !weight || !packed) return MOTIF_EINVAL;
     long total = (long)d->groups * p.ncg * p.Kpad * p.WN;
@@ -394,7 +305,9 @@ extern "C" int motif_conv2d_fwd_multi(const MotifConvDesc* d, int P, const float
                                       float* const* out, const long* in0_bs, const long* in1_bs, const long* res_bs,
                                       const long* out_bs, void* stream) {
     ConvPlan p;
-    if (!plan_conv(d, &p)) return MOTIF_ELIMIT;
+    const bool split = motif_conv_split_eligible(d);
+    if (!split && !plan_conv(d, &p)) return MOTIF_ELIMIT;
+    if (split) { p.Ho = d->H + 2 * d->pad - 2; p.Wo = d->W + 2 * d->pad - 2; }
     if (P < 1 || P > MOTIF_MAX_PROBLEMS || !in0 || !packed || !out || d->N < 1) return MOTIF_EINVAL;
     ConvArgs a;
     const long HW = (long)d->H * d->W, HWo = (long)p.Ho * p.Wo;
@@ -409,6 +322,14 @@ extern "C" int motif_conv2d_fwd_multi(const MotifConvDesc* d, int P, const float
         a.out_bs[i] = (out_bs && out_bs[j]) ? out_bs[j] : (long)d->Cout * HWo;
     }
     a.N = d->N;
+    a.dbg = 0;
+    if (const char* e = getenv("MOTIF_CONV_DBG")) a.dbg = atoi(e);
+    if (split) {
+        a.C0 = d->C0; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+        a.KH = 3; a.KW = 3; a.stride = 1; a.pad = d->pad; a.dil = 1; a.pad_mode = d->pad_mode;
+        a.act = d->act; a.act2 = d->act2; a.act_split = d->act_split; a.res_mode = d->res_mode;
+        return motif_conv_split_launch(d, a, P, (hipStream_t)stream);
+    }
     a.C0 = d->C0; a.H = d->H; a.W = d->W; a.Ho = p.Ho; a.Wo = p.Wo;
     a.Cin_g = p.Cin_g; a.Cout_g = p.Cout_g; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil; a.pad_mode = d->pad_mode;
@@ -417,8 +338,6 @@ extern "C" int motif_conv2d_fwd_multi(const MotifConvDesc* d, int P, const float
     a.tiles_x = (p.Wo + 31) / 32;
     const int tiles_y = (p.Ho + 7) / 8;
     a.ncg = p.ncg;
-    a.dbg = 0;
-    if (const char* e = getenv("MOTIF_CONV_DBG")) a.dbg = atoi(e);
     dim3 grid(a.tiles_x * tiles_y, d->groups * p.ncg, d->N * P);
     hipStream_t s = (hipStream_t)stream;
     const bool spec = d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1 && !getenv("MOTIF_CONV_NOSPEC");

@@ -38,12 +38,31 @@ def _planar(t):
 
 
 # ----------------------------------------------------------------------------------------- conv engine
-class ConvPlan:
-    """Packed weights of one convolution layer, re-packed when the parameter changes."""
+# Arithmetic of the convolution contractions (MotifConvDesc.mma): 0 = fp32 MFMA, 6 = fp32-equivalent 3-way bf16
+# split on the bf16 matrix cores (6 products, fp32 accumulate), 3 = 2-way split, 1 = plain bf16.
+MMA_FP32, MMA_BF16X3, MMA_BF16X2, MMA_BF16 = 0, 6, 3, 1
+_conv_mma = int(os.environ.get("MOTIF_CONV_MMA", "0"))
 
-    def __init__(self, weight, bias, stride=1, pad=0, dil=1, groups=1, pad_mode=0):
+
+def set_conv_mma(mode):
+    """Select the arithmetic for eligible conv layers (3x3, stride 1, > 32 couts); plans re-pack on the next call."""
+    global _conv_mma
+    if mode not in (MMA_FP32, MMA_BF16X3, MMA_BF16X2, MMA_BF16):
+        raise ValueError("conv mma mode must be 0, 6, 3 or 1")
+    _conv_mma = mode
+
+
+def get_conv_mma():
+    return _conv_mma
+
+
+class ConvPlan:
+    """Packed weights of one convolution layer, re-packed when the parameter (or the mma mode) changes."""
+
+    def __init__(self, weight, bias, stride=1, pad=0, dil=1, groups=1, pad_mode=0, mma=None):
         self.weight, self.bias = weight, bias
         self.stride, self.pad, self.dil, self.groups, self.pad_mode = stride, pad, dil, groups, pad_mode
+        self.mma = mma                     # None: follow set_conv_mma()
         self._packed = None
         self._key = None
 
@@ -53,11 +72,12 @@ class ConvPlan:
         d.N, d.H, d.W, d.C0, d.C1 = n, h, w, c0, c1
         d.Cout, d.KH, d.KW = co, kh, kw
         d.stride, d.pad, d.dil, d.groups, d.pad_mode = self.stride, self.pad, self.dil, self.groups, self.pad_mode
+        d.mma = _conv_mma if self.mma is None else self.mma
         return d
 
     def packed(self):
         w = self.weight
-        key = (w.data_ptr(), w._version, w.device)
+        key = (w.data_ptr(), w._version, w.device, _conv_mma if self.mma is None else self.mma)
         if self._key != key:
             lib = _lib.load()
             d = self.desc(1, 64, 64, w.shape[1] * self.groups)
@@ -184,7 +204,7 @@ class DcnPlan:
     def plan3x3(self):
         """The weight as an ordinary 3x3 conv plan (K order (channel pair, tap, half)) for the fused DCN kernel."""
         if getattr(self, "_p3", None) is None or self._p3.weight is not self.weight:
-            self._p3 = ConvPlan(self.weight, self.bias, 1, 1, 1, 1, 0)
+            self._p3 = ConvPlan(self.weight, self.bias, 1, 1, 1, 1, 0, mma=MMA_FP32)   # fused DCN reads the fp32 format
         return self._p3
 
     def plan(self):

@@ -105,6 +105,75 @@ def test_conv2d_fused_epilogues_and_concat():
     assert float(outbuf[:, :10].abs().max()) == 0 and float(outbuf[:, 90:].abs().max()) == 0
 
 
+SPLIT_CASES = [  # cin, cout, groups, pad_mode, H, W, N, two-source split (0 = single input)
+    (64, 64, 1, "zeros", 45, 80, 2, 0),
+    (128, 64, 1, "zeros", 23, 37, 1, 64),     # concat of two sources, ragged tile edges
+    (64, 216, 1, "zeros", 20, 36, 1, 0),      # partial cout group (216 = 3*64 + 24)
+    (48, 96, 1, "reflect", 19, 33, 1, 0),     # 3 channel chunks, reflect padding
+    (40, 80, 2, "zeros", 17, 40, 2, 0),       # groups: 20 -> 32 padded channels per group, 40 couts per group
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_conv_split_engine_is_fp32_equivalent(case):
+    """mma=6 (3-way bf16 split, 6 products on the bf16 matrix cores) against an fp64 convolution: its error must
+    not exceed the fp32-MFMA engine's; mma=3 / mma=1 keep 16 / 8 mantissa bits."""
+    from motif_amd import ops
+    from motif_amd.models.modules.layers import Conv2d
+    cin, cout, groups, pm, H, W, N, c0 = case
+    m = Conv2d(cin, cout, 3, 1, 1, 1, groups, True, pm)
+    with torch.no_grad():
+        m.weight.copy_(rnd(*m.weight.shape, seed=1, scale=1.0 / math.sqrt(cin * 9 / groups)))
+        m.bias.copy_(rnd(cout, seed=2, scale=0.1))
+    x = rnd(N, cin, H, W, seed=3)
+    res = rnd(N, cout, H, W, seed=4)
+    xp = F.pad(x.double(), (1,) * 4, mode="reflect") if pm == "reflect" else x.double()
+    ref = F.leaky_relu(F.conv2d(xp, m.weight.double(), m.bias.double(), 1, 0 if pm == "reflect" else 1, 1, groups) + res.double(), 0.1)
+    m = m.to(dev())
+    xd, rd = x.to(dev()), res.to(dev())
+    args = (xd[:, :c0].contiguous(), xd[:, c0:].contiguous()) if c0 else (xd, None)
+    err = {}
+    try:
+        for mode in (ops.MMA_FP32, ops.MMA_BF16X3, ops.MMA_BF16X2, ops.MMA_BF16):
+            ops.set_conv_mma(mode)
+            out = m(*args, act=ops.ACT_LRELU, res=rd, res_mode=1)
+            err[mode] = float((out.double().cpu() - ref).abs().max())
+    finally:
+        ops.set_conv_mma(ops.MMA_FP32)
+    scale = float(ref.abs().max())
+    assert err[ops.MMA_FP32] < 2e-6 * scale, err
+    assert err[ops.MMA_BF16X3] <= 1.25 * err[ops.MMA_FP32] + 1e-7 * scale, err
+    assert err[ops.MMA_BF16X2] < 1e-4 * scale, err
+    assert 1e-4 * scale < err[ops.MMA_BF16] < 3e-2 * scale, err      # really ran in bf16
+
+
+def test_conv_split_multi_problem_and_views():
+    from motif_amd import ops
+    from motif_amd.models.modules.layers import Conv2d
+    ms = [Conv2d(64, 64, 3, 1, 1) for _ in range(3)]
+    xs = [rnd(2, 64, 21, 50, seed=10 + i) for i in range(3)]
+    with torch.no_grad():
+        for i, m in enumerate(ms):
+            m.weight.copy_(rnd(64, 64, 3, 3, seed=20 + i, scale=0.04))
+            m.bias.copy_(rnd(64, seed=30 + i, scale=0.1))
+    refs = [F.relu(F.conv2d(x, m.weight, m.bias, 1, 1)) for m, x in zip(ms, xs)]
+    ms = [m.to(dev()) for m in ms]
+    try:
+        ops.set_conv_mma(ops.MMA_BF16X3)
+        out = ops.conv2d_multi([m.plan() for m in ms], [x.to(dev()) for x in xs], act=ops.ACT_RELU)
+        for i in range(3):
+            close(out[i], refs[i], 2e-5, 2e-5, "split multi %d" % i)
+        big = torch.zeros(2, 2, 64, 21, 50, device=dev())
+        big[:, 1] = xs[0].to(dev())
+        buf = torch.zeros(2, 80, 21, 50, device=dev())
+        ms[0](big[:, 1], out=buf[:, 8:72], act=ops.ACT_RELU)
+        close(buf[:, 8:72], refs[0], 2e-5, 2e-5, "split strided views")
+        assert float(buf[:, :8].abs().max()) == 0 and float(buf[:, 72:].abs().max()) == 0
+    finally:
+        ops.set_conv_mma(ops.MMA_FP32)
+
+
+
 # ------------------------------------------------------------------------------------------- DCNv2
 def test_dcn_matches_kernel_text_restatement():
     from oracle import native

@@ -18,6 +18,8 @@ SHAPES = [  # N, Cin, Cout, k, stride, H, W
 def main():
     reps = int(os.environ.get("REPS", "20"))
     only = os.environ.get("ONLY")
+    from motif_amd import ops
+    print("conv mma mode", ops.get_conv_mma())
     for i, (n, ci, co, k, s, h, w) in enumerate(SHAPES):
         if only is not None and int(only) != i:
             continue
