@@ -71,9 +71,15 @@ int motif_splat_motif_fwd(const float* imnet_out, const float* pred, const float
 long motif_siren_pack(const float* const* w, const float* const* b, const int* dims, int n_layers,
                       float* packed, void* stream);
 
+/* The same three networks (mode 0 imnet 66-64-64-256-64, 1 flow_imnet 67-64-64-256-3, 2 synth_net
+ * 198-64-64-64-256-3) packed for the bf16 matrix cores: every weight split into three bf16 parts (fp32-equivalent,
+ * see MotifConvDesc.mma = 6), stored as MFMA fragments.  Pass the blob with pre = 2.  Size query with packed = NULL. */
+long motif_siren_pack_split(int mode, const float* const* w, const float* const* b, float* packed, void* stream);
+
 /* `pre` (all three): 0 = `*_lr` holds the raw LR feature (64 ch) and the whole first layer runs per HR pixel;
  * 1 = `*_lr` holds the LR-resolution partial pre-activation W0[:, gathered 64 channels] . feature + b0 (a 1x1
- * convolution done once per clip -- it depends neither on the HR pixel nor on t), which seeds the accumulator.
+ * convolution done once per clip -- it depends neither on the HR pixel nor on t), which seeds the accumulator;
+ * 2 = as 1, with `packed` from motif_siren_pack_split: the contractions run as 6 bf16 products per fp32 MAC.
  * imnet: in = [feat_lr[d*B+b](64 gathered) | rel_y | rel_x] -> out [2B,64,Q] planar. */
 int motif_siren_imnet_fwd(const float* packed, const float* feat_lr, const int32_t* iy, const int32_t* ix,
                           const float* rel_y, const float* rel_x, float* out,

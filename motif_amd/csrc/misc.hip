@@ -1,14 +1,10 @@
 // Resampling, normalisation and gate kernels of the MoTIF path (gfx950).  All are HBM/L2-bound
 // streaming kernels: one element per thread, lanes along x so every access is coalesced.
 #include "common.h"
+#include <stdint.h>
 
 // ------------------------------------------------------------------ F.interpolate(bilinear)
-__global__ void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int Ho, int Wo,
-                                       float sh, float sw, int align, float mul) {
-    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
-    const int oy = blockIdx.y;
-    const long nc = blockIdx.z;
-    if (ox >= Wo) return;
+__device__ __forceinline__ float resize_sample(const float* __restrict__ p, int H, int W, int oy, int ox, float sh, float sw, int align) {
     float sy, sx;
     if (align) { sy = sh * oy; sx = sw * ox; }
     else {
@@ -18,10 +14,28 @@ __global__ void resize_bilinear_kernel(const float* __restrict__ in, float* __re
     const int y0 = (int)sy, x0 = (int)sx;
     const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
     const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    return hy * (hx * p[(long)y0 * W + x0] + lx * p[(long)y0 * W + x1]) +
+           ly * (hx * p[(long)y1 * W + x0] + lx * p[(long)y1 * W + x1]);
+}
+
+// one thread = VEC consecutive outputs of a row (16-byte stores when VEC = 4); block = 64 x 4 threads
+template <int VEC>
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                                               int Ho, int Wo, float sh, float sw, int align, float mul) {
+    const int ox = (blockIdx.x * 64 + threadIdx.x) * VEC;
+    const int oy = blockIdx.y * 4 + threadIdx.y;
+    const long nc = blockIdx.z;
+    if (ox >= Wo || oy >= Ho) return;
     const float* p = in + nc * (long)H * W;
-    const float v = hy * (hx * p[(long)y0 * W + x0] + lx * p[(long)y0 * W + x1]) +
-                    ly * (hx * p[(long)y1 * W + x0] + lx * p[(long)y1 * W + x1]);
-    out[nc * (long)Ho * Wo + (long)oy * Wo + ox] = v * mul;
+    float* o = out + nc * (long)Ho * Wo + (long)oy * Wo + ox;
+    if constexpr (VEC == 4) {
+        f32x4 v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = resize_sample(p, H, W, oy, ox + u, sh, sw, align) * mul;
+        *(f32x4*)o = v;
+    } else {
+        *o = resize_sample(p, H, W, oy, ox, sh, sw, align) * mul;
+    }
 }
 
 extern "C" int motif_resize_bilinear(const float* in, float* out, int NC, int H, int W, int Ho, int Wo,
@@ -30,8 +44,14 @@ extern "C" int motif_resize_bilinear(const float* in, float* out, int NC, int H,
     float sh, sw;
     if (align_corners) { sh = Ho > 1 ? (float)(H - 1) / (Ho - 1) : 0.f; sw = Wo > 1 ? (float)(W - 1) / (Wo - 1) : 0.f; }
     else { sh = (float)H / Ho; sw = (float)W / Wo; }
-    dim3 grid(cdiv(Wo, 256), Ho, NC);
-    resize_bilinear_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(in, out, H, W, Ho, Wo, sh, sw, align_corners, mul);
+    const dim3 block(64, 4);
+    if (Wo % 4 == 0 && ((uintptr_t)out & 15) == 0) {
+        dim3 grid(cdiv(Wo, 256), cdiv(Ho, 4), NC);
+        resize_bilinear_kernel<4><<<grid, block, 0, (hipStream_t)stream>>>(in, out, H, W, Ho, Wo, sh, sw, align_corners, mul);
+    } else {
+        dim3 grid(cdiv(Wo, 64), cdiv(Ho, 4), NC);
+        resize_bilinear_kernel<1><<<grid, block, 0, (hipStream_t)stream>>>(in, out, H, W, Ho, Wo, sh, sw, align_corners, mul);
+    }
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

@@ -13,61 +13,7 @@
 // straight into B-operand form (nearest gather of LR features, coordinate tables, splat accumulator
 // with the post-splat normalisation), and narrow heads (256 -> 3) run on the VALU, which has the same
 // fp32 rate as the f32 MFMA and no 32-row padding.
-#include "common.h"
-#include <stdlib.h>
-
-#define SIREN_THREADS 512
-#define SIREN_WAVES (SIREN_THREADS / 64)
-#ifndef SIREN_TP_IMNET
-#define SIREN_TP_IMNET 1
-#endif
-#ifndef SIREN_TP_FLOW
-#define SIREN_TP_FLOW 2
-#endif
-#ifndef SIREN_TP_SYNTH
-#define SIREN_TP_SYNTH 1
-#endif
-
-// ---------------------------------------------------------------- sin(x)
-// Default: 2-term FMA Cody-Waite reduction by 2*pi, then the hardware v_sin_f32 on the small remainder.
-// Measured on MI355X against fp64 (tools/ubench_sin.hip): max abs error 3.8e-7 for |x| <= 300, independent
-// of the range (v_sin_f32 on the unreduced argument: 2.7e-6 at |x|<=30, 2.4e-5 at 300; ocml sinf 7e-8).
-// -DMOTIF_SIN_PRECISE selects a pi/2 reduction + cephes polynomials (1.2e-7) at ~4x the VALU cost.
-__device__ __forceinline__ float sin_cw(float x) {
-#ifndef MOTIF_SIN_PRECISE
-    // branch-free for every finite x: the fma keeps j*2pi_hi exact, so the reduction error is ~|j|*1e-14 and the
-    // result degrades only with the spacing of x itself; inf/nan give nan.
-    const float j = rintf(x * 0.15915494309189535f);
-    float r = fmaf(j, -6.2831854820251465f, x);
-    r = fmaf(j, 1.7484555e-7f, r);                       // -(2*pi - float(2*pi))
-    return __builtin_amdgcn_sinf(r * 0.15915494309189535f);
-#else
-    float r;
-    int q;
-    if (__builtin_expect(fabsf(x) <= 3.0e4f, 1)) {
-        const float j = rintf(x * 0.636619772367581343f);
-        r = fmaf(j, -1.57079637050628662109375f, x);
-        r = fmaf(j, 4.37113900018624283e-8f, r);
-        q = (int)j;
-    } else {
-        const double xd = (double)x;
-        const double j = rint(xd * 0.63661977236758134308);
-        double rd = fma(j, -1.57079632679489655800, xd);
-        rd = fma(j, -6.12323399573676603587e-17, rd);
-        r = (float)rd;
-        q = (int)(j - 4.0 * floor(j * 0.25));
-    }
-    const float z = r * r;
-    const float sp = r + r * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
-    const float cp = 1.0f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
-    float v = (q & 1) ? cp : sp;
-    return (q & 2) ? -v : v;
-#endif
-}
-
-__host__ __device__ constexpr int kmap(int s, int hf) { return 8 * (s >> 2) + 4 * hf + (s & 3); }
-__host__ __device__ constexpr int pad8(int k) { return (k + 7) & ~7; }
-__host__ __device__ constexpr int pad32(int m) { return (m + 31) & ~31; }
+#include "siren_common.h"
 
 // packed blob layout per MFMA layer: Wp[KS][MT][64] then Bp[MT][16][2]; per VALU head: Wv[M][KQ][2][4], bias[M] (padded to 4)
 __host__ __device__ constexpr long mfma_layer_floats(int K, int M) { return (long)(pad8(K) / 2) * (pad32(M) / 32) * 64 + (long)(pad32(M) / 32) * 32; }
@@ -116,43 +62,6 @@ __device__ __forceinline__ void sine(const f32x16 (&acc)[TP][MT], float (&h)[TP]
                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep at most 4 sin pipelines live
             }
 }
-
-// VALU head partial: M outputs, inputs hc[32] are the k-steps [s0, s0+32) of a K-wide layer
-template <int M, int KQ, int TP>
-__device__ __forceinline__ void valu_head_partial(const float (&hc)[TP][32], float (&sum)[TP][M], const float* wv, int q0, int hf) {
-#pragma unroll
-    for (int o = 0; o < M; ++o)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const f32x4 w = *(const f32x4*)(wv + ((o * KQ + q0 + q) * 2 + hf) * 4);
-#pragma unroll
-            for (int p = 0; p < TP; ++p) {
-                sum[p][o] = fmaf(w[0], hc[p][q * 4 + 0], sum[p][o]);
-                sum[p][o] = fmaf(w[1], hc[p][q * 4 + 1], sum[p][o]);
-                sum[p][o] = fmaf(w[2], hc[p][q * 4 + 2], sum[p][o]);
-                sum[p][o] = fmaf(w[3], hc[p][q * 4 + 3], sum[p][o]);
-            }
-        }
-}
-
-struct SirenArgs {
-    const float* packed;
-    const float* src_lr;      // LR feature stack [imgs_lr, 64, H, W] to gather from
-    const float* acc;         // synth: splat accumulator [B*N,133,Q]
-    const int32_t* iy; const int32_t* ix;
-    const float* rel_y; const float* rel_x;
-    const float* times;       // [B*N]
-    float* out;
-    int NB, N, B, H, W, HH, WW;   // NB = number of HR images processed
-    int stagger;                  // start offset of the second wave per SIMD, in s_sleep(127) units (~8k cycles)
-};
-
-enum { MODE_IMNET = 0, MODE_FLOW = 1, MODE_SYNTH = 2 };
-
-template <int MODE> struct Net;
-template <> struct Net<MODE_IMNET> { static constexpr int K0 = 66, NH = 3, HEAD = 64; };
-template <> struct Net<MODE_FLOW>  { static constexpr int K0 = 67, NH = 3, HEAD = 3; };
-template <> struct Net<MODE_SYNTH> { static constexpr int K0 = 198, NH = 4, HEAD = 3; };
 
 // offsets (floats) of each layer inside the packed blob
 template <int MODE> struct Layout {
@@ -570,6 +479,7 @@ extern "C" int motif_siren_imnet_fwd(const float* packed, const float* feat_lr, 
                                      int B2, int H, int W, int HH, int WW, int pre, void* stream) {
     if (!packed || !feat_lr || !iy || !ix || !rel_y || !rel_x || !out || B2 < 1) return MOTIF_EINVAL;
     SirenArgs a{packed, feat_lr, nullptr, iy, ix, rel_y, rel_x, nullptr, out, B2, 1, B2, H, W, HH, WW};
+    if (pre == 2) return motif_siren_split_launch(MODE_IMNET, a, stream);
     return pre ? launch_siren<MODE_IMNET, SIREN_TP_IMNET, true>(a, stream) : launch_siren<MODE_IMNET, SIREN_TP_IMNET, false>(a, stream);
 }
 
@@ -578,6 +488,7 @@ extern "C" int motif_siren_flow_fwd(const float* packed, const float* flowfeat_l
                                     int B2, int N, int H, int W, int HH, int WW, int pre, void* stream) {
     if (!packed || !flowfeat_lr || !iy || !ix || !rel_y || !rel_x || !times || !pred || B2 < 2 || (B2 & 1) || N < 1) return MOTIF_EINVAL;
     SirenArgs a{packed, flowfeat_lr, nullptr, iy, ix, rel_y, rel_x, times, pred, B2 * N, N, B2 / 2, H, W, HH, WW};
+    if (pre == 2) return motif_siren_split_launch(MODE_FLOW, a, stream);
     return pre ? launch_siren<MODE_FLOW, SIREN_TP_FLOW, true>(a, stream) : launch_siren<MODE_FLOW, SIREN_TP_FLOW, false>(a, stream);
 }
 
@@ -586,6 +497,7 @@ extern "C" int motif_siren_synth_fwd(const float* packed, const float* acc, cons
                                      int B, int N, int H, int W, int HH, int WW, int pre, void* stream) {
     if (!packed || !acc || !residual_lr || !iy || !ix || !times || !frames || B < 1 || N < 1) return MOTIF_EINVAL;
     SirenArgs a{packed, residual_lr, acc, iy, ix, nullptr, nullptr, times, frames, B * N, N, B, H, W, HH, WW};
+    if (pre == 2) return motif_siren_split_launch(MODE_SYNTH, a, stream);
     return pre ? launch_siren<MODE_SYNTH, SIREN_TP_SYNTH, true>(a, stream) : launch_siren<MODE_SYNTH, SIREN_TP_SYNTH, false>(a, stream);
 }
 

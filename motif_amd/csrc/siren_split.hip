@@ -1,0 +1,630 @@
+// The three SIREN MLPs on the bf16 matrix cores with fp32-equivalent arithmetic (3-way bf16 split, 6 products,
+// fp32 accumulate -- see conv_split.hip for the arithmetic), register-chained like siren.hip.
+//
+// v_mfma_f32_32x32x16_bf16: lane (p = lane&31, hf = lane>>5) supplies 8 consecutive-k bf16 values of pixel p; the
+// C/D layout is the fp32 one (row m = 32t + (r&3) + 8(r>>2) + 4hf in register r of output tile t).  Registers
+// r = 8u..8u+7 of tile t, split into three packed-bf16 quads, ARE the B fragments of k-step (t,u) of the next layer;
+// the packing permutes each layer's K order to match:  k(t,u,hf,e) = 32t + (e&3) + 8(2u + (e>>2)) + 4hf.
+// The first layer's LR part comes precomputed (pre=1: a 1x1 conv at LR resolution seeds the accumulator), its
+// remaining inputs (coordinates, t, normalised splat accumulator) are split on the fly in natural K order.
+// The sine and the splitting run on the VALU while the other wave of the SIMD is in its MFMA stretch (bf16 MFMAs,
+// unlike the fp32 ones, do not occupy the vector ALU).  Heads that are 3 wide stay on the VALU in fp32.
+// Weights: split at pack time into A fragments [k-step][part][out tile][lane] x 8 bf16, resident in LDS (flow
+// 133 KB, imnet 131 KB + head streamed from L2, synth 152 KB + first layer streamed from L2).
+#include "siren_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int PW[6] = {2, 0, 1, 1, 0, 0};      // (weight part, activation part) of the six products, small terms first
+constexpr int PX[6] = {0, 2, 1, 0, 1, 0};
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    bf16x2 p = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ float bf_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[3]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float x0 = v[2 * q], x1 = v[2 * q + 1];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned pk = pk_bf16(x0, x1);
+            out[p][q] = pk;
+            if (p < 2) { x0 -= bf_lo(pk); x1 -= bf_hi(pk); }
+        }
+    }
+}
+
+// sin(x), x = 30 * pre-activation already rounded to fp32 like the reference's `omega_0 * linear(x)`:
+// x / 2pi - rint(x / 2pi) through two FMAs (1/2pi = hi + lo), then the hardware sine (argument in revolutions).
+// Reduction error < 2e-7 for |x| <= 300 (same bound as sin_cw, one multiply less).
+__device__ __forceinline__ float sin_rev(float x) {
+    const float j = rintf(x * 0.15915494f);
+    float r = fmaf(x, 0.15915494f, -j);
+    r = fmaf(x, 6.4206382e-09f, r);
+    return __builtin_amdgcn_sinf(r);
+}
+
+template <int MODE> struct SLayout {
+    static constexpr int KS0 = (MODE == MODE_SYNTH) ? 9 : 1;
+    // fragment section, in u32x4 (16-byte) units: layer = [KS][3 parts][MT][64 lanes]
+    static constexpr long F_W0 = 0;
+    static constexpr long F_W1 = F_W0 + (long)KS0 * 3 * 2 * 64;
+    static constexpr long F_W1B = F_W1 + 4L * 3 * 2 * 64;
+    static constexpr long F_W2 = F_W1B + (MODE == MODE_SYNTH ? 4L * 3 * 2 * 64 : 0);
+    static constexpr long F_W3 = F_W2 + 4L * 3 * 8 * 64;
+    static constexpr long F_END = F_W3 + (MODE == MODE_IMNET ? 16L * 3 * 2 * 64 : 0);
+    // float section (after the fragments): B1, [B1b], B2, then B3 (imnet) or the fp32 VALU head Wv[3][32][2][4] + bias[4]
+    static constexpr int O_B1 = 0;
+    static constexpr int O_B1B = 64;
+    static constexpr int O_B2 = O_B1B + (MODE == MODE_SYNTH ? 64 : 0);
+    static constexpr int O_HEAD = O_B2 + 256;
+    static constexpr int NFLOATS = O_HEAD + (MODE == MODE_IMNET ? 64 : 3 * 32 * 8 + 4);
+    // LDS residency: synth streams its first layer, imnet its head, from L2
+    static constexpr long LDS_F0 = (MODE == MODE_SYNTH) ? F_W1 : 0;
+    static constexpr long LDS_F1 = (MODE == MODE_IMNET) ? F_W3 : F_END;
+    static constexpr long LDS_BYTES = (LDS_F1 - LDS_F0) * 16 + (long)NFLOATS * 4;
+    static constexpr long TOTAL_FLOATS = F_END * 4 + NFLOATS;
+};
+
+template <int TP, int MT>
+__device__ __forceinline__ void init_bias_s(f32x16 (&acc)[TP][MT], const float* bp, int hf) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float b = bp[(t * 16 + r) * 2 + hf];
+#pragma unroll
+            for (int p = 0; p < TP; ++p) acc[p][t][r] = b;
+        }
+}
+
+// weight fragments of one k-step for MT output tiles: wk[(part * MTW + t0 + t) * 64]
+template <int MT, int MTW>
+__device__ __forceinline__ void load_w(u32x4 (&w)[MT][3], const u32x4* wk, int t0) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int part = 0; part < 3; ++part) w[t][part] = wk[(part * MTW + t0 + t) * 64];
+}
+
+// one k-step.  Products outermost so that consecutive MFMAs go to different accumulators.
+template <int MT, int TP>
+__device__ __forceinline__ void mfma_step(const u32x4 (&w)[MT][3], const u32x4 (&x)[TP][3], f32x16 (&acc)[TP][MT]) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int p = 0; p < TP; ++p)
+                acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t][PW[k]]),
+                                                                     __builtin_bit_cast(bf16x8, x[p][PX[k]]), acc[p][t], 0, 0, 0);
+}
+
+template <int MT, int MTW, int TP>
+__device__ __forceinline__ void split_step(const u32x4 (&x)[TP][3], f32x16 (&acc)[TP][MT], const u32x4* wk, int t0) {
+    u32x4 w[MT][3];
+    load_w<MT, MTW>(w, wk, t0);
+    mfma_step<MT, TP>(w, x, acc);
+}
+
+// KS k-steps; `wfirst` holds the fragments of k-step 0 (requested by the caller before the preceding sine stretch),
+// the fragments of k-step ks+1 are requested before the MFMAs of k-step ks
+template <int KS, int MT, int MTW, int TP>
+__device__ __forceinline__ void split_layer(const u32x4 (&h)[TP][KS][3], f32x16 (&acc)[TP][MT], const u32x4* wp, int t0,
+                                            const u32x4 (&wfirst)[MT][3]) {
+    u32x4 w[2][MT][3];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int part = 0; part < 3; ++part) w[0][t][part] = wfirst[t][part];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) load_w<MT, MTW>(w[(ks + 1) & 1], wp + (long)(ks + 1) * 3 * MTW * 64, t0);
+        u32x4 hx[TP][3];
+#pragma unroll
+        for (int p = 0; p < TP; ++p)
+#pragma unroll
+            for (int part = 0; part < 3; ++part) hx[p][part] = h[p][ks][part];
+        mfma_step<MT, TP>(w[ks & 1], hx, acc);
+    }
+}
+
+// h[p][2t+u] = split(sin(30 * acc[p][t][8u .. 8u+7]))
+template <int TP, int MT>
+__device__ __forceinline__ void sine_split(const f32x16 (&acc)[TP][MT], u32x4 (&h)[TP][2 * MT][3]) {
+#pragma unroll
+    for (int p = 0; p < TP; ++p)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = sin_rev(30.0f * acc[p][t][8 * u + e]);
+                split8(v, h[p][2 * t + u]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+}
+
+#ifdef MOTIF_SIREN_DBG
+template <int TP, int MT>
+__device__ __forceinline__ void fake_split(const f32x16 (&acc)[TP][MT], u32x4 (&h)[TP][2 * MT][3]) {
+#pragma unroll
+    for (int p = 0; p < TP; ++p)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int part = 0; part < 3; ++part)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) h[p][2 * t + u][part][q] = __builtin_bit_cast(unsigned, acc[p][t][8 * u + 2 * q + (part & 1)]);
+}
+template <int TP, int MT>
+__device__ __forceinline__ void fake_f32(const f32x16 (&acc)[TP][MT], float (&h)[TP][MT * 16]) {
+#pragma unroll
+    for (int p = 0; p < TP; ++p)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[p][t * 16 + r] = acc[p][t][r];
+}
+#endif
+
+template <int TP, int MT>
+__device__ __forceinline__ void sine_f32(const f32x16 (&acc)[TP][MT], float (&h)[TP][MT * 16]) {
+#pragma unroll
+    for (int p = 0; p < TP; ++p)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                h[p][t * 16 + r] = sin_rev(30.0f * acc[p][t][r]);
+            }
+}
+}  // namespace
+
+#ifdef MOTIF_TRACE
+__device__ long long g_strace[256 * 8 * 16];
+extern "C" int motif_debug_siren_trace(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_strace), sizeof(long long) * n); }
+#define PH(i) do { const long long now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define PH(i)
+#endif
+
+template <int MODE, int TP>
+__global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void siren_split_kernel(SirenArgs a) {
+#ifdef MOTIF_TRACE
+    long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = __builtin_amdgcn_s_memtime();
+#endif
+    extern __shared__ __attribute__((aligned(16))) u32x4 ldsv[];
+    using L = SLayout<MODE>;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+    const u32x4* gfr = (const u32x4*)a.packed;
+    float* ldsf0 = (float*)(ldsv + (L::LDS_F1 - L::LDS_F0));
+    {
+        for (long i = tid; i < L::LDS_F1 - L::LDS_F0; i += SIREN_THREADS) ldsv[i] = gfr[L::LDS_F0 + i];
+        const float* gfl = (const float*)(gfr + L::F_END);
+        for (int i = tid; i < L::NFLOATS; i += SIREN_THREADS) ldsf0[i] = gfl[i];
+    }
+    __syncthreads();
+    // start the second wave of every SIMD late so that one is in its sine/split (VALU) stretch while the other
+    // issues MFMAs
+    if (wave >= SIREN_WAVES / 2) {
+        const int naps = a.stagger & 255;
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#ifdef MOTIF_SIREN_DBG
+    const int grp = wave >= SIREN_WAVES / 2;
+    const bool skipV = (a.stagger >> (8 + grp)) & 1, skipM = (a.stagger >> (10 + grp)) & 1;
+#define DBG_V(stmt_real, stmt_skip) do { if (skipV) { stmt_skip; } else { stmt_real; } } while (0)
+#define DBG_M(stmt) do { if (!skipM) { stmt; } } while (0)
+#else
+#define DBG_V(stmt_real, stmt_skip) do { stmt_real; } while (0)
+#define DBG_M(stmt) do { stmt; } while (0)
+#endif
+    const u32x4* lw1_0 = ldsv + (L::F_W1 - L::LDS_F0) + lane;
+    const u32x4* lw1b_0 = ldsv + (L::F_W1B - L::LDS_F0) + lane;
+    const u32x4* lw2_0 = ldsv + (L::F_W2 - L::LDS_F0) + lane;
+    const u32x4* w0 = (MODE == MODE_SYNTH ? gfr + L::F_W0 : ldsv + (L::F_W0 - L::LDS_F0)) + lane;
+
+    const long Q = (long)a.HH * a.WW;
+    const long HWl = (long)a.H * a.W;
+    const int tiles_per_img = (int)((Q + 32 * TP - 1) / (32 * TP));
+    const long total = (long)a.NB * tiles_per_img;
+
+    for (long work = (long)blockIdx.x * SIREN_WAVES + wave; work < total; work += (long)gridDim.x * SIREN_WAVES) {
+        // LDS contents never change after the staging barrier, so the compiler would hoist bias / head-weight reads out
+        // of this loop and spill them; an opaque zero offset per iteration keeps them where they are used
+        int lds_o = 0;
+        asm volatile("" : "+s"(lds_o));
+        const float* ldsf = ldsf0 + lds_o;
+        const u32x4* lw1 = lw1_0 + lds_o;
+        const u32x4* lw1b = lw1b_0 + lds_o;
+        const u32x4* lw2 = lw2_0 + lds_o;
+        const int img = (int)(work / tiles_per_img);
+        const long pbase = (long)(work % tiles_per_img) * (32 * TP) + l31;
+        long pp[TP], pc[TP], lr[TP];
+        int Y[TP], X[TP];
+        bool valid[TP];
+#pragma unroll
+        for (int p = 0; p < TP; ++p) {
+            pp[p] = pbase + 32 * p;
+            valid[p] = pp[p] < Q;
+            pc[p] = valid[p] ? pp[p] : Q - 1;
+            Y[p] = (int)(pc[p] / a.WW);
+            X[p] = (int)(pc[p] - (long)Y[p] * a.WW);
+            lr[p] = (long)a.iy[Y[p]] * a.W + a.ix[X[p]];
+        }
+
+        PH(0);                                               // tile bookkeeping
+        // ------------------------------------------------ layer 0: LR partial seeds the accumulator
+        f32x16 acc0[TP][2];
+        {
+            const int ilr = (MODE == MODE_FLOW || MODE == MODE_SYNTH) ? img / a.N : img;
+#pragma unroll
+            for (int p = 0; p < TP; ++p) {
+                const float* gp = a.src_lr + (long)ilr * 64 * HWl + lr[p] + (long)(4 * hf) * HWl;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc0[p][t][r] = gp[(long)(32 * t + (r & 3) + 8 * (r >> 2)) * HWl];
+            }
+        }
+        if constexpr (MODE == MODE_IMNET || MODE == MODE_FLOW) {
+            // natural K order: imnet k0 = rel_y, k1 = rel_x; flow k0 = t, k1 = rel_y, k2 = rel_x (lower half-wave)
+            u32x4 x[TP][3];
+#pragma unroll
+            for (int p = 0; p < TP; ++p) {
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if constexpr (MODE == MODE_FLOW) { v[0] = a.times[img % (a.B * a.N)]; v[1] = a.rel_y[Y[p]]; v[2] = a.rel_x[X[p]]; }
+                else { v[0] = a.rel_y[Y[p]]; v[1] = a.rel_x[X[p]]; }
+                if (hf) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; }
+                split8(v, x[p]);
+            }
+            split_step<2, 2, TP>(x, acc0, w0, 0);
+        } else {
+            // synth, natural K order: k < 130 sum/wz; 130 zmax; 131 cnt/16; 132 wz_/cnt_; 133 t; 134..143 zero
+            const float tval = a.times[img];
+            const float* A[TP];
+            float wz[TP], cnt[TP], cnt_[TP], wz_[TP];
+#pragma unroll
+            for (int p = 0; p < TP; ++p) {
+                A[p] = a.acc + (long)img * 133 * Q + pc[p];
+                wz[p] = A[p][130 * Q];
+                cnt[p] = A[p][132 * Q];
+                if (wz[p] == 0.f) wz[p] = 1.0f;                           // Ours.py:813
+                cnt_[p] = (cnt[p] == 0.f) ? 1.0f : cnt[p];                // Ours.py:828
+                wz_[p] = (wz[p] == 1.0f) ? 0.f : wz[p];                   // Ours.py:830
+            }
+            const float* ap[TP];
+            float v[TP][8];
+#pragma unroll
+            for (int p = 0; p < TP; ++p) {
+                ap[p] = A[p] + (long)(8 * hf) * Q;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[p][e] = ap[p][(long)e * Q];
+            }
+#pragma unroll 1
+            for (int ks = 0; ks < 8; ++ks) {         // k = 16ks + 8hf + e < 128: accumulator planes, next step's loads in flight
+                float vn[TP][8];
+#pragma unroll
+                for (int p = 0; p < TP; ++p) {
+                    ap[p] += 16 * Q;
+                    if (ks < 7) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) vn[p][e] = ap[p][(long)e * Q];
+                    }
+                }
+                u32x4 x[TP][3];
+#pragma unroll
+                for (int p = 0; p < TP; ++p) {
+                    float d[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d[e] = v[p][e] / wz[p];
+                    split8(d, x[p]);
+                }
+                split_step<2, 2, TP>(x, acc0, w0 + (long)ks * 3 * 2 * 64, 0);
+#pragma unroll
+                for (int p = 0; p < TP; ++p)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[p][e] = vn[p][e];
+            }
+            {
+                u32x4 x[TP][3];
+#pragma unroll
+                for (int p = 0; p < TP; ++p) {
+                    float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (!hf) {
+                        d[0] = A[p][128 * Q] / wz[p];
+                        d[1] = A[p][129 * Q] / wz[p];
+                        d[2] = A[p][131 * Q];
+                        d[3] = cnt[p] / 16.0f;
+                        d[4] = wz_[p] / cnt_[p];
+                        d[5] = tval;
+                    }
+                    split8(d, x[p]);
+                }
+                split_step<2, 2, TP>(x, acc0, w0 + 8L * 3 * 2 * 64, 0);
+            }
+        }
+        PH(1);                                               // layer 0 (gather + MFMA issue)
+        u32x4 wn[2][3];                                  // first fragments of the next layer, in flight during the sine
+        load_w<2, 2>(wn, lw1, 0);
+        u32x4 h1[TP][4][3];
+        DBG_V(sine_split(acc0, h1), fake_split(acc0, h1));
+
+        PH(2);                                               // sine 1
+        // ------------------------------------------------ 64 -> 64 (x2 for synth)
+        f32x16 acc1[TP][2];
+        init_bias_s(acc1, ldsf + L::O_B1, hf);
+        DBG_M((split_layer<4, 2, 2, TP>(h1, acc1, lw1, 0, wn)));
+        PH(3);                                               // layer 1 MFMAs
+        if constexpr (MODE == MODE_SYNTH) load_w<2, 2>(wn, lw1b, 0); else load_w<2, 8>(wn, lw2, 0);
+        u32x4 h2[TP][4][3];
+        DBG_V(sine_split(acc1, h2), fake_split(acc1, h2));
+        if constexpr (MODE == MODE_SYNTH) {
+            init_bias_s(acc1, ldsf + L::O_B1B, hf);
+            DBG_M((split_layer<4, 2, 2, TP>(h2, acc1, lw1b, 0, wn)));
+            load_w<2, 8>(wn, lw2, 0);
+            DBG_V(sine_split(acc1, h2), fake_split(acc1, h2));
+        }
+
+        PH(4);                                               // sine 2 (+ layer 1b)
+        // ------------------------------------------------ 64 -> 256 in four 64-wide chunks, each fed to the head
+        if constexpr (Net<MODE>::HEAD == 3) {
+            float sum[TP][3];
+#pragma unroll
+            for (int p = 0; p < TP; ++p) sum[p][0] = sum[p][1] = sum[p][2] = 0.f;
+            // software pipeline over the four 64-wide chunks, interleaved by hand: after every MFMA of chunk c+1 (matrix
+            // pipe) comes one unit of chunk c's vector work (a sine, or four head FMAs), so the wave's own VALU
+            // instructions fill the issue slots its MFMAs leave free.  The barriers pin MFMA/VALU order only; LDS
+            // reads (weight fragments, head weights) may be hoisted across them.
+            f32x16 acc2[2][TP][2];
+            init_bias_s(acc2[0], ldsf + L::O_B2, hf);
+            DBG_M((split_layer<4, 2, 8, TP>(h2, acc2[0], lw2, 0, wn)));
+            PH(5);                                           // 64->256 chunk 0 MFMAs
+            const float* headw = ldsf + L::O_HEAD;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float hc[TP][32];
+                auto valu_unit = [&](int u) {                // 32 sines, then 24 x (4 FMAs of one head output)
+                    if (u < 32) {
+#pragma unroll
+                        for (int p = 0; p < TP; ++p) hc[p][u] = sin_rev(30.0f * acc2[c & 1][p][u >> 4][u & 15]);
+                    } else if (u < 56) {
+                        const int q = (u - 32) / 3, o = (u - 32) % 3;
+                        const f32x4 w4 = *(const f32x4*)(headw + ((o * 32 + 8 * c + q) * 2 + hf) * 4);
+#pragma unroll
+                        for (int p = 0; p < TP; ++p) {
+                            sum[p][o] = fmaf(w4[0], hc[p][q * 4 + 0], sum[p][o]);
+                            sum[p][o] = fmaf(w4[1], hc[p][q * 4 + 1], sum[p][o]);
+                            sum[p][o] = fmaf(w4[2], hc[p][q * 4 + 2], sum[p][o]);
+                            sum[p][o] = fmaf(w4[3], hc[p][q * 4 + 3], sum[p][o]);
+                        }
+                    }
+                };
+                int unit = 0;
+                if (c < 3) {
+                    f32x16 (&nxt)[TP][2] = acc2[(c + 1) & 1];
+                    // one set of weight fragments, refilled in place: part PW[k] of the next k-step is requested right
+                    // after its last use in this one (products are ordered so that parts retire 2, 1, 0)
+                    u32x4 w[2][3];
+                    load_w<2, 8>(w, lw2, 2 * c + 2);
+                    init_bias_s(nxt, ldsf + L::O_B2 + (c + 1) * 64, hf);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const u32x4* wnext = lw2 + (long)(ks + 1) * 3 * 8 * 64;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+#pragma unroll
+                            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                                for (int p = 0; p < TP; ++p)
+                                    nxt[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                        __builtin_bit_cast(bf16x8, w[t][PW[k]]), __builtin_bit_cast(bf16x8, h2[p][ks][PX[k]]),
+                                        nxt[p][t], 0, 0, 0);
+                                valu_unit(unit++);
+                                if ((unit & 3) == 0) __builtin_amdgcn_sched_barrier(0);      // bound the LDS-read hoisting
+                                else __builtin_amdgcn_sched_barrier(0x180);                   // only DS instructions may cross
+                            }
+                            if (ks < 3 && (k == 0 || k == 3 || k == 5)) {      // last use of part PW[k]
+#pragma unroll
+                                for (int t = 0; t < 2; ++t) w[t][PW[k]] = wnext[(PW[k] * 8 + 2 * c + 2 + t) * 64];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 56; ++u)
+                    if (u >= unit) valu_unit(u);
+                PH(6);                                       // chunk sine + head (+ next chunk's MFMAs)
+            }
+            const float* hb = ldsf + L::O_HEAD + 3 * 32 * 8;
+#pragma unroll
+            for (int p = 0; p < TP; ++p) {
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    sum[p][o] += __shfl_xor(sum[p][o], 32);
+                    sum[p][o] += hb[o];
+                }
+                if (valid[p] && hf == 0) {
+                    if constexpr (MODE == MODE_FLOW) {
+#pragma unroll
+                        for (int o = 0; o < 3; ++o) a.out[((long)img * 3 + o) * Q + pp[p]] = sum[p][o];
+                    } else {
+                        const int b = img / a.N, n = img % a.N;
+#pragma unroll
+                        for (int o = 0; o < 3; ++o) {
+                            float v = sum[p][o];
+                            v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+                            a.out[(((long)n * a.B + b) * 3 + o) * Q + pp[p]] = v;
+                        }
+                    }
+                }
+            }
+        } else {
+            f32x16 acc3[TP][2];
+            const u32x4* w3g = gfr + L::F_W3 + lane;                    // streamed from L2
+            init_bias_s(acc3, ldsf + L::O_HEAD, hf);
+#pragma unroll 1
+            for (int c = 0; c < 4; ++c) {
+                f32x16 acc2[TP][2];
+                init_bias_s(acc2, ldsf + L::O_B2 + c * 64, hf);
+                split_layer<4, 2, 8, TP>(h2, acc2, lw2, 2 * c, wn);
+                u32x4 w3[2][3];
+                load_w<2, 2>(w3, w3g + (long)c * 4 * 3 * 2 * 64, 0);
+                u32x4 hc[TP][4][3];
+                sine_split(acc2, hc);
+                if (c < 3) load_w<2, 8>(wn, lw2, 2 * c + 2);
+                split_layer<4, 2, 2, TP>(hc, acc3, w3g + (long)c * 4 * 3 * 2 * 64, 0, w3);
+            }
+#pragma unroll
+            for (int p = 0; p < TP; ++p) {
+                if (!valid[p]) continue;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                        a.out[((long)img * 64 + m) * Q + pp[p]] = acc3[p][t][r];
+                    }
+            }
+        }
+        PH(8);                                               // outputs
+    }
+#ifdef MOTIF_TRACE
+    if (lane == 0 && blockIdx.x < 256)
+        for (int i = 0; i < 10; ++i) g_strace[(blockIdx.x * 8 + wave) * 16 + i] = ph[i];
+#endif
+}
+
+// ---------------------------------------------------------------- packing
+// mode 0 imnet (66-64-64-256-64), 1 flow (67-64-64-256-3), 2 synth (198-64-64-64-256-3); w/b: the nn.Linear
+// parameters in network order.
+struct SplitPackArgs { const float* w[5]; const float* b[5]; int mode; };
+
+template <int MODE>
+__device__ void siren_split_pack_elem(const SplitPackArgs& pa, unsigned short* frags, float* floats, long i) {
+    using L = SLayout<MODE>;
+    constexpr int K0 = Net<MODE>::K0;
+    constexpr int NL = (MODE == MODE_SYNTH) ? 5 : 4;                // linear layers incl. the head
+    const long nfrag16 = L::F_END * 8;                              // bf16 elements in the fragment section
+    if (i < nfrag16) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const long f = i >> 9;                                      // fragment index = ((ks*3 + part)*MT + t) within a layer
+        int layer, MT, K, M;
+        long fb;
+        if (f < L::F_W1 / 64) { layer = 0; fb = 0; MT = 2; K = K0; M = 64; }
+        else if (f < L::F_W1B / 64) { layer = 1; fb = L::F_W1 / 64; MT = 2; K = 64; M = 64; }
+        else if (f < L::F_W2 / 64) { layer = 2; fb = L::F_W1B / 64; MT = 2; K = 64; M = 64; }
+        else if (f < L::F_W3 / 64) { layer = NL - 2; fb = L::F_W2 / 64; MT = 8; K = 64; M = 256; }
+        else { layer = NL - 1; fb = L::F_W3 / 64; MT = 2; K = 256; M = 64; }
+        const long fl = f - fb;
+        const int t = (int)(fl % MT), part = (int)((fl / MT) % 3), ks = (int)(fl / (3 * MT));
+        const int hfl = lane >> 5, m = 32 * t + (lane & 31);
+        int k;
+        if (layer == 0) {
+            const int kn = 16 * ks + 8 * hfl + e;                   // natural order of the non-LR inputs
+            if (MODE == MODE_IMNET) k = kn < 2 ? 64 + kn : -1;
+            else if (MODE == MODE_FLOW) k = kn < 3 ? 64 + kn : -1;
+            else k = kn < 133 ? kn : (kn == 133 ? 197 : -1);
+        } else {
+            const int tt = ks >> 1, u = ks & 1;                     // chained order
+            k = 32 * tt + (e & 3) + 8 * (2 * u + (e >> 2)) + 4 * hfl;
+        }
+        float v = (k >= 0 && k < K && m < M) ? pa.w[layer][(long)m * K + k] : 0.f;
+        unsigned short out = 0;
+        for (int p = 0; p <= part; ++p) {
+            const unsigned pk = pk_bf16(v, 0.f);
+            out = (unsigned short)(pk & 0xffffu);
+            v -= bf_lo(pk);
+        }
+        frags[i] = out;
+        return;
+    }
+    const int j = (int)(i - nfrag16);
+    if (j >= L::NFLOATS) return;
+    auto bias_cd = [&](const float* b, int jj, int M) {              // [t][r][hf] order of the C/D layout
+        const int hfl = jj & 1, r = (jj >> 1) & 15, t = jj >> 5;
+        const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hfl;
+        return m < M ? b[m] : 0.f;
+    };
+    float v;
+    if (j < L::O_B1B) v = bias_cd(pa.b[1], j - L::O_B1, 64);
+    else if (j < L::O_B2) v = bias_cd(pa.b[2], j - L::O_B1B, 64);
+    else if (j < L::O_HEAD) v = bias_cd(pa.b[NL - 2], j - L::O_B2, 256);
+    else if (MODE == MODE_IMNET) v = bias_cd(pa.b[NL - 1], j - L::O_HEAD, 64);
+    else {
+        const int jj = j - L::O_HEAD;
+        if (jj < 3 * 32 * 8) {                                      // Wv[o][q][hf][r]: k = 8q + 4hf + r
+            const int r = jj & 3, hfl = (jj >> 2) & 1, q = (jj >> 3) & 31, o = jj >> 8;
+            v = pa.w[NL - 1][(long)o * 256 + 8 * q + 4 * hfl + r];
+        } else {
+            const int o = jj - 3 * 32 * 8;
+            v = o < 3 ? pa.b[NL - 1][o] : 0.f;
+        }
+    }
+    floats[j] = v;
+}
+
+__global__ void siren_split_pack_kernel(SplitPackArgs pa, float* out, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    if (pa.mode == MODE_IMNET) siren_split_pack_elem<MODE_IMNET>(pa, (unsigned short*)out, out + SLayout<MODE_IMNET>::F_END * 4, i);
+    else if (pa.mode == MODE_FLOW) siren_split_pack_elem<MODE_FLOW>(pa, (unsigned short*)out, out + SLayout<MODE_FLOW>::F_END * 4, i);
+    else siren_split_pack_elem<MODE_SYNTH>(pa, (unsigned short*)out, out + SLayout<MODE_SYNTH>::F_END * 4, i);
+}
+
+extern "C" long motif_siren_pack_split(int mode, const float* const* w, const float* const* b, float* packed, void* stream) {
+    if (mode < 0 || mode > 2) return MOTIF_EINVAL;
+    const long floats = mode == MODE_IMNET ? SLayout<MODE_IMNET>::TOTAL_FLOATS
+                      : mode == MODE_FLOW ? SLayout<MODE_FLOW>::TOTAL_FLOATS : SLayout<MODE_SYNTH>::TOTAL_FLOATS;
+    if (!packed) return floats;
+    if (!w || !b) return MOTIF_EINVAL;
+    const int nl = mode == MODE_SYNTH ? 5 : 4;
+    SplitPackArgs pa;
+    for (int l = 0; l < 5; ++l) { pa.w[l] = l < nl ? w[l] : nullptr; pa.b[l] = l < nl ? b[l] : nullptr; }
+    pa.mode = mode;
+    const long fend = mode == MODE_IMNET ? SLayout<MODE_IMNET>::F_END : mode == MODE_FLOW ? SLayout<MODE_FLOW>::F_END : SLayout<MODE_SYNTH>::F_END;
+    const long nfl = floats - fend * 4;
+    const long total = fend * 8 + nfl;                              // one thread per bf16 element, then per float
+    siren_split_pack_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(pa, packed, total);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return -(long)e - 1000;
+    return floats;
+}
+
+template <int MODE, int TP>
+static int launch_siren_split(const SirenArgs& a_in, void* stream) {
+    using L = SLayout<MODE>;
+    static_assert(L::LDS_BYTES <= 160 * 1024, "resident part of the packed network must fit the 160 KB LDS");
+    SirenArgs a = a_in;
+    a.stagger = 4;
+    if (const char* e = getenv("MOTIF_SIREN_STAGGER")) a.stagger = atoi(e);
+    hipError_t e = hipFuncSetAttribute((const void*)siren_split_kernel<MODE, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long Q = (long)a.HH * a.WW;
+    const long tiles = (long)a.NB * ((Q + 32 * TP - 1) / (32 * TP));
+    long blocks = (tiles + SIREN_WAVES - 1) / SIREN_WAVES;
+    if (blocks > cus) blocks = cus;
+    siren_split_kernel<MODE, TP><<<(int)blocks, SIREN_THREADS, (size_t)L::LDS_BYTES, (hipStream_t)stream>>>(a);
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}
+
+int motif_siren_split_launch(int mode, const SirenArgs& a, void* stream) {
+    if (mode == MODE_IMNET) return launch_siren_split<MODE_IMNET, 1>(a, stream);
+    if (mode == MODE_FLOW) return launch_siren_split<MODE_FLOW, 1>(a, stream);
+    return launch_siren_split<MODE_SYNTH, 1>(a, stream);
+}

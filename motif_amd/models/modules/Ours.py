@@ -392,8 +392,9 @@ class LunaTokis(nn.Module):
         iy, ix, rel_y, rel_x = gather_tables(H, W, HH, WW, x.device)
         # the gathered-LR-feature part of each MLP's first layer does not depend on the HR pixel or on t:
         # evaluate it once per clip at LR resolution (1x1 convs), the HR kernels start from it (pre=1)
-        imnet_out = ops.siren_imnet(self.imnet.packed(), ops.conv2d(self.imnet.l0_plan(0, 64), feat01), iy, ix, rel_y, rel_x,
-                                    HH, WW, pre=True)
+        split = ops.get_siren_mma() == ops.MMA_BF16X3
+        imnet_out = ops.siren_imnet(self.imnet.packed_split(ops.SIREN_IMNET) if split else self.imnet.packed(),
+                                    ops.conv2d(self.imnet.l0_plan(0, 64), feat01), iy, ix, rel_y, rel_x, HH, WW, pre=2 if split else 1)
         flow_l0 = ops.conv2d(self.flow_imnet.l0_plan(0, 64), flow_feat)
         synth_l0 = ops.conv2d(self.synth_net.l0_plan(133, 197), residual)
         return dict(flow_l0=flow_l0, synth_l0=synth_l0, flow=flow, psies=psies, flow_feat_in=flow_feat_in, feat=feat, residual=residual, feat01=feat01,
@@ -425,9 +426,12 @@ class LunaTokis(nn.Module):
         c = self._cache
         iy, ix, rel_y, rel_x = c["tables"]
         times = target_t.contiguous()                                           # [B,N]
-        pred = ops.siren_flow(self.flow_imnet.packed(), c["flow_l0"], iy, ix, rel_y, rel_x, times, N, HH, WW, pre=True)   # [2BN,3,HH,WW]
+        split = ops.get_siren_mma() == ops.MMA_BF16X3
+        pred = ops.siren_flow(self.flow_imnet.packed_split(ops.SIREN_FLOW) if split else self.flow_imnet.packed(), c["flow_l0"],
+                              iy, ix, rel_y, rel_x, times, N, HH, WW, pre=2 if split else 1)   # [2BN,3,HH,WW]
         acc = ops.splat_motif(c["imnet_out"], pred, c["feat01"], iy, ix, self.alpha, HH / H, B, N, HH, WW)
-        frames = ops.siren_synth(self.synth_net.packed(), acc, c["synth_l0"], iy, ix, times, B, N, HH, WW, pre=True)
+        frames = ops.siren_synth(self.synth_net.packed_split(ops.SIREN_SYNTH) if split else self.synth_net.packed(), acc,
+                                 c["synth_l0"], iy, ix, times, B, N, HH, WW, pre=2 if split else 1)
         if stages is not None:
             stages.update(c)
             stages.update(pred=pred, acc=acc)

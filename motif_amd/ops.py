@@ -290,6 +290,44 @@ def siren_pack(linears):
     return blob
 
 
+SIREN_IMNET, SIREN_FLOW, SIREN_SYNTH = 0, 1, 2
+_siren_mma = int(os.environ.get("MOTIF_SIREN_MMA", "0"))
+
+
+def set_siren_mma(mode):
+    """0: fp32-MFMA SIREN kernels; 6: 3-way bf16 split on the bf16 matrix cores (needs the LR partial, `pre`)."""
+    global _siren_mma
+    if mode not in (MMA_FP32, MMA_BF16X3):
+        raise ValueError("siren mma mode must be 0 or 6")
+    _siren_mma = mode
+
+
+def get_siren_mma():
+    return _siren_mma
+
+
+def siren_pack_split(kind, linears):
+    """Packed blob of one of the three MoTIF MLPs (kind = SIREN_IMNET / _FLOW / _SYNTH) for the split kernels; pass it
+    with pre=2."""
+    lib = _lib.load()
+    n = len(linears)
+    ws = [_c(w.detach()) for w, _ in linears]
+    bs = [_c(b.detach()) for _, b in linears]
+    want = {SIREN_IMNET: [66, 64, 64, 256, 64], SIREN_FLOW: [67, 64, 64, 256, 3], SIREN_SYNTH: [198, 64, 64, 64, 256, 3]}[kind]
+    if [ws[0].shape[1]] + [w.shape[0] for w in ws] != want:
+        raise RuntimeError("siren_pack_split: layer sizes do not match kind %d" % kind)
+    wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+    bp = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bs])
+    total = lib.motif_siren_pack_split(kind, wp, bp, None, None)
+    if total <= 0:
+        raise RuntimeError("motif_siren_pack_split size query failed (%d)" % total)
+    blob = torch.empty(total, dtype=torch.float32, device=ws[0].device)
+    rc = lib.motif_siren_pack_split(kind, wp, bp, _p(blob), _stream())
+    if rc != total:
+        raise RuntimeError("motif_siren_pack_split failed (%d)" % rc)
+    return blob
+
+
 def siren_imnet(blob, feat_lr, iy, ix, rel_y, rel_x, HH, WW, pre=False):
     lib = _lib.load()
     feat_lr = _c(feat_lr)

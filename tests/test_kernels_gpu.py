@@ -424,6 +424,7 @@ def test_siren_kernels_vs_torch(HW):
     close(o, r, 5e-6, 1e-4, "imnet")
     l0 = ops.conv2d(mine.imnet.l0_plan(0, 64), feat.to(dev()))          # LR partial of layer 0, then pre=1
     close(ops.siren_imnet(mine.imnet.packed(), l0, iy, ix, rel_y, rel_x, HH, WW, pre=True), r, 5e-6, 1e-4, "imnet pre")
+    close(ops.siren_imnet(mine.imnet.packed_split(ops.SIREN_IMNET), l0, iy, ix, rel_y, rel_x, HH, WW, pre=2), r, 5e-6, 1e-4, "imnet split")
     # flow_imnet
     times = torch.tensor([[0.0, 0.5], [0.25, 1.0]])
     g = gather(feat).repeat(1, N, 1, 1).reshape(2 * B * N, 64, HH, WW)
@@ -435,6 +436,7 @@ def test_siren_kernels_vs_torch(HW):
     close(o, r, 5e-6, 1e-4, "flow_imnet")
     l0 = ops.conv2d(mine.flow_imnet.l0_plan(0, 64), feat.to(dev()))
     close(ops.siren_flow(mine.flow_imnet.packed(), l0, iy, ix, rel_y, rel_x, times.to(dev()), N, HH, WW, pre=True), r, 5e-6, 1e-4, "flow pre")
+    close(ops.siren_flow(mine.flow_imnet.packed_split(ops.SIREN_FLOW), l0, iy, ix, rel_y, rel_x, times.to(dev()), N, HH, WW, pre=2), r, 5e-6, 1e-4, "flow split")
     # synth (with the normalisation prologue): build an accumulator with zeros / ones / exact-equality cases
     acc = rnd(B * N, 133, HH, WW, seed=5, scale=0.5)
     acc[:, 130] = acc[:, 130].abs() * 2 + 1e-3
@@ -463,6 +465,7 @@ def test_siren_kernels_vs_torch(HW):
     close(o, r, 2e-5, 1e-4, "synth")
     l0 = ops.conv2d(mine.synth_net.l0_plan(133, 197), res.to(dev()))
     close(ops.siren_synth(mine.synth_net.packed(), acc.to(dev()), l0, iy, ix, times.to(dev()), B, N, HH, WW, pre=True), r, 2e-5, 1e-4, "synth pre")
+    close(ops.siren_synth(mine.synth_net.packed_split(ops.SIREN_SYNTH), acc.to(dev()), l0, iy, ix, times.to(dev()), B, N, HH, WW, pre=2), r, 2e-5, 1e-4, "synth split")
 
 
 # ------------------------------------------------------------------------------------------- fused MoTIF splat

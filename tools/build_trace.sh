@@ -1,10 +1,10 @@
 #!/bin/bash
-# instrumented build (-DMOTIF_TRACE) of the library into tools/_trace/ (git-ignored); use with MOTIF_HIP_LIB
+# instrumented build (-DMOTIF_TRACE -DMOTIF_SIREN_DBG) of the library into tools/_trace/ (git-ignored); use with MOTIF_HIP_LIB
 set -e
 cd "$(dirname "$0")/../motif_amd/csrc"
 mkdir -p ../../tools/_trace /tmp/motif_trace_obj
-for f in api conv_igemm conv_split siren splat misc corr dcn; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-value -Wno-pass-failed -DMOTIF_TRACE -c $f.hip -o /tmp/motif_trace_obj/$f.o &
+for f in api conv_igemm conv_split siren siren_split splat misc corr dcn; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-value -Wno-pass-failed -DMOTIF_TRACE -DMOTIF_SIREN_DBG -c $f.hip -o /tmp/motif_trace_obj/$f.o &
 done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/_trace/libmotif_hip.so /tmp/motif_trace_obj/*.o

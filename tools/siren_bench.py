@@ -38,6 +38,20 @@ def main():
     if "imnet" in which:
         ms = t(lambda: ops.siren_imnet(net.imnet.packed(), feat, iy, ix, ry, rx, HH, WW), reps)
         print("imnet: %.3f ms  %.1f TFLOP/s" % (ms, 2 * 41088 * 2 * B * Q / ms / 1e9))
+    if "split" in which:
+        l0i = ops.conv2d(net.imnet.l0_plan(0, 64), feat)
+        l0f = ops.conv2d(net.flow_imnet.l0_plan(0, 64), feat)
+        l0s = ops.conv2d(net.synth_net.l0_plan(133, 197), res)
+        for pre, name in ((1, "fp32 pre"), (2, "split")):
+            bf = net.flow_imnet.packed_split(ops.SIREN_FLOW) if pre == 2 else net.flow_imnet.packed()
+            bs = net.synth_net.packed_split(ops.SIREN_SYNTH) if pre == 2 else net.synth_net.packed()
+            bi = net.imnet.packed_split(ops.SIREN_IMNET) if pre == 2 else net.imnet.packed()
+            ms = t(lambda: ops.siren_flow(bf, l0f, iy, ix, ry, rx, times, N, HH, WW, pre=pre), reps)
+            print("[%s] flow_imnet N=3: %.3f ms  %.1f TFLOP/s" % (name, ms, 2 * 25536 * 2 * B * N * Q / ms / 1e9))
+            ms = t(lambda: ops.siren_synth(bs, acc, l0s, iy, ix, times, B, N, HH, WW, pre=pre), reps)
+            print("[%s] synth N=3: %.3f ms  %.1f TFLOP/s" % (name, ms, 2 * 38016 * B * N * Q / ms / 1e9))
+            ms = t(lambda: ops.siren_imnet(bi, l0i, iy, ix, ry, rx, HH, WW, pre=pre), reps)
+            print("[%s] imnet: %.3f ms  %.1f TFLOP/s" % (name, ms, 2 * 41088 * 2 * B * Q / ms / 1e9))
     if "splat" in which:
         ms = t(lambda: ops.splat_motif(imn, pred, feat, iy, ix, net.alpha, HH / H, B, N, HH, WW, acc=acc), reps)
         print("splat N=3: %.3f ms  %.2f TB/s algorithmic (2640 B/px-frame)" % (ms, 2640.0 * B * N * Q / ms / 1e9))
