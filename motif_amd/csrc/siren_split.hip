@@ -189,6 +189,68 @@ __device__ __forceinline__ void sine_f32(const f32x16 (&acc)[TP][MT], float (&h)
                 h[p][t * 16 + r] = sin_rev(30.0f * acc[p][t][r]);
             }
 }
+
+// One sine/split unit of k-step ks of the layer input `src` (pre-activations): units 0..7 = one sine each,
+// units 8..11 = split of one value pair into the three packed-bf16 parts.
+template <int TP>
+__device__ __forceinline__ void ss_unit(int u, const f32x16 (&src)[TP][2], int ks, float (&tmp)[TP][8], u32x4 (&hx)[TP][3]) {
+    const int t = ks >> 1, uu = ks & 1;
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+        if (u < 8) {
+            tmp[p][u] = sin_rev(30.0f * src[p][t][8 * uu + u]);
+        } else {
+            const int q = u - 8;
+            float x0 = tmp[p][2 * q], x1 = tmp[p][2 * q + 1];
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                const unsigned pk = pk_bf16(x0, x1);
+                hx[p][part][q] = pk;
+                if (part < 2) { x0 -= bf_lo(pk); x1 -= bf_hi(pk); }
+            }
+        }
+    }
+}
+
+// dst += W . sin(30 src) for a 64-wide input: the sine + split of k-step ks+1 (12 VALU units) is interleaved, unit by
+// unit, with the 12 MFMAs of k-step ks, so only the first k-step's vector work and the last k-step's MFMAs are exposed.
+// One set of weight fragments, refilled in place after the last use of each part.  KEEP: also store the split input.
+template <int MTW, int TP, bool KEEP>
+__device__ __forceinline__ void fused_layer(const f32x16 (&src)[TP][2], f32x16 (&dst)[TP][2], const u32x4* wp, int t0,
+                                            u32x4 (&keep)[TP][4][3]) {
+    u32x4 hx[2][TP][3];
+    float tmp[TP][8];
+    u32x4 w[2][3];
+    load_w<2, MTW>(w, wp, t0);
+#pragma unroll
+    for (int u = 0; u < 12; ++u) ss_unit<TP>(u, src, 0, tmp, hx[0]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        if constexpr (KEEP) {
+#pragma unroll
+            for (int p = 0; p < TP; ++p)
+#pragma unroll
+                for (int part = 0; part < 3; ++part) keep[p][ks][part] = hx[ks & 1][p][part];
+        }
+        const u32x4* wnext = wp + (long)(ks + 1) * 3 * MTW * 64;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int p = 0; p < TP; ++p)
+                    dst[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t][PW[k]]),
+                                                                         __builtin_bit_cast(bf16x8, hx[ks & 1][p][PX[k]]), dst[p][t], 0, 0, 0);
+                if (ks < 3) ss_unit<TP>(2 * k + t, src, ks + 1, tmp, hx[(ks + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0x180);               // only DS instructions may cross
+            }
+            if (ks < 3 && (k == 0 || k == 3 || k == 5)) {             // last use of part PW[k] in this k-step
+#pragma unroll
+                for (int t = 0; t < 2; ++t) w[t][PW[k]] = wnext[(PW[k] * MTW + t0 + t) * 64];
+            }
+        }
+    }
+}
 }  // namespace
 
 #ifdef MOTIF_TRACE
@@ -241,7 +303,44 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
     const int tiles_per_img = (int)((Q + 32 * TP - 1) / (32 * TP));
     const long total = (long)a.NB * tiles_per_img;
 
-    for (long work = (long)blockIdx.x * SIREN_WAVES + wave; work < total; work += (long)gridDim.x * SIREN_WAVES) {
+    // 32-bit tile bookkeeping (Q < 2^31).  The LR partial of the NEXT tile is gathered into acc0 as soon as the current
+    // tile has consumed it, so its L2 latency hides behind the rest of the tile.
+    struct Tile { int img; int pp[TP], Y[TP], X[TP], lr[TP]; bool valid[TP]; };
+    auto locate = [&](unsigned work, Tile& T) {
+        const unsigned w = __builtin_amdgcn_readfirstlane(work);
+        T.img = (int)(w / (unsigned)tiles_per_img);
+        const unsigned tl = w - (unsigned)T.img * (unsigned)tiles_per_img;
+#pragma unroll
+        for (int p = 0; p < TP; ++p) {
+            const unsigned pp = tl * (32 * TP) + 32 * p + l31;
+            T.pp[p] = (int)pp;
+            T.valid[p] = pp < (unsigned)Q;
+            const unsigned pc = T.valid[p] ? pp : (unsigned)Q - 1;
+            T.Y[p] = (int)(pc / (unsigned)a.WW);
+            T.X[p] = (int)(pc - (unsigned)T.Y[p] * (unsigned)a.WW);
+            T.lr[p] = a.iy[T.Y[p]] * a.W + a.ix[T.X[p]];
+        }
+    };
+    auto gather = [&](f32x16 (&acc)[TP][2], const Tile& T) {
+        const int ilr = (MODE == MODE_FLOW || MODE == MODE_SYNTH) ? T.img / a.N : T.img;
+#pragma unroll
+        for (int p = 0; p < TP; ++p) {
+            const float* gp = a.src_lr + (long)ilr * 64 * HWl + T.lr[p] + (long)(4 * hf) * HWl;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][t][r] = gp[(long)(32 * t + (r & 3) + 8 * (r >> 2)) * HWl];
+        }
+    };
+    const unsigned utotal = (unsigned)total, stride = gridDim.x * SIREN_WAVES;
+    unsigned work = blockIdx.x * SIREN_WAVES + wave;
+    Tile cur, nxt;
+    f32x16 acc0[TP][2];
+    if (work < utotal) {
+        locate(work, cur);
+        if constexpr (MODE != MODE_SYNTH) gather(acc0, cur);
+    }
+    for (; work < utotal; work += stride) {
         // LDS contents never change after the staging barrier, so the compiler would hoist bias / head-weight reads out
         // of this loop and spill them; an opaque zero offset per iteration keeps them where they are used
         int lds_o = 0;
@@ -250,35 +349,13 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
         const u32x4* lw1 = lw1_0 + lds_o;
         const u32x4* lw1b = lw1b_0 + lds_o;
         const u32x4* lw2 = lw2_0 + lds_o;
-        const int img = (int)(work / tiles_per_img);
-        const long pbase = (long)(work % tiles_per_img) * (32 * TP) + l31;
-        long pp[TP], pc[TP], lr[TP];
-        int Y[TP], X[TP];
-        bool valid[TP];
-#pragma unroll
-        for (int p = 0; p < TP; ++p) {
-            pp[p] = pbase + 32 * p;
-            valid[p] = pp[p] < Q;
-            pc[p] = valid[p] ? pp[p] : Q - 1;
-            Y[p] = (int)(pc[p] / a.WW);
-            X[p] = (int)(pc[p] - (long)Y[p] * a.WW);
-            lr[p] = (long)a.iy[Y[p]] * a.W + a.ix[X[p]];
-        }
-
+        const int img = cur.img;
+        const int (&Y)[TP] = cur.Y;
+        const int (&X)[TP] = cur.X;
+        const bool has_next = work + stride < utotal;
         PH(0);                                               // tile bookkeeping
-        // ------------------------------------------------ layer 0: LR partial seeds the accumulator
-        f32x16 acc0[TP][2];
-        {
-            const int ilr = (MODE == MODE_FLOW || MODE == MODE_SYNTH) ? img / a.N : img;
-#pragma unroll
-            for (int p = 0; p < TP; ++p) {
-                const float* gp = a.src_lr + (long)ilr * 64 * HWl + lr[p] + (long)(4 * hf) * HWl;
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc0[p][t][r] = gp[(long)(32 * t + (r & 3) + 8 * (r >> 2)) * HWl];
-            }
-        }
+        // ------------------------------------------------ layer 0: the LR partial (gathered ahead) seeds the accumulator
+        if constexpr (MODE == MODE_SYNTH) gather(acc0, cur);    // synth: no spare registers to carry it across the tile
         if constexpr (MODE == MODE_IMNET || MODE == MODE_FLOW) {
             // natural K order: imnet k0 = rel_y, k1 = rel_x; flow k0 = t, k1 = rel_y, k2 = rel_x (lower half-wave)
             u32x4 x[TP][3];
@@ -298,7 +375,7 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
             float wz[TP], cnt[TP], cnt_[TP], wz_[TP];
 #pragma unroll
             for (int p = 0; p < TP; ++p) {
-                A[p] = a.acc + (long)img * 133 * Q + pc[p];
+                A[p] = a.acc + (long)img * 133 * Q + (cur.valid[p] ? cur.pp[p] : (int)Q - 1);
                 wz[p] = A[p][130 * Q];
                 cnt[p] = A[p][132 * Q];
                 if (wz[p] == 0.f) wz[p] = 1.0f;                           // Ours.py:813
@@ -357,29 +434,6 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
             }
         }
         PH(1);                                               // layer 0 (gather + MFMA issue)
-        u32x4 wn[2][3];                                  // first fragments of the next layer, in flight during the sine
-        load_w<2, 2>(wn, lw1, 0);
-        u32x4 h1[TP][4][3];
-        DBG_V(sine_split(acc0, h1), fake_split(acc0, h1));
-
-        PH(2);                                               // sine 1
-        // ------------------------------------------------ 64 -> 64 (x2 for synth)
-        f32x16 acc1[TP][2];
-        init_bias_s(acc1, ldsf + L::O_B1, hf);
-        DBG_M((split_layer<4, 2, 2, TP>(h1, acc1, lw1, 0, wn)));
-        PH(3);                                               // layer 1 MFMAs
-        if constexpr (MODE == MODE_SYNTH) load_w<2, 2>(wn, lw1b, 0); else load_w<2, 8>(wn, lw2, 0);
-        u32x4 h2[TP][4][3];
-        DBG_V(sine_split(acc1, h2), fake_split(acc1, h2));
-        if constexpr (MODE == MODE_SYNTH) {
-            init_bias_s(acc1, ldsf + L::O_B1B, hf);
-            DBG_M((split_layer<4, 2, 2, TP>(h2, acc1, lw1b, 0, wn)));
-            load_w<2, 8>(wn, lw2, 0);
-            DBG_V(sine_split(acc1, h2), fake_split(acc1, h2));
-        }
-
-        PH(4);                                               // sine 2 (+ layer 1b)
-        // ------------------------------------------------ 64 -> 256 in four 64-wide chunks, each fed to the head
         if constexpr (Net<MODE>::HEAD == 3) {
             float sum[TP][3];
 #pragma unroll
@@ -388,9 +442,26 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
             // pipe) comes one unit of chunk c's vector work (a sine, or four head FMAs), so the wave's own VALU
             // instructions fill the issue slots its MFMAs leave free.  The barriers pin MFMA/VALU order only; LDS
             // reads (weight fragments, head weights) may be hoisted across them.
+            // 64 -> 64 (x2 for synth) -> first 64-wide chunk of 64 -> 256, each layer fused with the sine of its input
+            u32x4 h2[TP][4][3];
+            f32x16 acc1[TP][2];
+            init_bias_s(acc1, ldsf + L::O_B1, hf);
+            fused_layer<2, TP, false>(acc0, acc1, lw1, 0, h2);
+            if constexpr (MODE != MODE_SYNTH) {
+                if (has_next) { locate(work + stride, nxt); gather(acc0, nxt); }
+            }
+            PH(3);
             f32x16 acc2[2][TP][2];
-            init_bias_s(acc2[0], ldsf + L::O_B2, hf);
-            DBG_M((split_layer<4, 2, 8, TP>(h2, acc2[0], lw2, 0, wn)));
+            if constexpr (MODE == MODE_SYNTH) {
+                init_bias_s(acc0, ldsf + L::O_B1B, hf);                   // acc0 is free: reuse as the 1b accumulator
+                fused_layer<2, TP, false>(acc1, acc0, lw1b, 0, h2);
+                init_bias_s(acc2[0], ldsf + L::O_B2, hf);
+                fused_layer<8, TP, true>(acc0, acc2[0], lw2, 0, h2);
+                if (has_next) locate(work + stride, nxt);
+            } else {
+                init_bias_s(acc2[0], ldsf + L::O_B2, hf);
+                fused_layer<8, TP, true>(acc1, acc2[0], lw2, 0, h2);
+            }
             PH(5);                                           // 64->256 chunk 0 MFMAs
             const float* headw = ldsf + L::O_HEAD;
 #pragma unroll
@@ -456,22 +527,46 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
                     sum[p][o] += __shfl_xor(sum[p][o], 32);
                     sum[p][o] += hb[o];
                 }
-                if (valid[p] && hf == 0) {
+                if (cur.valid[p] && hf == 0) {
                     if constexpr (MODE == MODE_FLOW) {
 #pragma unroll
-                        for (int o = 0; o < 3; ++o) a.out[((long)img * 3 + o) * Q + pp[p]] = sum[p][o];
+                        for (int o = 0; o < 3; ++o) a.out[((long)img * 3 + o) * Q + cur.pp[p]] = sum[p][o];
                     } else {
                         const int b = img / a.N, n = img % a.N;
 #pragma unroll
                         for (int o = 0; o < 3; ++o) {
                             float v = sum[p][o];
                             v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
-                            a.out[(((long)n * a.B + b) * 3 + o) * Q + pp[p]] = v;
+                            a.out[(((long)n * a.B + b) * 3 + o) * Q + cur.pp[p]] = v;
                         }
                     }
                 }
             }
         } else {
+            u32x4 wn[2][3];                                  // first fragments of the next layer, in flight during the sine
+            load_w<2, 2>(wn, lw1, 0);
+            u32x4 h1[TP][4][3];
+            DBG_V(sine_split(acc0, h1), fake_split(acc0, h1));
+            if (has_next) { locate(work + stride, nxt); gather(acc0, nxt); }
+
+            PH(2);                                               // sine 1
+            // ------------------------------------------------ 64 -> 64 (x2 for synth)
+            f32x16 acc1[TP][2];
+            init_bias_s(acc1, ldsf + L::O_B1, hf);
+            DBG_M((split_layer<4, 2, 2, TP>(h1, acc1, lw1, 0, wn)));
+            PH(3);                                               // layer 1 MFMAs
+            if constexpr (MODE == MODE_SYNTH) load_w<2, 2>(wn, lw1b, 0); else load_w<2, 8>(wn, lw2, 0);
+            u32x4 h2[TP][4][3];
+            DBG_V(sine_split(acc1, h2), fake_split(acc1, h2));
+            if constexpr (MODE == MODE_SYNTH) {
+                init_bias_s(acc1, ldsf + L::O_B1B, hf);
+                DBG_M((split_layer<4, 2, 2, TP>(h2, acc1, lw1b, 0, wn)));
+                load_w<2, 8>(wn, lw2, 0);
+                DBG_V(sine_split(acc1, h2), fake_split(acc1, h2));
+            }
+
+            PH(4);                                               // sine 2 (+ layer 1b)
+            // ------------------------------------------------ 64 -> 256 in four 64-wide chunks, each fed to the head
             f32x16 acc3[TP][2];
             const u32x4* w3g = gfr + L::F_W3 + lane;                    // streamed from L2
             init_bias_s(acc3, ldsf + L::O_HEAD, hf);
@@ -489,17 +584,18 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
             }
 #pragma unroll
             for (int p = 0; p < TP; ++p) {
-                if (!valid[p]) continue;
+                if (!cur.valid[p]) continue;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                        a.out[((long)img * 64 + m) * Q + pp[p]] = acc3[p][t][r];
+                        a.out[((long)img * 64 + m) * Q + cur.pp[p]] = acc3[p][t][r];
                     }
             }
         }
         PH(8);                                               // outputs
+        cur = nxt;
     }
 #ifdef MOTIF_TRACE
     if (lane == 0 && blockIdx.x < 256)
