@@ -6,10 +6,16 @@ x6 temporal = 7 timestamps (BASELINE.json configs[1], "c2"), B = 1 clip per step
 metric = HR pixels / second = T*B*HH*WW / wall, whole job over all ranks (clips shard embarrassingly:
 rank r renders its own clips, weak scaling; the only collective is the final gather of the uint8 frames).
 
+Arithmetic (--mma): "bf16x3" (default) runs the dense contractions (3x3 convolutions, the three MLPs) on the bf16
+matrix cores with every fp32 operand split exactly into three bf16 parts and six products accumulated in fp32 --
+fp32-equivalent (error below an fp32 FMA chain, tests/test_kernels_gpu.py::test_conv_split_engine_is_fp32_equivalent);
+"fp32" runs them on v_mfma_f32_32x32x2_f32.  The line carries the fp32-MFMA number of the same run as `fp32_mfma`.
+
 Extra objects on the JSON line:
-  roofline     dominant kernel = conv_igemm_kernel<2> (fp32 MFMA implicit GEMM): algorithmic FLOP of
-               its launches / their measured duration (events on the launch stream, one instrumented
-               clip after the timed region), vs the 157.3 TFLOP/s fp32-MFMA peak.
+  roofline     dominant kernel = the 3x3 convolution engine (conv_split_kernel<3,4>, or conv_igemm_kernel<2> with
+               --mma fp32): algorithmic FLOP of its launches / their measured duration (events on the launch
+               stream, one instrumented clip after the timed region).  Peak: bf16 dense MFMA 2500 TFLOP/s / 6
+               products per fp32 MAC = 416.7 TFLOP/s for bf16x3, 157.3 TFLOP/s fp32 MFMA for fp32.
   cpu_baseline the CPU oracle (oracle/, "port" of the reference) on a bounded crop of the same workload.
 """
 import argparse
@@ -24,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # same guide, "Peak BF16/FP16 MFMA" dense
 
 
 def parse():
@@ -34,6 +41,8 @@ def parse():
     ap.add_argument("--lr", type=int, nargs=2, default=[180, 320], help="LR height width")
     ap.add_argument("--scale", type=int, default=4)
     ap.add_argument("--times", type=int, default=7)
+    ap.add_argument("--mma", choices=["bf16x3", "fp32"], default="bf16x3", help="arithmetic of the dense contractions")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the secondary fp32-MFMA measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -48,6 +57,13 @@ def instrumented_clip(model, sample):
     from motif_amd import ops
     log, events = [], []
     orig = ops.conv2d
+    split = ops.get_conv_mma() != ops.MMA_FP32
+
+    def dominant(plan):          # launches served by the dominant kernel (same rule as the C side)
+        co, cig, kh, kw = plan.weight.shape
+        if split:
+            return kh == 3 and kw == 3 and plan.stride == 1 and plan.dil == 1 and cig >= 16 and co > 32 * plan.groups
+        return co > 32 * plan.groups
 
     def timed_conv(plan, x, x2=None, *a, **k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -55,7 +71,7 @@ def instrumented_clip(model, sample):
         out = orig(plan, x, x2, *a, **k)
         e1.record()
         co, cig, kh, kw = plan.weight.shape
-        events.append((e0, e1, co > 32 * plan.groups))
+        events.append((e0, e1, dominant(plan)))
         log.append((x.shape[0], co, cig * plan.groups, plan.groups, kh, kw, out.shape[2], out.shape[3]))
         return out
 
@@ -67,7 +83,7 @@ def instrumented_clip(model, sample):
         out = orig_multi(plans, xs, x2s, *a, **k)
         e1.record()
         co, cig, kh, kw = plans[0].weight.shape
-        events.append((e0, e1, co > 32 * plans[0].groups))
+        events.append((e0, e1, dominant(plans[0])))
         log.append((len(plans) * xs[0].shape[0], co, cig * plans[0].groups, plans[0].groups, kh, kw, out.shape[3], out.shape[4]))
         return out
 
@@ -138,7 +154,7 @@ def main():
     from motif_amd.utils.synth_weights import fill_state_dict
 
     h, w = a.lr
-    model = create_model(default_opt(scale=a.scale, gpu_ids=[local]))
+    model = create_model(default_opt(scale=a.scale, gpu_ids=[local], mma=a.mma))
     fill_state_dict(model.netG)
     HH, WW = h * a.scale, w * a.scale
     # two distinct clips per rank, resident in HBM before the timed region
@@ -162,38 +178,57 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(warmup, steps):
+        for i in range(warmup):
+            step(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    dt = timed(a.warmup, a.steps)
     px = a.times * 1 * HH * WW
     line = {
         "metric": "HR pixels/sec", "value": world * a.steps * px / dt, "unit": "px/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "c2: 4-frame %dx%d LR clip -> %dx%d (x%d spatial), x%dt = %d timestamps, B=1 clip per step per GPU, "
+        "config": {"arithmetic": ("fp32-equivalent on the bf16 matrix cores: every fp32 operand = 3 exact bf16 parts, 6 products, fp32 "
+                                  "accumulate (3x3 convolutions and the three MLPs); everything else fp32" if a.mma == "bf16x3"
+                                  else "fp32 MFMA (v_mfma_f32_32x32x2_f32) and fp32 VALU"),
+                   "workload": "c2: 4-frame %dx%d LR clip -> %dx%d (x%d spatial), x%dt = %d timestamps, B=1 clip per step per GPU, "
                                "RAFT-small iters=4, seeded key-hashed weights" % (h, w, HH, WW, a.scale, a.times - 1, a.times),
                    "parallelism": "clips sharded per GPU (dp%d), uint8 frame gather to rank 0" % world},
     }
+    if a.mma == "bf16x3" and not a.no_fp32_leg:
+        # the same job on the fp32 MFMA (all ranks, same barriers), reported next to the headline value
+        from motif_amd import ops
+        ops.set_mma("fp32")
+        dt32 = timed(1, a.steps)
+        ops.set_mma("bf16x3")
+        line["fp32_mfma"] = {"value": world * a.steps * px / dt32, "unit": "px/s", "ms_per_step": 1000.0 * dt32 / a.steps,
+                             "note": "same job with --mma fp32 (v_mfma_f32_32x32x2_f32 contractions)"}
     if rank == 0:
         if not a.no_roofline:
             r = instrumented_clip(model, clips[0])
             ach = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
             traffic = None
-            tj = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+            split = a.mma == "bf16x3"
+            tj = os.path.join(ROOT, "profiles", "r01_conv_split_traffic.json" if split else "r01_conv_traffic.json")
             if os.path.exists(tj):          # PMC run of the same kernel (separate --pmc passes), see the file's note
                 traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
-            line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                                "kernel": "conv_igemm_kernel<2>", "launches_per_clip": r["launches"],
+            peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
+            line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                                "frac": ach / peak, "traffic": traffic,
+                                "peak_basis": ("bf16 dense MFMA 2500 TFLOP/s / 6 bf16 products per fp32 MAC" if split
+                                               else "fp32 MFMA 157.3 TFLOP/s"),
+                                "kernel": "conv_split_kernel<3,4>" if split else "conv_igemm_kernel<2>", "launches_per_clip": r["launches"],
                                 "avg_launch_us": 1000.0 * r["ms"] / max(r["launches"], 1),
                                 "avg_launch_gflop": r["flops"] / max(r["launches"], 1) / 1e9,
                                 "all_conv_ms_per_clip": r["all_conv_ms"], "all_conv_tflop_per_clip": r["all_conv_flops"] / 1e12}

@@ -8,6 +8,9 @@ def define_G(opt):
     opt_net = opt["network_G"]
     which_model = opt_net["which_model_G"]
     if which_model == "Ours":
+        if opt_net.get("mma"):                          # "bf16x3" (default) | "fp32" | "bf16x2" | "bf16", see ops.set_mma
+            from .. import ops
+            ops.set_mma(opt_net["mma"])
         if "setting" in opt_net and opt_net["setting"] is not None:
             return Ours.LunaTokis(setting=opt_net["setting"])
         return Ours.LunaTokis()

@@ -41,7 +41,9 @@ def _planar(t):
 # Arithmetic of the convolution contractions (MotifConvDesc.mma): 0 = fp32 MFMA, 6 = fp32-equivalent 3-way bf16
 # split on the bf16 matrix cores (6 products, fp32 accumulate), 3 = 2-way split, 1 = plain bf16.
 MMA_FP32, MMA_BF16X3, MMA_BF16X2, MMA_BF16 = 0, 6, 3, 1
-_conv_mma = int(os.environ.get("MOTIF_CONV_MMA", "0"))
+_MMA_NAMES = {"fp32": MMA_FP32, "bf16x3": MMA_BF16X3, "bf16x2": MMA_BF16X2, "bf16": MMA_BF16}
+_default_mma = _MMA_NAMES[os.environ.get("MOTIF_MMA", "bf16x3")]
+_conv_mma = int(os.environ.get("MOTIF_CONV_MMA", str(_default_mma)))
 
 
 def set_conv_mma(mode):
@@ -291,7 +293,20 @@ def siren_pack(linears):
 
 
 SIREN_IMNET, SIREN_FLOW, SIREN_SYNTH = 0, 1, 2
-_siren_mma = int(os.environ.get("MOTIF_SIREN_MMA", "0"))
+_siren_mma = int(os.environ.get("MOTIF_SIREN_MMA", str(MMA_BF16X3 if _default_mma != MMA_FP32 else MMA_FP32)))
+
+
+def set_mma(name):
+    """Arithmetic of the dense contractions on the path: "bf16x3" (default: fp32-equivalent 3-way bf16 split on the
+    bf16 matrix cores, convolutions and MLPs), "fp32" (v_mfma_f32_32x32x2_f32 everywhere), "bf16x2" / "bf16"
+    (convolutions only; reduced precision, the MLPs stay bf16x3)."""
+    mode = _MMA_NAMES[name]
+    set_conv_mma(mode)
+    set_siren_mma(MMA_FP32 if mode == MMA_FP32 else MMA_BF16X3)
+
+
+def get_mma():
+    return {v: k for k, v in _MMA_NAMES.items()}[_conv_mma]
 
 
 def set_siren_mma(mode):

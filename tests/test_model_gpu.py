@@ -41,6 +41,17 @@ def psnr(a, b):
     return 99.0 if mse == 0 else 10 * np.log10(1.0 / mse)
 
 
+@pytest.fixture(params=["bf16x3", "fp32"], autouse=True)
+def mma_mode(request):
+    """Every model-level parity test runs on both contraction engines: the bf16 matrix cores with the 3-way split
+    (default) and the fp32 MFMA."""
+    from motif_amd import ops
+    before = ops.get_mma()
+    ops.set_mma(request.param)
+    yield request.param
+    ops.set_mma(before)
+
+
 def build_net():
     from motif_amd.models.modules.Ours import LunaTokis
     from motif_amd.utils.synth_weights import fill_state_dict
