@@ -201,3 +201,38 @@ def test_non_integer_scale_and_cache_invalidation():
         assert net._cache_key != key0
         ref2, _, _ = fill_state_dict(MotifRef().eval())(s["LQs"] * 0.5, None, s["time"], s["scale"], use_GT=False, iter=4)
     assert psnr(out2.cpu(), ref2) >= 60.0
+
+
+def test_c3_vimeo_septuplet_bf16_path(mma_mode):
+    """BASELINE config 3: 7 LR frames 256x448 (Vimeo-7 septuplet shape), x4 spatial, x8 temporal = 9 timestamps.  The
+    convolution arithmetic modes against the fp32-MFMA engine on the same weights/inputs: bf16x3 (fp32-equivalent
+    split) >= 90 dB, plain bf16 convolutions (`mma: bf16`, the "bf16 MFMA path") >= 60 dB with a Y-PSNR against the
+    synthetic GT within 0.05 dB (measured on MI355X: 106.1 dB / 71.8 dB)."""
+    if mma_mode != "bf16x3":
+        pytest.skip("runs all arithmetic modes itself")
+    from motif_amd import ops
+    from motif_amd.data.synthetic import synthetic_sample
+    from motif_amd.models import create_model
+    from motif_amd.option import default_opt
+    from motif_amd.utils.synth_weights import fill_state_dict
+    from motif_amd.utils import util
+    model = create_model(default_opt(scale=4, gpu_ids=[0]))
+    fill_state_dict(model.netG)
+    smp = synthetic_sample(256, 448, 4, 9, n_frames=7)
+    data = {"LQs": smp["LQs"].cuda(), "GT": smp["GT"][:, :1].cuda(), "time": [t.cuda() for t in smp["time"]], "scale": smp["scale"]}
+    gt = smp["GT"][0, :9]
+    outs, ypsnr = {}, {}
+    try:
+        for mode in ("fp32", "bf16x3", "bf16"):
+            ops.set_mma(mode)
+            model.feed_data(data)
+            model.test()
+            outs[mode] = model.fake_H.float().cpu()
+            assert outs[mode].shape == (9, 1, 3, 1024, 1792)
+            ypsnr[mode] = util.y_psnr_per_frame(gt, outs[mode][:, 0])
+    finally:
+        ops.set_mma("bf16x3")
+    p3, p1 = psnr(outs["bf16x3"], outs["fp32"]), psnr(outs["bf16"], outs["fp32"])
+    print("c3: PSNR(bf16x3, fp32) = %.1f dB, PSNR(bf16, fp32) = %.1f dB" % (p3, p1))
+    assert p3 >= 90.0 and p1 >= 60.0, (p3, p1)
+    assert np.abs(ypsnr["bf16"] - ypsnr["fp32"]).max() < 0.05 and np.abs(ypsnr["bf16x3"] - ypsnr["fp32"]).max() < 0.05

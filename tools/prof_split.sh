@@ -11,7 +11,3 @@ run() {  # tag, env assignments...
       echo "== $tag"; python $R/tools/rocpd_stats.py $db | grep -E "conv_(split|igemm)_kernel" | cut -c1-60,90-160 )
 }
 run x6 MOTIF_CONV_MMA=6
-run x6_nostore MOTIF_CONV_MMA=6 MOTIF_CONV_DBG=4
-run x6_w8 MOTIF_CONV_MMA=6 MOTIF_SPLIT_WAVES=8
-run x3 MOTIF_CONV_MMA=3
-run x1 MOTIF_CONV_MMA=1
