@@ -55,10 +55,13 @@ int motif_splat_fwd(const float* src, const float* flow, const float* z,
  * from the LR encoder feature by the nearest tables)], flow = pred[0:2]*flow_scale,
  * z = relu(pred[2])*alpha.  Both directions accumulate into the same accumulator
  *   acc [B*N, 133, HH, WW]: planes 0..129 feature sums, 130 sum of e^z*w, 131 max (init 1), 132 count.
- * imnet_out [2B,64,Q], pred [2B*N,3,Q], feat_lr [2B,64,H,W], iy[HH], ix[WW] int32 tables. */
+ * imnet_out [2B,64,Q], pred [2B*N,3,Q], feat_lr [2B,64,H,W], iy[HH], ix[WW] int32 tables.
+ * row0: 0 for a whole image; when the tensors hold the HR row band [row0, row0+HH) of a taller image (spatial
+ * tiling), the image row of local row 0 -- coordinates are then formed with image rows, so corner indices and
+ * weights are bit-identical to the untiled call. */
 int motif_splat_motif_fwd(const float* imnet_out, const float* pred, const float* feat_lr,
                           const int32_t* iy, const int32_t* ix, const float* alpha, float flow_scale,
-                          float* acc, int B, int N, int H, int W, int HH, int WW, void* stream);
+                          float* acc, int B, int N, int H, int W, int HH, int WW, int row0, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * B1-B4  space-time local implicit MLPs (SIREN, omega0=30) with the nearest gather fused in.

@@ -25,7 +25,7 @@ _SIGS = {
     "motif_abi_version": (c_int, []),
     "motif_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
     "motif_splat_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
-    "motif_splat_motif_fwd": (c_int, [P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "motif_splat_motif_fwd": (c_int, [P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_siren_pack": (c_long, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), c_int, P, P]),
     "motif_siren_pack_split": (c_long, [c_int, POINTER(c_void_p), POINTER(c_void_p), P, P]),
     "motif_siren_imnet_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

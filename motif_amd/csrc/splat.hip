@@ -131,6 +131,8 @@ struct MotifSplatArgs {
     const int32_t* iy; const int32_t* ix; const float* alpha;
     float s20, sr; float* acc;
     int B, N, H, W, HH, WW, R;
+    int row0;      // image row of local row 0 (row-band rendering): float coordinates are formed with GLOBAL rows so that
+                   // floor() and the bilinear weights are bit-identical to the untiled render
 };
 
 struct SrcGeom {
@@ -147,12 +149,13 @@ __device__ __forceinline__ SrcGeom src_geom(const MotifSplatArgs& a, int img, in
     g.p0 = a.pred[((long)img * 3 + 0) * Q + p];
     g.p1 = a.pred[((long)img * 3 + 1) * Q + p];
     const float fx = (g.p0 * a.s20) * a.sr, fy = (g.p1 * a.s20) * a.sr;          // Ours.py:794
-    const float ox = (float)x + fx, oy = (float)y + fy;
+    const float yg = (float)(y + a.row0);
+    const float ox = (float)x + fx, oy = yg + fy;
     const float flx = floorf(ox), fly = floorf(oy);
     const float R = (float)a.R;
-    g.near_ = (flx >= (float)x - R) && (flx + 1.f <= (float)x + R) && (fly >= (float)y - R) && (fly + 1.f <= (float)y + R);
+    g.near_ = (flx >= (float)x - R) && (flx + 1.f <= (float)x + R) && (fly >= yg - R) && (fly + 1.f <= yg + R);
     g.x0 = g.near_ ? (int)flx : 0;
-    g.y0 = g.near_ ? (int)fly : 0;
+    g.y0 = g.near_ ? (int)fly - a.row0 : 0;
     const float xe = flx + 1.f, ye = fly + 1.f;
     g.wnw = (xe - ox) * (ye - oy);
     g.wne = (ox - flx) * (ye - oy);
@@ -309,10 +312,12 @@ __global__ __launch_bounds__(256) void splat_far_kernel(MotifSplatArgs a, int ti
     const float e = expf((p2 > 0.f ? p2 : 0.f) * a.alpha[0]);
     const float fx = (p0 * a.s20) * a.sr, fy = (p1 * a.s20) * a.sr;
     Scatter s;
-    const float ox = (float)X + fx, oy = (float)Y + fy;
+    const float ox = (float)X + fx, oy = (float)(Y + a.row0) + fy;
     // far targets may be anywhere (or nowhere): clamp before the int conversion, bounds tests do the rest
-    if (!(ox > -4.f && ox < (float)a.WW + 4.f && oy > -4.f && oy < (float)a.HH + 4.f)) return;
-    s.init(corners_of(X, Y, fx, fy), a.HH, a.WW);
+    if (!(ox > -4.f && ox < (float)a.WW + 4.f && oy > (float)a.row0 - 4.f && oy < (float)(a.row0 + a.HH) + 4.f)) return;
+    Corners cn = corners_of(X, Y + a.row0, fx, fy);
+    cn.y0 -= a.row0;
+    s.init(cn, a.HH, a.WW);
     float* abase = a.acc + (long)(b * a.N + n) * 133 * Q;
     const long lr = (long)a.iy[Y] * a.W + a.ix[X];
     for (int c = 0; c < 130; ++c) {
@@ -330,10 +335,10 @@ __global__ __launch_bounds__(256) void splat_far_kernel(MotifSplatArgs a, int ti
 
 extern "C" int motif_splat_motif_fwd(const float* imnet_out, const float* pred, const float* feat_lr,
                                      const int32_t* iy, const int32_t* ix, const float* alpha, float flow_scale,
-                                     float* acc, int B, int N, int H, int W, int HH, int WW, void* stream) {
+                                     float* acc, int B, int N, int H, int W, int HH, int WW, int row0, void* stream) {
     if (!imnet_out || !pred || !feat_lr || !iy || !ix || !alpha || !acc) return MOTIF_EINVAL;
-    if (B < 1 || N < 1 || H < 1 || W < 1 || HH < 1 || WW < 1) return MOTIF_EINVAL;
-    MotifSplatArgs a{imnet_out, pred, feat_lr, iy, ix, alpha, 20.0f, flow_scale, acc, B, N, H, W, HH, WW, 16};
+    if (B < 1 || N < 1 || H < 1 || W < 1 || HH < 1 || WW < 1 || row0 < 0) return MOTIF_EINVAL;
+    MotifSplatArgs a{imnet_out, pred, feat_lr, iy, ix, alpha, 20.0f, flow_scale, acc, B, N, H, W, HH, WW, 16, row0};
     const int cap = 2 * (OT_H + 2 * a.R) * (OT_W + 2 * a.R);
     const size_t lds = (size_t)OT_CC * OT_TP * 8 + (size_t)cap * 4;
     hipError_t e = hipFuncSetAttribute((const void*)splat_owner_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -340,6 +340,11 @@ class LunaTokis(nn.Module):
         self.shuffle = Conv2d(channel, channel, 1, 1, 0)
         self.skip_zero_pairs = True
         self.overlap_raft = True
+        # spatial tiling of the HR half (BASELINE config 5): render HR rows [r0, r1) only; the
+        # band is extended by `band_halo` rows on each side, everything HR is recomputed there (nothing is exchanged)
+        self.band = None
+        self.band_halo = 64
+        self.last_max_flow_y = None
         self._side_stream = None
         self._cache_key, self._cache = None, None
 
@@ -393,8 +398,10 @@ class LunaTokis(nn.Module):
         # the gathered-LR-feature part of each MLP's first layer does not depend on the HR pixel or on t:
         # evaluate it once per clip at LR resolution (1x1 convs), the HR kernels start from it (pre=1)
         split = ops.get_siren_mma() == ops.MMA_BF16X3
-        imnet_out = ops.siren_imnet(self.imnet.packed_split(ops.SIREN_IMNET) if split else self.imnet.packed(),
-                                    ops.conv2d(self.imnet.l0_plan(0, 64), feat01), iy, ix, rel_y, rel_x, HH, WW, pre=2 if split else 1)
+        imnet_out = None                                                        # band mode renders it per band
+        if self.band is None:
+            imnet_out = ops.siren_imnet(self.imnet.packed_split(ops.SIREN_IMNET) if split else self.imnet.packed(),
+                                        ops.conv2d(self.imnet.l0_plan(0, 64), feat01), iy, ix, rel_y, rel_x, HH, WW, pre=2 if split else 1)
         flow_l0 = ops.conv2d(self.flow_imnet.l0_plan(0, 64), flow_feat)
         synth_l0 = ops.conv2d(self.synth_net.l0_plan(133, 197), residual)
         return dict(flow_l0=flow_l0, synth_l0=synth_l0, flow=flow, psies=psies, flow_feat_in=flow_feat_in, feat=feat, residual=residual, feat01=feat01,
@@ -402,6 +409,33 @@ class LunaTokis(nn.Module):
 
     def clear_cache(self):
         self._cache_key, self._cache = None, None
+
+    def _forward_band(self, c, times, B, N, H, HH, WW, flow_blob, synth_blob, pre, stages):
+        """HR rows [r0, r1) of the output.  The HR kernels run on the row range [e0, e1) = the band extended by
+        `band_halo` rows (clipped to the image) as if it were an image of e1-e0 rows: the gather / rel_coord tables are
+        sliced, so every per-pixel value equals the untiled one, and the owner-computes splat sees every source within
+        `band_halo` rows of the band.  Exact as long as max |flow_y| + 1 <= band_halo; `last_max_flow_y` (device scalar,
+        over the band's own rows, in HR pixels) lets the caller verify that over all bands."""
+        r0, r1 = self.band
+        if not (0 <= r0 < r1 <= HH):
+            raise ValueError("band %r outside [0, %d)" % (self.band, HH))
+        e0, e1 = max(0, r0 - self.band_halo), min(HH, r1 + self.band_halo)
+        iy, ix, rel_y, rel_x = c["tables"]
+        iyb, ryb, HHb = iy[e0:e1].contiguous(), rel_y[e0:e1].contiguous(), e1 - e0
+        bkey = ("imnet_band", e0, e1)
+        if bkey not in c:                                                       # t-independent, cached per band
+            split = pre == 2
+            c[bkey] = ops.siren_imnet(self.imnet.packed_split(ops.SIREN_IMNET) if split else self.imnet.packed(),
+                                      ops.conv2d(self.imnet.l0_plan(0, 64), c["feat01"]), iyb, ix, ryb, rel_x, HHb, WW, pre=pre)
+        pred = ops.siren_flow(flow_blob, c["flow_l0"], iyb, ix, ryb, rel_x, times, N, HHb, WW, pre=pre)
+        acc = ops.splat_motif(c[bkey], pred, c["feat01"], iyb, ix, self.alpha, HH / H, B, N, HHb, WW, row0=e0)
+        frames = ops.siren_synth(synth_blob, acc, c["synth_l0"], iyb, ix, times, B, N, HHb, WW, pre=pre)
+        lo, hi = r0 - e0, r1 - e0
+        flow_hr = pred[:, :2, lo:hi]
+        self.last_max_flow_y = (flow_hr[:, 1].abs().max() * 20.0 * (HH / H)).detach()
+        if stages is not None:
+            stages.update(pred=pred, acc=acc, rows=(e0, e1))
+        return frames[..., lo:hi, :].contiguous(), flow_hr.contiguous(), 0
 
     # ----------------------------------------------------------------------------- forward
     def forward(self, x, input_target_frames, target_t, scale=None, rank=0, train_idx=0, use_GT=True, iter=12, flows=None,
@@ -419,7 +453,7 @@ class LunaTokis(nn.Module):
         else:
             HH, WW = round(H * scale), round(W * scale)
         # the cached clip tensor is kept alive, so its address cannot be recycled for another clip
-        key = (x.data_ptr(), x._version, tuple(x.shape), HH, WW, iter)
+        key = (x.data_ptr(), x._version, tuple(x.shape), HH, WW, iter, self.band is None)
         if key != self._cache_key:
             self._cache, self._cache_key = self._clip_stage(x, HH, WW, iter), key
             self._cache["x"] = x
@@ -427,11 +461,14 @@ class LunaTokis(nn.Module):
         iy, ix, rel_y, rel_x = c["tables"]
         times = target_t.contiguous()                                           # [B,N]
         split = ops.get_siren_mma() == ops.MMA_BF16X3
-        pred = ops.siren_flow(self.flow_imnet.packed_split(ops.SIREN_FLOW) if split else self.flow_imnet.packed(), c["flow_l0"],
-                              iy, ix, rel_y, rel_x, times, N, HH, WW, pre=2 if split else 1)   # [2BN,3,HH,WW]
+        flow_blob = self.flow_imnet.packed_split(ops.SIREN_FLOW) if split else self.flow_imnet.packed()
+        synth_blob = self.synth_net.packed_split(ops.SIREN_SYNTH) if split else self.synth_net.packed()
+        pre = 2 if split else 1
+        if self.band is not None:
+            return self._forward_band(c, times, B, N, H, HH, WW, flow_blob, synth_blob, pre, stages)
+        pred = ops.siren_flow(flow_blob, c["flow_l0"], iy, ix, rel_y, rel_x, times, N, HH, WW, pre=pre)   # [2BN,3,HH,WW]
         acc = ops.splat_motif(c["imnet_out"], pred, c["feat01"], iy, ix, self.alpha, HH / H, B, N, HH, WW)
-        frames = ops.siren_synth(self.synth_net.packed_split(ops.SIREN_SYNTH) if split else self.synth_net.packed(), acc,
-                                 c["synth_l0"], iy, ix, times, B, N, HH, WW, pre=2 if split else 1)
+        frames = ops.siren_synth(synth_blob, acc, c["synth_l0"], iy, ix, times, B, N, HH, WW, pre=pre)
         if stages is not None:
             stages.update(c)
             stages.update(pred=pred, acc=acc)

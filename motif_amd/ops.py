@@ -403,7 +403,7 @@ def splat(src, flow, z=None, want=("sum", "norm")):
     return outs
 
 
-def splat_motif(imnet_out, pred, feat_lr, iy, ix, alpha, flow_scale, B, N, HH, WW, acc=None):
+def splat_motif(imnet_out, pred, feat_lr, iy, ix, alpha, flow_scale, B, N, HH, WW, acc=None, row0=0):
     lib = _lib.load()
     feat_lr = _c(feat_lr)
     _, _, h, w = feat_lr.shape
@@ -411,7 +411,7 @@ def splat_motif(imnet_out, pred, feat_lr, iy, ix, alpha, flow_scale, B, N, HH, W
         acc = torch.empty(B * N, 133, HH, WW, dtype=torch.float32, device=pred.device)
     # no zero fill: the owner-computes kernel writes every accumulator cell (max plane starts at 1)
     check(lib.motif_splat_motif_fwd(_p(imnet_out), _p(pred), _p(feat_lr), _p(iy), _p(ix), _p(alpha.detach()), float(flow_scale), _p(acc),
-                                    B, N, h, w, HH, WW, _stream()), "motif_splat_motif_fwd")
+                                    B, N, h, w, HH, WW, int(row0), _stream()), "motif_splat_motif_fwd")
     return acc
 
 

@@ -178,3 +178,46 @@ dist.destroy_process_group()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29533", str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "GATHER_OK [0, 2, 4]" in r.stdout, r.stdout + r.stderr
+
+
+def test_row_band_tile_driver_over_gloo_world2(tmp_path):
+    """motif_amd.dist.render_clip_tiled (one clip, HR row bands over ranks) with a stand-in renderer: band split,
+    halo retry after the MAX all-reduce, uint8 band gather to rank 0."""
+    script = tmp_path / "t.py"
+    script.write_text('''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from motif_amd import dist as md
+dist.init_process_group("gloo")
+r, w = md.world()
+HH, WW = 104, 16
+
+class FakeNet:
+    band, band_halo, last_max_flow_y, calls = None, 64, None, []
+    def __call__(self, x, _, times, scale, use_GT=False, iter=4):
+        r0, r1 = self.band
+        self.calls.append((self.band, self.band_halo))
+        rows = torch.arange(r0, r1, dtype=torch.float32).view(1, 1, 1, -1, 1)
+        t = torch.stack([tt[0, 0] for tt in times]).view(-1, 1, 1, 1, 1)
+        self.last_max_flow_y = torch.tensor(20.0 if r == 1 else 3.0)          # rank 1 sees a 20 px motion
+        return ((rows %% 251) / 255.0 + 0 * t).expand(len(times), 1, 3, r1 - r0, WW), None, 0
+
+net = FakeNet()
+x = torch.zeros(1, 4, 3, 26, 4)
+times = [torch.full((1, 1), i / 4) for i in range(5)]
+out = md.render_clip_tiled(net, x, times, [[HH], [WW]], halo=16)
+assert net.band is None
+assert [c[1] for c in net.calls] == [16, 16, 32, 32], net.calls           # 2 chunks per attempt, halo doubled once
+assert net.calls[0][0] == md.band_of(HH, r, w, 8)
+if r == 0:
+    assert out.shape == (5, 1, 3, HH, WW) and out.dtype == torch.uint8
+    assert [int(v) for v in out[0, 0, 0, :, 0]] == [i %% 251 for i in range(HH)]
+    print("TILED_OK", md.band_of(HH, 0, w, 8), md.band_of(HH, 1, w, 8))
+else:
+    assert out is None
+dist.destroy_process_group()
+''' % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29537", str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "TILED_OK (0, 56) (56, 104)" in r.stdout, r.stdout + r.stderr
