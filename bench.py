@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--times", type=int, default=7)
     ap.add_argument("--mma", choices=["bf16x3", "fp32"], default="bf16x3", help="arithmetic of the dense contractions")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the secondary fp32-MFMA measurement")
+    ap.add_argument("--streams", type=int, default=1, help="clips in flight per GPU (each on its own HIP stream and model instance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -156,6 +157,13 @@ def main():
     h, w = a.lr
     model = create_model(default_opt(scale=a.scale, gpu_ids=[local], mma=a.mma))
     fill_state_dict(model.netG)
+    # --streams S: S clips in flight per GPU, each on its own stream with its own model instance (same weights)
+    models, streams = [model], [torch.cuda.current_stream()]
+    for _ in range(1, a.streams):
+        m = create_model(default_opt(scale=a.scale, gpu_ids=[local], mma=a.mma))
+        fill_state_dict(m.netG)
+        models.append(m)
+        streams.append(torch.cuda.Stream())
     HH, WW = h * a.scale, w * a.scale
     # two distinct clips per rank, resident in HBM before the timed region
     clips = []
@@ -165,12 +173,14 @@ def main():
         clips.append(s)
 
     def step(i):
-        model.feed_data(clips[i % 2])
-        model.test()
-        if world > 1:
-            u8 = mdist.frames_to_uint8(model.fake_H.permute(1, 0, 2, 3, 4))       # [B,T,3,HH,WW] = this rank's clip
-            mdist.gather_to_rank0(u8, world)
-        return model.fake_H
+        m = models[i % len(models)]
+        with torch.cuda.stream(streams[i % len(models)]):
+            m.feed_data(clips[i % 2])
+            m.test()
+            if world > 1:
+                u8 = mdist.frames_to_uint8(m.fake_H.permute(1, 0, 2, 3, 4))       # [B,T,3,HH,WW] = this rank's clip
+                mdist.gather_to_rank0(u8, world)
+        return m.fake_H
 
     def fence():
         torch.cuda.synchronize()

@@ -32,6 +32,45 @@ __device__ __forceinline__ float act_c(float v) {
     else return v;
 }
 
+// The activation / residual mode is block-uniform: dispatch ONCE to a specialised body `run(actf, res_tag)`;
+// actf(v, residual, cout) -> stored value, res_tag = std::true_type when a residual tensor is read.
+template <class RUN>
+__device__ __forceinline__ void conv_act_dispatch(const ConvArgs& a, RUN&& run) {
+    auto run_rm = [&](auto actf) {
+        if (a.res_mode) run(actf, std::true_type{}); else run(actf, std::false_type{});
+    };
+    const int rm = a.res_mode;
+    if (a.act_split > 0) {
+        run_rm([&](float v, float rv, int co) {
+            const int act = co >= a.act_split ? a.act2 : a.act;
+            if (rm == 1) return act_apply(v + rv, act);
+            float y = act_apply(v, act);
+            if (rm == 2) y += rv; else if (rm == 3) { y += rv; y = y > 0.f ? y : 0.f; } else if (rm == 4) y *= rv;
+            return y;
+        });
+    } else if (rm == 0) {
+        switch (a.act) {
+            case MOTIF_ACT_RELU: run([](float v, float, int) { return act_c<MOTIF_ACT_RELU>(v); }, std::false_type{}); break;
+            case MOTIF_ACT_LRELU: run([](float v, float, int) { return act_c<MOTIF_ACT_LRELU>(v); }, std::false_type{}); break;
+            case MOTIF_ACT_SIGMOID: run([](float v, float, int) { return act_c<MOTIF_ACT_SIGMOID>(v); }, std::false_type{}); break;
+            case MOTIF_ACT_TANH: run([](float v, float, int) { return act_c<MOTIF_ACT_TANH>(v); }, std::false_type{}); break;
+            default: run([](float v, float, int) { return v; }, std::false_type{}); break;
+        }
+    } else if (rm == 1 && a.act == MOTIF_ACT_NONE) {
+        run([](float v, float rv, int) { return v + rv; }, std::true_type{});
+    } else if (rm == 1 && a.act == MOTIF_ACT_LRELU) {
+        run([](float v, float rv, int) { return act_c<MOTIF_ACT_LRELU>(v + rv); }, std::true_type{});
+    } else {
+        const int act = a.act;
+        run_rm([&](float v, float rv, int) {
+            if (rm == 1) return act_apply(v + rv, act);
+            float y = act_apply(v, act);
+            if (rm == 2) y += rv; else if (rm == 3) { y += rv; y = y > 0.f ? y : 0.f; } else if (rm == 4) y *= rv;
+            return y;
+        });
+    }
+}
+
 // Epilogue of one wave: acc[i][j] = 32 couts (tile i of the block's cout group) x 32 pixels of output row oy0+j,
 // column ox.  `a_*` are the per-problem pointers/strides, bias_s the LDS copy of the cout group's bias.
 template <int NC, int RPW>
@@ -111,39 +150,53 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
             }
         }
     };
-    auto run_rm = [&](auto actf) {
-        if (a.res_mode) run(actf, std::true_type{}); else run(actf, std::false_type{});
-    };
-    const int rm = a.res_mode;
-    if (a.act_split > 0) {
-        run_rm([&](float v, float rv, int co) {
-            const int act = co >= a.act_split ? a.act2 : a.act;
-            if (rm == 1) return act_apply(v + rv, act);
-            float y = act_apply(v, act);
-            if (rm == 2) y += rv; else if (rm == 3) { y += rv; y = y > 0.f ? y : 0.f; } else if (rm == 4) y *= rv;
-            return y;
-        });
-    } else if (rm == 0) {
-        switch (a.act) {
-            case MOTIF_ACT_RELU: run([](float v, float, int) { return act_c<MOTIF_ACT_RELU>(v); }, std::false_type{}); break;
-            case MOTIF_ACT_LRELU: run([](float v, float, int) { return act_c<MOTIF_ACT_LRELU>(v); }, std::false_type{}); break;
-            case MOTIF_ACT_SIGMOID: run([](float v, float, int) { return act_c<MOTIF_ACT_SIGMOID>(v); }, std::false_type{}); break;
-            case MOTIF_ACT_TANH: run([](float v, float, int) { return act_c<MOTIF_ACT_TANH>(v); }, std::false_type{}); break;
-            default: run([](float v, float, int) { return v; }, std::false_type{}); break;
+    conv_act_dispatch(a, run);
+}
+
+// Block-cooperative epilogue through LDS: the accumulators of one 32-cout tile are transposed in `scratch`
+// ([32 couts][TH*32 pixels], row stride +8 floats so the two half-waves hit different banks), then every thread
+// finishes 8 groups of 4 consecutive pixels of one cout: bias, residual (one 16-byte load), activation, one 16-byte
+// store -- 16 store instructions per lane instead of 64.  Needs a full cout group, Wo % 4 == 0 and 16-byte aligned
+// tensors (checked by the caller, block-uniform); `scratch` must hold 32 * (TH*32 + 8) floats and be free.
+template <int NC, int RPW, int WAVES>
+__device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&acc)[NC][RPW], const float* bias_s, float* scratch,
+                                                  int n, int g, int cg, int ty, int tx, const float* a_res, long a_res_bs,
+                                                  float* a_out, long a_out_bs) {
+    constexpr int TH = RPW * WAVES, NT = 64 * WAVES, S = TH * 32 + 8, WN = 32 * NC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const long HWo = (long)a.Ho * a.Wo;
+    const int cobase = g * a.Cout_g + cg * WN;
+    float* ob = a_out + (long)n * a_out_bs + (long)cobase * HWo;
+    const float* rb = a.res_mode ? a_res + (long)n * a_res_bs + (long)cobase * HWo : nullptr;
+    conv_act_dispatch(a, [&](auto actf, auto res_tag) {
+        constexpr bool RES = decltype(res_tag)::value;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            __syncthreads();                                   // scratch free (main loop / previous tile done)
+#pragma unroll
+            for (int j = 0; j < RPW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    scratch[((r & 3) + 8 * (r >> 2) + 4 * half) * S + (RPW * wave + j) * 32 + l31] = acc[i][j][r];
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = tid + NT * it;
+                const int co = idx / (TH * 8), q = idx - co * (TH * 8);
+                const int row = q >> 3, col = (q & 7) * 4;
+                const int oy = ty * TH + row, ox = tx * 32 + col;
+                if (oy >= a.Ho || ox >= a.Wo) continue;
+                f32x4 v = *(const f32x4*)(scratch + co * S + row * 32 + col);
+                const float b = bias_s[i * 32 + co];
+                const long off = (long)(i * 32 + co) * HWo + (long)oy * a.Wo + ox;
+                f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (RES) rv = *(const f32x4*)(rb + off);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = actf(v[u] + b, rv[u], cobase + i * 32 + co);
+                *(f32x4*)(ob + off) = v;
+            }
         }
-    } else if (rm == 1 && a.act == MOTIF_ACT_NONE) {
-        run([](float v, float rv, int) { return v + rv; }, std::true_type{});
-    } else if (rm == 1 && a.act == MOTIF_ACT_LRELU) {
-        run([](float v, float rv, int) { return act_c<MOTIF_ACT_LRELU>(v + rv); }, std::true_type{});
-    } else {
-        const int act = a.act;
-        run_rm([&](float v, float rv, int) {
-            if (rm == 1) return act_apply(v + rv, act);
-            float y = act_apply(v, act);
-            if (rm == 2) y += rv; else if (rm == 3) { y += rv; y = y > 0.f ? y : 0.f; } else if (rm == 4) y *= rv;
-            return y;
-        });
-    }
+    });
 }
 
 // split engine (conv_split.hip)

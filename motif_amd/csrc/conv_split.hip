@@ -74,8 +74,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
     constexpr int NI = (2 * PHW + NT - 1) / NT;          // (pixel, channel octet) items a thread stages per chunk
     using PR = SplitProducts<NP>;
     constexpr int SLOTS = 2 * PHW + 4;                   // per (buffer, part): [2 octets][PHW] 16-byte slots + dummy
-    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // [2 buffers][NP][SLOTS]
-    float* bias_s = (float*)(lds + 2 * NP * SLOTS);
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds_raw[];
+    float* bias_s = (float*)lds_raw;                     // [64] bias of this cout group
+    u32x4* lds = lds_raw + 16;                           // [2 buffers][NP][SLOTS]; reused by the epilogue transpose
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
     const int g = blockIdx.y / a.ncg, cg = blockIdx.y % a.ncg;
@@ -212,7 +213,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
     };
     for (int chunk = 0; chunk + 1 < nch; ++chunk) chunk_body(chunk, std::true_type{});
     chunk_body(nch - 1, std::false_type{});
-    conv_epilogue<NC, RP>(a, acc, bias_s, n, g, cg, ty * TH + RP * wave, tx * 32 + l31, half, a_res, a_res_bs, a_out, a_out_bs);
+    // 16-byte stores through an LDS transpose when the layout allows it (block-uniform test), else per-lane stores
+    const bool vec_ok = !(a.dbg & 4) && a.Cout_g - cg * 64 >= 64 && (a.Wo & 3) == 0 && (a_out_bs & 3) == 0 &&
+                        (((unsigned long long)a_out) & 15) == 0 &&
+                        (!a.res_mode || ((a_res_bs & 3) == 0 && (((unsigned long long)a_res) & 15) == 0)) && !(a.dbg & 32);
+    if (vec_ok)
+        conv_epilogue_lds<NC, RP, WAVES>(a, acc, bias_s, (float*)lds, n, g, cg, ty, tx, a_res, a_res_bs, a_out, a_out_bs);
+    else
+        conv_epilogue<NC, RP>(a, acc, bias_s, n, g, cg, ty * TH + RP * wave, tx * 32 + l31, half, a_res, a_res_bs, a_out, a_out_bs);
     TRACE(14);
     __builtin_amdgcn_s_waitcnt(0);
     TRACE(15);
@@ -284,7 +292,9 @@ int motif_conv_split_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStrea
     int waves = 4;
     if (const char* e = getenv("MOTIF_SPLIT_WAVES")) { const int w = atoi(e); if (w == 8 || w == 2) waves = w; }
     const int TH = 2 * waves, tiles_y = (Ho + TH - 1) / TH;
-    const size_t ldsb = (size_t)2 * NP * (2 * (TH + 2) * 34 + 4) * 16 + 64 * 4;
+    size_t ldsb = (size_t)2 * NP * (2 * (TH + 2) * 34 + 4) * 16;
+    const size_t scratch = (size_t)32 * (TH * 32 + 8) * 4;                      // epilogue transpose of one 32-cout tile
+    ldsb = (ldsb > scratch ? ldsb : scratch) + 64 * 4;
     dim3 grid(a.tiles_x * tiles_y, d->groups * a.ncg, d->N * P);
 #define MOTIF_LAUNCH_SPLIT(NPV, WV)                                                                                     \
     do {                                                                                                                \

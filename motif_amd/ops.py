@@ -224,7 +224,8 @@ _ws = {}
 
 
 def workspace(numel, device, tag="default"):
-    key = (tag, str(device))
+    """Scratch buffer per (tag, device, current stream): clips in flight on different streams never share one."""
+    key = (tag, str(device), torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
     buf = _ws.get(key)
     if buf is None or buf.numel() < numel:
         buf = torch.empty(numel, dtype=torch.float32, device=device)
