@@ -4,6 +4,7 @@
 // (deformable group, tap, pixel) and reused for the group's channels; the reference recomputes them per
 // channel (dcn_v2_im2col_cuda.cu:125-194).
 #include "common.h"
+#include <stdlib.h>
 
 struct DcnArgs {
     const float* im[4]; const float* offset[4]; const float* mask[4];
@@ -127,11 +128,15 @@ struct DcnFusedArgs {
 #define DF_CH 4             // channels per chunk
 #define DF_ROWS (DF_CH * 9) // K rows per chunk
 
-__global__ __launch_bounds__(512) void dcn_fused_kernel(DcnFusedArgs a) {
+// WAVES = output rows per block (one wave per row of 32 pixels): 8 -> one 92 KB block per CU; 4 -> two 55 KB blocks per
+// CU whose gather latencies and MFMA stretches overlap each other.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void dcn_fused_kernel(DcnFusedArgs a) {
+    constexpr int NPX = 32 * WAVES, NT = 64 * WAVES;       // pixels per tile, threads
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int WN = 64;
-    float* col0 = smem;                                  // [2][DF_ROWS][256]
-    float* wl0 = col0 + 2 * DF_ROWS * 256;               // [2][DF_ROWS][WN]
+    float* col0 = smem;                                  // [2][DF_ROWS][NPX]
+    float* wl0 = col0 + 2 * DF_ROWS * NPX;               // [2][DF_ROWS][WN]
     float* bias_s = wl0 + 2 * DF_ROWS * WN;              // [WN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
@@ -146,11 +151,11 @@ __global__ __launch_bounds__(512) void dcn_fused_kernel(DcnFusedArgs a) {
     const int cpg = a.C / a.dg;
 
     // this thread's pixel and taps
-    const int pxl = tid & 255;                           // pixel index in the tile: row pxl>>5, column pxl&31
-    const int oy = ty * 8 + (pxl >> 5), ox = tx * 32 + (pxl & 31);
+    const int pxl = tid % NPX;                           // pixel index in the tile: row pxl>>5, column pxl&31
+    const int oy = ty * WAVES + (pxl >> 5), ox = tx * 32 + (pxl & 31);
     const bool pix_ok = oy < H && ox < W;
     const long p = (long)oy * W + ox;
-    const int tap0 = tid >> 8;                           // taps tap0, tap0+2, ...
+    const int tap0 = tid / NPX;                          // taps tap0, tap0+2, ...
 
     if (tid < WN) {
         const int col = cg * WN + tid;
@@ -193,7 +198,8 @@ __global__ __launch_bounds__(512) void dcn_fused_kernel(DcnFusedArgs a) {
     };
 
     float pre[DF_PAIRS][DF_CH][4];
-    f32x4 wreg[2];
+    constexpr int NWR = (DF_ROWS * 64 / 4 + NT - 1) / NT;
+    f32x4 wreg[NWR];
     auto issue = [&](int c0) {                           // corner values of channels c0..c0+3 for my pairs; weight rows
 #pragma unroll
         for (int j = 0; j < DF_PAIRS; ++j) {
@@ -209,13 +215,13 @@ __global__ __launch_bounds__(512) void dcn_fused_kernel(DcnFusedArgs a) {
         }
         const f32x4* src = (const f32x4*)(wbase + (long)c0 * 9 * WN);       // rows (c0/2*9*2 ...) = c0*9
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i = tid + 512 * j;
+        for (int j = 0; j < NWR; ++j) {
+            const int i = tid + NT * j;
             if (i < DF_ROWS * WN / 4) wreg[j] = src[i];
         }
     };
     auto commit = [&](int buf) {
-        float* col = col0 + buf * DF_ROWS * 256;
+        float* col = col0 + buf * DF_ROWS * NPX;
 #pragma unroll
         for (int j = 0; j < DF_PAIRS; ++j) {
             const int tap = tap0 + 2 * j;
@@ -223,14 +229,14 @@ __global__ __launch_bounds__(512) void dcn_fused_kernel(DcnFusedArgs a) {
 #pragma unroll
                 for (int cl = 0; cl < DF_CH; ++cl) {
                     const float val = (gw1[j] * pre[j][cl][0] + gw2[j] * pre[j][cl][1] + gw3[j] * pre[j][cl][2] + gw4[j] * pre[j][cl][3]);
-                    col[(((cl >> 1) * 9 + tap) * 2 + (cl & 1)) * 256 + pxl] = val * gm[j];
+                    col[(((cl >> 1) * 9 + tap) * 2 + (cl & 1)) * NPX + pxl] = val * gm[j];
                 }
             }
         }
         f32x4* w4 = (f32x4*)(wl0 + buf * DF_ROWS * WN);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i = tid + 512 * j;
+        for (int j = 0; j < NWR; ++j) {
+            const int i = tid + NT * j;
             if (i < DF_ROWS * WN / 4) w4[i] = wreg[j];
         }
     };
@@ -248,14 +254,14 @@ __global__ __launch_bounds__(512) void dcn_fused_kernel(DcnFusedArgs a) {
             if (cnext % cpg == 0) geometry(cnext / cpg);      // next chunk starts a new deformable group
             issue(cnext);
         }
-        const float* colb = col0 + cur * DF_ROWS * 256 + half * 256 + wave * 32 + l31;
+        const float* colb = col0 + cur * DF_ROWS * NPX + half * NPX + wave * 32 + l31;
         const float* wl = wl0 + cur * DF_ROWS * WN + half * WN + l31;
 #pragma unroll
         for (int cp = 0; cp < DF_CH / 2; ++cp) {
             float bv[9], av[9][2];
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                bv[t] = colb[(cp * 9 + t) * 2 * 256];
+                bv[t] = colb[(cp * 9 + t) * 2 * NPX];
                 av[t][0] = wl[(cp * 9 + t) * 2 * WN];
                 av[t][1] = wl[(cp * 9 + t) * 2 * WN + 32];
             }
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(512) void dcn_fused_kernel(DcnFusedArgs a) {
     }
 
     // epilogue (C/D layout: column = pixel lane&31, row = (r&3) + 8*(r>>2) + 4*half)
-    const int eox = tx * 32 + l31, eoy = ty * 8 + wave;
+    const int eox = tx * 32 + l31, eoy = ty * WAVES + wave;
     if (eox >= W || eoy >= H) return;
     float* op = a.out[pz] + ((long)b * a.Cout + (long)cg * WN) * HW + (long)eoy * W + eox;
     const int climit = a.Cout - cg * WN;
@@ -309,11 +315,20 @@ extern "C" int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, co
     a.ncg = (Cout + 63) / 64;
     a.Kpad = 2 * 9 * ((C + 1) / 2);
     a.tiles_x = (W + 31) / 32;
-    const size_t lds = (size_t)(2 * DF_ROWS * 256 + 2 * DF_ROWS * 64 + 64) * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)dcn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    dim3 grid(a.tiles_x * ((H + 7) / 8), a.ncg, P * B);
-    dcn_fused_kernel<<<grid, 512, lds, (hipStream_t)stream>>>(a);
+    int waves = 4;
+    if (const char* ev = getenv("MOTIF_DCN_WAVES")) waves = atoi(ev) == 8 ? 8 : 4;
+    const size_t lds = (size_t)(2 * DF_ROWS * 32 * waves + 2 * DF_ROWS * 64 + 64) * 4;
+    dim3 grid(a.tiles_x * ((H + waves - 1) / waves), a.ncg, P * B);
+    hipError_t e;
+    if (waves == 8) {
+        e = hipFuncSetAttribute((const void*)dcn_fused_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        dcn_fused_kernel<8><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+    } else {
+        e = hipFuncSetAttribute((const void*)dcn_fused_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        dcn_fused_kernel<4><<<grid, 256, lds, (hipStream_t)stream>>>(a);
+    }
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

@@ -235,24 +235,9 @@ def workspace(numel, device, tag="default"):
 
 def dcn_v2(dplan, x, offset_mask, dg=8, act=ACT_NONE, kh=3, kw=3, stride=1, pad=1, dil=1):
     """x [B,C,H,W]; offset_mask [B, 3*dg*kh*kw, Ho, Wo] = conv_offset_mask output with the mask third
-    already sigmoid'ed (chunk/cat of dcn_v2.py:131-138 is a no-op on the channel order)."""
-    lib = _lib.load()
-    x = _c(x)
-    offset_mask = _c(offset_mask)
-    b, c, h, w = x.shape
-    co = dplan.weight.shape[0]
-    ho = (h + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
-    wo = (w + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
-    t = kh * kw
-    cols = workspace(b * c * t * ho * wo, x.device, "dcn_cols")
-    out = torch.empty(b, co, ho, wo, dtype=torch.float32, device=x.device)
-    plan = dplan.plan()
-    mask = offset_mask[:, 2 * dg * t:]
-    bs = offset_mask.stride(0)
-    bias = dplan.bias.detach() if dplan.bias is not None else None
-    check(lib.motif_dcn_v2_fwd(_p(x), _p(offset_mask), ctypes.c_void_p(mask.data_ptr()), _p(plan.packed()), _p(bias), _p(cols), _p(out),
-                               b, c, h, w, co, kh, kw, stride, pad, dil, dg, bs, bs, act, _stream()), "motif_dcn_v2_fwd")
-    return out
+    already sigmoid'ed (chunk/cat of dcn_v2.py:131-138 is a no-op on the channel order).  Same kernels as the
+    multi-problem form (fused deformable im2col + MFMA for the 3x3/s1/p1 configuration)."""
+    return dcn_v2_multi([dplan], [x], [offset_mask], dg, act, kh, kw, stride, pad, dil)[0]
 
 
 def dcn_v2_raw(x, offset, mask, weight, bias, kh, kw, stride, pad, dil, dg, act=ACT_NONE):
