@@ -295,6 +295,7 @@ int motif_conv_split_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStrea
     size_t ldsb = (size_t)2 * NP * (2 * (TH + 2) * 34 + 4) * 16;
     const size_t scratch = (size_t)32 * (TH * 32 + 8) * 4;                      // epilogue transpose of one 32-cout tile
     ldsb = (ldsb > scratch ? ldsb : scratch) + 64 * 4;
+    if (const char* e = getenv("MOTIF_LDS_PAD")) ldsb = (ldsb + atoi(e) - 1) / atoi(e) * atoi(e);
     dim3 grid(a.tiles_x * tiles_y, d->groups * a.ncg, d->N * P);
 #define MOTIF_LAUNCH_SPLIT(NPV, WV)                                                                                     \
     do {                                                                                                                \

@@ -1,0 +1,49 @@
+import sys, torch
+sys.path.insert(0, "/root/repo")
+from motif_amd import ops
+from motif_amd.data.synthetic import synthetic_sample
+from motif_amd.models.modules.Ours import LunaTokis
+from motif_amd.utils.synth_weights import fill_state_dict
+ops.set_mma("bf16x3")
+net = fill_state_dict(LunaTokis()).cuda().eval()
+s = synthetic_sample(180, 320, 4, 7)
+x = s["LQs"].cuda(); times = [t.cuda() for t in s["time"]]
+rec = None
+names = ["conv2d", "conv2d_multi", "dcn_v2_multi", "lstm_gates", "resize_bilinear", "axpby", "instance_norm", "raft_corr_lookup_pyramid", "gru_update", "reliability", "avg_pool2", "nchw_to_nhwc"]
+orig = {n: getattr(ops, n) for n in names if hasattr(ops, n)}
+def wrap(n):
+    f = orig[n]
+    def g(*a, **k):
+        out = f(*a, **k)
+        if rec is not None and torch.is_tensor(out):
+            rec.append((n, tuple(out.shape), torch.cuda.current_stream().cuda_stream, out.clone()))
+        return out
+    return g
+for n in orig: setattr(ops, n, wrap(n))
+# modules import ops functions by attribute (ops.conv2d) so patching the module attribute is enough
+runs = []
+with torch.no_grad():
+    for r in range(3):
+        net.clear_cache(); rec = []
+        o, f, _ = net(x, None, times[6:7], s["scale"], use_GT=False, iter=4)
+        torch.cuda.synchronize()
+        runs.append(rec); rec = None
+print("recorded", [len(r) for r in runs])
+main_id = torch.cuda.current_stream().cuda_stream
+for ri in (1, 2):
+    first = None
+    for i, (a, b) in enumerate(zip(runs[0], runs[ri])):
+        if a[0] != b[0] or a[1] != b[1]:
+            print("sequence differs at", i, a[:3], b[:3]); break
+        if not torch.equal(a[3], b[3]):
+            first = i; break
+    if first is None:
+        print("run", ri, "identical to run 0 in all recorded outputs")
+    else:
+        a, b = runs[0][first], runs[ri][first]
+        d = (a[3] - b[3]).abs()
+        nz = torch.nonzero(d > 0)
+        print("run", ri, "first differing op #%d: %s shape %s stream %s; n diff %d; max %.3e" % (first, a[0], a[1], "main" if a[2] == main_id else "side", nz.shape[0], float(d.max())))
+        print("   previous ops:", [(runs[0][j][0], runs[0][j][1], "main" if runs[0][j][2] == main_id else "side") for j in range(max(0, first - 4), first)])
+        for dim in range(nz.shape[1]):
+            u = torch.unique(nz[:, dim]); print("   dim", dim, "min", int(u.min()), "max", int(u.max()), "count", u.numel())
