@@ -68,6 +68,8 @@ extern "C" int motif_debug_trace(long long* host, int n) { return (int)hipMemcpy
 #define TRACE(slot)
 #endif
 
+// Tried and rejected: a thread-level-parallel variant (three blocks per CU at <= 168 VGPRs, one LDS buffer, weight
+// fragments just in time) -- 15-20 % slower than hiding the latencies inside the wave as below.
 template <int NP, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_split_kernel(ConvArgs a) {
     constexpr int RP = 2, NC = 2, NT = 64 * WAVES, TH = RP * WAVES, PH = TH + 2, PW = 34, PHW = PH * PW;
@@ -131,7 +133,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const bool ok = eoff[j] >= 0 && q < cvalid;               // branch-free: padding reads base[0] and is
-            pre[j][q] = base[ok ? eoff[j] + q * HW : 0];               // zeroed at commit time
+            const unsigned idx = ok ? (unsigned)(eoff[j] + q * HW) : 0u;   // zeroed at commit time; uniform base + 32-bit
+            pre[j][q] = base[idx];                                      // per-lane offset (one address VGPR per load)
         }
     };
     auto commit_item = [&](int j, int buf, int c0) {         // mask, split, registers -> LDS (branch-free)
