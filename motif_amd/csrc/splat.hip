@@ -9,7 +9,6 @@
 // Bit-level contract with the kernel text (softsplat_cp.py:27-38 etc.): floor -> int corners, weights
 // as (SE - o) products, bounds test >=0 & <size, addend = (value*e^z) rounded, then * weight rounded.
 #include "common.h"
-#include <stdlib.h>
 
 struct Corners {
     int x0, y0;
@@ -126,14 +125,12 @@ extern "C" int motif_splat_fwd(const float* src, const float* flow, const float*
 #define OT_TPW (OT_W + 2)
 #define OT_TP (OT_TPH * OT_TPW)
 #define OT_THREADS 1024
-#define OT_NE 2             // list entries per thread whose geometry stays in registers across the 17 passes
 
 struct MotifSplatArgs {
     const float* imnet_out; const float* pred; const float* feat_lr;
     const int32_t* iy; const int32_t* ix; const float* alpha;
     float s20, sr; float* acc;
     int B, N, H, W, HH, WW, R;
-    int pair;      // 1: neighbouring lanes combine their LDS atomics (tuning aid: MOTIF_SPLAT_NOPAIR=1 disables)
     int row0;      // image row of local row 0 (row-band rendering): float coordinates are formed with GLOBAL rows so that
                    // floor() and the bilinear weights are bit-identical to the untiled render
 };
@@ -177,20 +174,6 @@ __device__ __forceinline__ void add_fix(unsigned long long* cell, float x) {
     const unsigned lo = (unsigned)((x - fl) * 4294967296.0f);        // fract < 1, exact; cvt saturates
     const int hi = (int)fl;
     atomicAdd(cell, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)lo);
-}
-
-__device__ __forceinline__ unsigned long long to_fix(float x) {
-    const float fl = floorf(x);
-    const unsigned lo = (unsigned)((x - fl) * 4294967296.0f);
-    const int hi = (int)fl;
-    return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)lo;
-}
-// value of lane-1 (row_shr:1) / lane+1 (row_shl:1) within a row of 16 lanes; `old` where there is no such lane
-__device__ __forceinline__ int dpp_prev(int v, int old) { return __builtin_amdgcn_update_dpp(old, v, 0x111, 0xf, 0xf, false); }
-__device__ __forceinline__ int dpp_next(int v, int old) { return __builtin_amdgcn_update_dpp(old, v, 0x101, 0xf, 0xf, false); }
-__device__ __forceinline__ unsigned long long dpp_prev_u64(unsigned long long v) {
-    const unsigned lo = (unsigned)dpp_prev((int)(unsigned)v, 0), hi = (unsigned)dpp_prev((int)(unsigned)(v >> 32), 0);
-    return ((unsigned long long)hi << 32) | lo;
 }
 
 __device__ __forceinline__ float fix_to_float(unsigned long long v) {
@@ -241,84 +224,6 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
     float* abase = a.acc + (long)bn * 133 * Q;
     float* tmax = (float*)(tile + 3 * OT_TP);          // last chunk only: fp32 max plane, uint count plane
     unsigned* tcnt = (unsigned*)(tmax + OT_TP);
-    // Every pass walks the same list with the same thread -> entry assignment, so the geometry of a thread's first
-    // OT_NE entries (corner cell, weights * e^z, source offsets, pairing flags) is computed once and kept in registers;
-    // entries beyond that (dense convergence of sources onto one tile) are recomputed per pass.
-    struct Ent { int off, p, lr, db; float wnw, wne, wsw, wse, e, p0, p1; bool valid, recv, hand; };
-    const bool pair = a.pair != 0;
-    auto make_ent = [&](int e) {
-        Ent t;
-        t.valid = e < cnt;
-        const unsigned ent = list[t.valid ? e : 0];
-        const int d = ent >> 16, y = ry0 + ((ent >> 8) & 255), x = rx0 + (ent & 255);
-        t.db = d * a.B + b;
-        const SrcGeom g = src_geom(a, t.db * a.N + n, x, y, true);
-        t.e = t.valid ? g.e : 0.f;
-        t.off = t.valid ? (g.y0 - (ty0 - 1)) * OT_TPW + (g.x0 - (tx0 - 1)) : -1000000;
-        // Consecutive list entries are mostly consecutive sources of one row; under a locally constant flow the NE/SE
-        // cells of lane L are the NW/SW cells of lane L+1.  Then lane L hands its NE/SE addends (exact 32.32 integers,
-        // so the association is free) to lane L+1 through DPP and issues two LDS atomics instead of four.
-        t.recv = pair && t.valid && dpp_prev(t.off, -2000000) + 1 == t.off;
-        t.hand = pair && t.valid && dpp_next(t.off, -2000000) == t.off + 1;
-        t.p = y * a.WW + x;
-        t.lr = a.iy[y] * a.W + a.ix[x];
-        t.wnw = g.wnw; t.wne = g.wne; t.wsw = g.wsw; t.wse = g.wse; t.p0 = g.p0; t.p1 = g.p1;
-        return t;
-    };
-    auto feature = [&](const Ent& t, int c) -> float {
-        if (c < 64) return a.imnet_out[((long)t.db * 64 + c) * Q + t.p];
-        if (c == 64) return t.p0;
-        if (c == 65) return t.p1;
-        return a.feat_lr[((long)t.db * 64 + (c - 66)) * HWl + t.lr];
-    };
-    auto add_planes = [&](const Ent& t, const float (&v)[OT_CC], int nplanes) {      // executed by all lanes (DPP inside)
-#pragma unroll
-        for (int cc = 0; cc < OT_CC; ++cc) {
-            if (cc >= nplanes) break;
-            const float ve = v[cc] * t.e;
-            unsigned long long f_nw = to_fix(ve * t.wnw), f_sw = to_fix(ve * t.wsw);
-            const unsigned long long f_ne = to_fix(ve * t.wne), f_se = to_fix(ve * t.wse);
-            const unsigned long long r_ne = dpp_prev_u64(f_ne), r_se = dpp_prev_u64(f_se);
-            if (t.recv) { f_nw += r_ne; f_sw += r_se; }
-            if (t.valid) {
-                unsigned long long* tc = tile + cc * OT_TP + t.off;
-                atomicAdd(tc, f_nw);
-                atomicAdd(tc + OT_TPW, f_sw);
-                if (!t.hand) { atomicAdd(tc + 1, f_ne); atomicAdd(tc + OT_TPW + 1, f_se); }
-            }
-        }
-    };
-    auto process = [&](const Ent& t, int k, bool last) {
-        float v[OT_CC];
-        if (!last) {
-#pragma unroll
-            for (int cc = 0; cc < OT_CC; ++cc) v[cc] = t.valid ? feature(t, k * OT_CC + cc) : 0.f;
-            add_planes(t, v, OT_CC);
-        } else {
-            v[0] = t.valid ? feature(t, 128) : 0.f;
-            v[1] = t.valid ? feature(t, 129) : 0.f;
-            v[2] = 1.0f;                                                    // norm plane: sum of e^z * w
-#pragma unroll
-            for (int cc = 3; cc < OT_CC; ++cc) v[cc] = 0.f;
-            add_planes(t, v, 3);
-            if (t.valid) {
-                float* tm = tmax + t.off;
-                atomic_max_float(tm, t.e * t.wnw);
-                atomic_max_float(tm + 1, t.e * t.wne);
-                atomic_max_float(tm + OT_TPW, t.e * t.wsw);
-                atomic_max_float(tm + OT_TPW + 1, t.e * t.wse);
-                unsigned* tn = tcnt + t.off;
-                atomicAdd(tn, 1u);
-                atomicAdd(tn + 1, 1u);
-                atomicAdd(tn + OT_TPW, 1u);
-                atomicAdd(tn + OT_TPW + 1, 1u);
-            }
-        }
-    };
-    Ent ce[OT_NE];
-#pragma unroll
-    for (int j = 0; j < OT_NE; ++j) ce[j] = make_ent(tid + j * OT_THREADS);
-
     for (int k = 0; k < 17; ++k) {
         const bool last = (k == 16);
         const int n64 = (last ? 3 : OT_CC) * OT_TP;
@@ -326,10 +231,55 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
         if (last)
             for (int i = tid; i < OT_TP; i += OT_THREADS) { tmax[i] = 1.0f; tcnt[i] = 0u; }
         __syncthreads();
+        for (int e = tid; e < cnt; e += OT_THREADS) {
+            const unsigned ent = list[e];
+            const int d = ent >> 16, y = ry0 + ((ent >> 8) & 255), x = rx0 + (ent & 255);
+            const int db = d * a.B + b, img = db * a.N + n;
+            const SrcGeom g = src_geom(a, img, x, y, true);
+            const int off = (g.y0 - (ty0 - 1)) * OT_TPW + (g.x0 - (tx0 - 1));
+            const long p = (long)y * a.WW + x;
+            const long lr = (long)a.iy[y] * a.W + a.ix[x];
+            if (!last) {
+                float v[OT_CC];
 #pragma unroll
-        for (int j = 0; j < OT_NE; ++j)
-            if (j * OT_THREADS < cnt) process(ce[j], k, last);
-        for (int e0 = OT_NE * OT_THREADS; e0 < cnt; e0 += OT_THREADS) process(make_ent(e0 + tid), k, last);
+                for (int cc = 0; cc < OT_CC; ++cc) {
+                    const int c = k * OT_CC + cc;
+                    if (c < 64) v[cc] = a.imnet_out[((long)db * 64 + c) * Q + p];
+                    else if (c == 64) v[cc] = g.p0;
+                    else if (c == 65) v[cc] = g.p1;
+                    else v[cc] = a.feat_lr[((long)db * 64 + (c - 66)) * HWl + lr];
+                }
+#pragma unroll
+                for (int cc = 0; cc < OT_CC; ++cc) {
+                    const float ve = v[cc] * g.e;
+                    unsigned long long* tc = tile + cc * OT_TP + off;
+                    add_fix(tc, ve * g.wnw);
+                    add_fix(tc + 1, ve * g.wne);
+                    add_fix(tc + OT_TPW, ve * g.wsw);
+                    add_fix(tc + OT_TPW + 1, ve * g.wse);
+                }
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    const float ve = (cc < 2) ? a.feat_lr[((long)db * 64 + 62 + cc) * HWl + lr] * g.e : g.e;
+                    unsigned long long* tc = tile + cc * OT_TP + off;
+                    add_fix(tc, ve * g.wnw);
+                    add_fix(tc + 1, ve * g.wne);
+                    add_fix(tc + OT_TPW, ve * g.wsw);
+                    add_fix(tc + OT_TPW + 1, ve * g.wse);
+                }
+                float* tm = tmax + off;
+                atomic_max_float(tm, g.e * g.wnw);
+                atomic_max_float(tm + 1, g.e * g.wne);
+                atomic_max_float(tm + OT_TPW, g.e * g.wsw);
+                atomic_max_float(tm + OT_TPW + 1, g.e * g.wse);
+                unsigned* tn = tcnt + off;
+                atomicAdd(tn, 1u);
+                atomicAdd(tn + 1, 1u);
+                atomicAdd(tn + OT_TPW, 1u);
+                atomicAdd(tn + OT_TPW + 1, 1u);
+            }
+        }
         __syncthreads();
         const int nplanes = last ? 5 : OT_CC;
         for (int i = tid; i < nplanes * OT_H * OT_W; i += OT_THREADS) {
@@ -388,7 +338,7 @@ extern "C" int motif_splat_motif_fwd(const float* imnet_out, const float* pred, 
                                      float* acc, int B, int N, int H, int W, int HH, int WW, int row0, void* stream) {
     if (!imnet_out || !pred || !feat_lr || !iy || !ix || !alpha || !acc) return MOTIF_EINVAL;
     if (B < 1 || N < 1 || H < 1 || W < 1 || HH < 1 || WW < 1 || row0 < 0) return MOTIF_EINVAL;
-    MotifSplatArgs a{imnet_out, pred, feat_lr, iy, ix, alpha, 20.0f, flow_scale, acc, B, N, H, W, HH, WW, 16, getenv("MOTIF_SPLAT_NOPAIR") ? 0 : 1, row0};
+    MotifSplatArgs a{imnet_out, pred, feat_lr, iy, ix, alpha, 20.0f, flow_scale, acc, B, N, H, W, HH, WW, 16, row0};
     const int cap = 2 * (OT_H + 2 * a.R) * (OT_W + 2 * a.R);
     const size_t lds = (size_t)OT_CC * OT_TP * 8 + (size_t)cap * 4;
     hipError_t e = hipFuncSetAttribute((const void*)splat_owner_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
