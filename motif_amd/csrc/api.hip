@@ -2,7 +2,7 @@
 #include "common.h"
 #include <string.h>
 
-extern "C" int motif_abi_version(void) { return 1; }
+extern "C" int motif_abi_version(void) { return 2; }   // 2: MotifConvDesc.mma, motif_siren_pack_split + pre=2, splat row0
 
 extern "C" int motif_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len) {
     int dev = 0;
