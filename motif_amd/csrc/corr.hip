@@ -15,8 +15,21 @@ struct LookupArgs {
 };
 
 // grid: x = 64-query tiles, y = batch, z = pyramid level (all levels of AlternateCorrBlock in one launch)
+// Dot products: 16 lanes share one neighbour (8 channels = 32 bytes each, so a load instruction reads four half rows of
+// 256 contiguous bytes instead of 64 scattered 16-byte pieces), partial sums are reduced inside the 16-lane DPP row and
+// parked in LDS so that lane n ends up with the dot of neighbour n.  C = 128 only (RAFT-small fnet); other widths use
+// the one-lane-per-neighbour form.
+__device__ __forceinline__ float row16_sum(float v) {         // sum over the 16 lanes of a DPP row, valid in lane 15
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));   // row_shr:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));   // row_shr:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));   // row_shr:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   // row_shr:1
+    return v;
+}
+
 __global__ __launch_bounds__(256) void raft_lookup_kernel(LookupArgs a) {
     __shared__ float tile[49][65];
+    __shared__ float dots[4][64];
     const int b = blockIdx.y, lv = blockIdx.z;
     const float* __restrict__ fmap2 = a.fmap2[lv];
     const int H2 = a.H2[lv], W2 = a.W2[lv], C = a.C;
@@ -25,6 +38,7 @@ __global__ __launch_bounds__(256) void raft_lookup_kernel(LookupArgs a) {
     const long q0 = (long)blockIdx.x * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gy = lane >> 3, gx = lane & 7;
+    const int sub = lane & 15, grp = lane >> 4;
     for (int i = 0; i < 16; ++i) {
         const int ql = wave * 16 + i;
         const long q = q0 + ql;
@@ -33,18 +47,39 @@ __global__ __launch_bounds__(256) void raft_lookup_kernel(LookupArgs a) {
         const float y = a.coords[((long)b * 2 + 1) * HW1 + q] * cs;
         const float fx = floorf(x), fy = floorf(y);
         const float dx = x - fx, dy = y - fy;
-        const int h2 = (int)fy - 3 + gy, w2 = (int)fx - 3 + gx;
         float s = 0.f;
-        if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
-            const f32x4* f1 = (const f32x4*)(a.fmap1 + ((long)b * HW1 + q) * C);
-            const f32x4* f2 = (const f32x4*)(fmap2 + (((long)b * H2 + h2) * W2 + w2) * C);
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll 8
-            for (int c = 0; c < C / 4; ++c) {
-                const f32x4 u = f1[c], v = f2[c];
-                s0 = fmaf(u[0], v[0], s0); s1 = fmaf(u[1], v[1], s1); s2 = fmaf(u[2], v[2], s2); s3 = fmaf(u[3], v[3], s3);
+        if (C == 128) {
+            const f32x4* f1 = (const f32x4*)(a.fmap1 + ((long)b * HW1 + q) * 128) + sub * 2;
+            const f32x4 u0 = f1[0], u1 = f1[1];
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int nb = it * 4 + grp;                            // neighbour handled by this 16-lane row
+                const int h2 = (int)fy - 3 + (nb >> 3), w2 = (int)fx - 3 + (nb & 7);
+                float part = 0.f;
+                if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
+                    const f32x4* f2 = (const f32x4*)(fmap2 + (((long)b * H2 + h2) * W2 + w2) * 128) + sub * 2;
+                    const f32x4 v0 = f2[0], v1 = f2[1];
+                    float s0 = u0[0] * v0[0], s1 = u0[1] * v0[1], s2 = u0[2] * v0[2], s3 = u0[3] * v0[3];
+                    s0 = fmaf(u1[0], v1[0], s0); s1 = fmaf(u1[1], v1[1], s1); s2 = fmaf(u1[2], v1[2], s2); s3 = fmaf(u1[3], v1[3], s3);
+                    part = (s0 + s1) + (s2 + s3);
+                }
+                part = row16_sum(part);
+                if (sub == 15) dots[wave][nb] = part;
             }
-            s = (s0 + s1) + (s2 + s3);
+            s = dots[wave][lane];                                       // same wave wrote it: LDS ops of a wave are ordered
+        } else {
+            const int h2 = (int)fy - 3 + gy, w2 = (int)fx - 3 + gx;
+            if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
+                const f32x4* f1 = (const f32x4*)(a.fmap1 + ((long)b * HW1 + q) * C);
+                const f32x4* f2 = (const f32x4*)(fmap2 + (((long)b * H2 + h2) * W2 + w2) * C);
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+                for (int c = 0; c < C / 4; ++c) {
+                    const f32x4 u = f1[c], v = f2[c];
+                    s0 = fmaf(u[0], v[0], s0); s1 = fmaf(u[1], v[1], s1); s2 = fmaf(u[2], v[2], s2); s3 = fmaf(u[3], v[3], s3);
+                }
+                s = (s0 + s1) + (s2 + s3);
+            }
         }
         const float s_e = __shfl(s, (lane + 1) & 63), s_s = __shfl(s, (lane + 8) & 63), s_se = __shfl(s, (lane + 9) & 63);
         if (gy < 7 && gx < 7) {

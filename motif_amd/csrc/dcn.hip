@@ -132,7 +132,7 @@ struct DcnFusedArgs {
 // WAVES = output rows per block (one wave per row of 32 pixels): 8 -> one 92 KB block per CU; 4 -> two 55 KB blocks per
 // CU whose gather latencies and MFMA stretches overlap each other.
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void dcn_fused_kernel(DcnFusedArgs a) {
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void dcn_fused_kernel(DcnFusedArgs a) {
     constexpr int NPX = 32 * WAVES, NT = 64 * WAVES;       // pixels per tile, threads
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int WN = 64;
