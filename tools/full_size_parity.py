@@ -15,21 +15,28 @@ def main():
     times = [float(t) for t in os.environ.get("TIMES", "0.5").split(",")]
     s = synthetic_sample(180, 320, 4, 7)
     tl = [torch.full((1, 1), t) for t in times]
+    from motif_amd import ops
     net = fill_state_dict(LunaTokis()).cuda().eval()
-    with torch.no_grad():
-        out, flow, _ = net(s["LQs"].cuda(), None, [t.cuda() for t in tl], s["scale"], use_GT=False, iter=4)
-    torch.cuda.synchronize()
+    outs = {}
+    for mode in os.environ.get("MODES", "bf16x3,fp32").split(","):
+        ops.set_mma(mode)
+        net.clear_cache()
+        with torch.no_grad():
+            outs[mode] = net(s["LQs"].cuda(), None, [t.cuda() for t in tl], s["scale"], use_GT=False, iter=4)[:2]
+        torch.cuda.synchronize()
     t0 = time.time()
     with torch.no_grad():
         ref, rflow, _ = fill_state_dict(MotifRef().eval())(s["LQs"], None, tl, s["scale"], use_GT=False, iter=4)
     dt = time.time() - t0
-    o = out.cpu()
-    mse = float(((o.double() - ref.double()) ** 2).mean())
     gt = s["GT"][0, 1:1 + len(times)]
-    pm = util.y_psnr_per_frame(gt, o[:, 0]); pr = util.y_psnr_per_frame(gt, ref[:, 0])
+    pr = util.y_psnr_per_frame(gt, ref[:, 0])
     print("c2 full size, %d timestamp(s): oracle %.1f s on %d threads" % (len(times), dt, torch.get_num_threads()))
-    print("PSNR(build, oracle) = %.2f dB   Linf = %.3e   flow Linf = %.3e px(LR units)" % (10 * np.log10(1.0 / mse), float((o - ref).abs().max()), float((flow.cpu() - rflow).abs().max())))
-    print("Y-PSNR vs seeded GT: build %s  oracle %s  |delta| max %.5f dB" % (pm, pr, float(np.abs(pm - pr).max())))
+    for mode, (out, flow) in outs.items():
+        o = out.cpu()
+        mse = float(((o.double() - ref.double()) ** 2).mean())
+        pm = util.y_psnr_per_frame(gt, o[:, 0])
+        print("[%s] PSNR(build, oracle) = %.2f dB   Linf = %.3e   flow Linf = %.3e px(LR units)   Y-PSNR vs GT |delta| max %.5f dB"
+              % (mode, 10 * np.log10(1.0 / mse), float((o - ref).abs().max()), float((flow.cpu() - rflow).abs().max()), float(np.abs(pm - pr).max())))
 
 if __name__ == "__main__":
     main()
