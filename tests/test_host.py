@@ -221,3 +221,29 @@ dist.destroy_process_group()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29537", str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "TILED_OK (0, 56) (56, 104)" in r.stdout, r.stdout + r.stderr
+
+
+def test_arithmetic_mode_option_plumbing():
+    """network_G.mma / ops.set_mma select the contraction engines; default is the bf16x3 split."""
+    from motif_amd import ops, option
+    from motif_amd.models import networks
+    before = ops.get_mma()
+    try:
+        assert before in ("bf16x3", "fp32", "bf16x2", "bf16")
+        networks.define_G(option.default_opt(mma="fp32"))
+        assert ops.get_mma() == "fp32" and ops.get_conv_mma() == ops.MMA_FP32 and ops.get_siren_mma() == ops.MMA_FP32
+        networks.define_G(option.default_opt(mma="bf16"))
+        assert ops.get_conv_mma() == ops.MMA_BF16 and ops.get_siren_mma() == ops.MMA_BF16X3      # MLPs never drop below the split
+        networks.define_G(option.default_opt())                                                   # mma=None leaves the mode alone
+        assert ops.get_mma() == "bf16"
+        with pytest.raises(KeyError):
+            ops.set_mma("fp16")
+        b0, b1 = dist_band(2160, 8)
+        assert b0 == (0, 272) and b1 == (1896, 2160)
+    finally:
+        ops.set_mma(before)
+
+
+def dist_band(n, w):
+    from motif_amd.dist import band_of
+    return band_of(n, 0, w, 8), band_of(n, w - 1, w, 8)
