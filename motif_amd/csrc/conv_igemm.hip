@@ -25,7 +25,8 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
     constexpr int NE_MAX = PATCH_MAX / NT;    // patch elements a thread prefetches per chunk
     constexpr int NW_MAX = WCHUNK_MAX / 4 / NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    const int tile_id = (a.dbg & 64) ? (int)blockIdx.x : xcd_tile_id();
+    const int tx = tile_id % a.tiles_x, ty = tile_id / a.tiles_x;
     const int g = blockIdx.y / a.ncg, cg = blockIdx.y % a.ncg;
     const int pz = blockIdx.z / a.N, n = blockIdx.z - pz * a.N;
     const float* a_in0 = a.in0[pz]; const float* a_in1 = a.in1[pz]; const float* a_wp = a.wp[pz];

@@ -80,7 +80,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
     float* bias_s = (float*)lds_raw;                     // [64] bias of this cout group
     u32x4* lds = lds_raw + 16;                           // [2 buffers][NP][SLOTS]; reused by the epilogue transpose
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    // XCD-aware tile order: workgroups go round-robin over the 8 XCDs (each with its own L2) in linear-id order, so
+    // the blocks that land on one XCD get a contiguous run of tiles -- vertically adjacent tiles share their halo rows
+    // in that XCD's L2 instead of fetching them once per XCD.
+    const int tile_id = (a.dbg & 64) ? (int)blockIdx.x : xcd_tile_id();
+    const int tx = tile_id % a.tiles_x, ty = tile_id / a.tiles_x;
     const int g = blockIdx.y / a.ncg, cg = blockIdx.y % a.ncg;
     const int pz = blockIdx.z / a.N, n = blockIdx.z - pz * a.N;
     const float* a_in0 = a.in0[pz]; const float* a_in1 = a.in1[pz];

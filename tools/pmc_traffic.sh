@@ -9,7 +9,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   cp $f $R/gpurun_out/r01_conv_split_${c}_pmc.csv
   python - "$f" $c <<'PY'
 import csv, sys
-v = [float(r["Counter_Value"]) for r in csv.DictReader(open(sys.argv[1])) if "conv_split_kernel" in r["Kernel_Name"] and r["Counter_Name"] == sys.argv[2]]
+v = [float(r["Counter_Value"]) for r in csv.DictReader(open(sys.argv[1])) if ("conv_split_kernel" in r["Kernel_Name"] or "conv_igemm_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == sys.argv[2]]
 print(sys.argv[2], "per launch: mean %.1f  n=%d" % (sum(v) / len(v), len(v)))
 PY
 done
