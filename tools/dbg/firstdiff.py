@@ -1,5 +1,6 @@
 import sys, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from motif_amd import ops
 from motif_amd.data.synthetic import synthetic_sample
 from motif_amd.models.modules.Ours import LunaTokis

@@ -1,5 +1,6 @@
 import sys, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from motif_amd import ops
 from motif_amd.models.modules.layers import Conv2d
 from motif_amd.models.modules.DCNv2.dcn_v2 import DCN_sep
