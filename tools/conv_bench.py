@@ -13,6 +13,10 @@ SHAPES = [  # N, Cin, Cout, k, stride, H, W
     (1, 128, 64, 3, 1, 45, 80),
     (2, 64, 64, 3, 1, 90, 160),
     (8, 64, 64, 3, 1, 180, 320),
+    (8, 64, 64, 3, 1, 45, 80),
+    (8, 64, 216, 3, 1, 45, 80),
+    (8, 64, 64, 3, 1, 90, 160),
+    (2, 64, 64, 3, 1, 90, 160),
 ]
 
 def main():
