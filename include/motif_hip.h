@@ -219,6 +219,16 @@ int motif_axpby(const float* x, const float* y, float a, float b, float* out, lo
 int motif_deconv4x4s2(const float* in, const float* weight /*[Cin,Cout,4,4]*/, const float* bias, float* out,
                       int N, int Cin, int Cout, int H, int W, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Frame formats either side of the path.
+ * decode: uint8 interleaved [N,H,W,3] (cv2.imread order, BGR) -> fp32 planar [N,3,H,W] in [0,1]; swap_rb = 1 also turns
+ *   BGR into RGB -- `img.astype(np.float32) / 255.`, `[:, :, :, [2, 1, 0]]`, HWC->CHW of data/Adobe_test_3.py:171-195.
+ * encode: fp32 planar [N,3,H,W] -> uint8 interleaved [N,H,W,3]: clamp(0,1), *255, then round_mode 1 = round half to even
+ *   (utils/util.py:105-129 tensor2img, swap_rb = 1 for its RGB->BGR) or 0 = truncate (demo.py:94-99, swap_rb = 0).
+ * ---------------------------------------------------------------------------------------------- */
+int motif_frames_u8_to_f32(const unsigned char* in, float* out, int N, int H, int W, int swap_rb, void* stream);
+int motif_frames_f32_to_u8(const float* in, unsigned char* out, int N, int H, int W, int round_mode, int swap_rb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

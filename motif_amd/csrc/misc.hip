@@ -414,3 +414,58 @@ extern "C" int motif_deconv4x4s2(const float* in, const float* weight, const flo
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }
+
+
+// ------------------------------------------------------------------ frame formats either side of the path
+// decode: uint8 interleaved frames [N,H,W,3] as cv2.imread yields them (BGR) -> fp32 planar [N,3,H,W] in [0,1], RGB:
+// `img.astype(np.float32) / 255.` then `[:, :, :, [2, 1, 0]]` and HWC->CHW (data/Adobe_test_3.py:171-195).
+__global__ void frames_u8_to_f32_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, long HW, int swap) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = blockIdx.y;
+    if (p >= HW) return;
+    const unsigned char* q = in + (n * HW + p) * 3;
+    const float c0 = (float)q[0] / 255.0f, c1 = (float)q[1] / 255.0f, c2 = (float)q[2] / 255.0f;
+    float* o = out + n * 3 * HW + p;
+    o[0] = swap ? c2 : c0;
+    o[HW] = c1;
+    o[2 * HW] = swap ? c0 : c2;
+}
+
+// encode: fp32 planar RGB [N,3,H,W] -> uint8 interleaved [N,H,W,3].  mode 1: clamp(0,1), *255, round half to even,
+// RGB->BGR when swap (utils/util.py:105-129 tensor2img); mode 0: clamp, *255, truncate (demo.py:94-99).
+__global__ void frames_f32_to_u8_kernel(const float* __restrict__ in, unsigned char* __restrict__ out, long HW, int mode, int swap) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = blockIdx.y;
+    if (p >= HW) return;
+    const float* q = in + n * 3 * HW + p;
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = q[k * HW];
+        v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);           // NaN -> passes through both tests like torch.clamp; cast gives 0
+        v = v * 255.0f;
+        c[k] = mode ? rintf(v) : truncf(v);
+    }
+    unsigned char* o = out + (n * HW + p) * 3;
+    o[0] = (unsigned char)(swap ? c[2] : c[0]);
+    o[1] = (unsigned char)c[1];
+    o[2] = (unsigned char)(swap ? c[0] : c[2]);
+}
+
+extern "C" int motif_frames_u8_to_f32(const unsigned char* in, float* out, int N, int H, int W, int swap_rb, void* stream) {
+    if (!in || !out || N < 1 || H < 1 || W < 1) return MOTIF_EINVAL;
+    const long HW = (long)H * W;
+    dim3 grid(cdiv(HW, 256), N);
+    frames_u8_to_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(in, out, HW, swap_rb);
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}
+
+extern "C" int motif_frames_f32_to_u8(const float* in, unsigned char* out, int N, int H, int W, int round_mode, int swap_rb, void* stream) {
+    if (!in || !out || N < 1 || H < 1 || W < 1) return MOTIF_EINVAL;
+    const long HW = (long)H * W;
+    dim3 grid(cdiv(HW, 256), N);
+    frames_f32_to_u8_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(in, out, HW, round_mode, swap_rb);
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}

@@ -27,6 +27,12 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _p8(t):
+    if not t.is_cuda or t.dtype != torch.uint8:
+        raise RuntimeError("expected a CUDA(ROCm) uint8 tensor, got %s %s" % (t.device, t.dtype))
+    return ctypes.c_void_p(t.data_ptr())
+
+
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
@@ -540,4 +546,30 @@ def deconv4x4s2(x, weight, bias):
     out = torch.empty(n, co, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
     check(lib.motif_deconv4x4s2(_p(x), _p(_c(weight.detach())), _p(bias.detach()) if bias is not None else None, _p(out),
                                 n, ci, co, h, w, _stream()), "motif_deconv4x4s2")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- frame formats
+def frames_u8_to_f32(frames_u8, swap_rb=True):
+    """uint8 [N,H,W,3] (cv2 order) -> fp32 [N,3,H,W] in [0,1] (data/Adobe_test_3.py:171-195)."""
+    lib = _lib.load()
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[-1] != 3:
+        raise RuntimeError("frames_u8_to_f32 expects uint8 [N,H,W,3]")
+    x = frames_u8.contiguous()
+    n, h, w, _ = x.shape
+    out = torch.empty(n, 3, h, w, dtype=torch.float32, device=x.device)
+    check(lib.motif_frames_u8_to_f32(_p8(x), _p(out), n, h, w, int(swap_rb), _stream()), "motif_frames_u8_to_f32")
+    return out
+
+
+def frames_f32_to_u8(frames, round_half_even=True, swap_rb=True):
+    """fp32 [N,3,H,W] -> uint8 [N,H,W,3]: tensor2img (utils/util.py:105-129) by default, demo.py:94-99 with
+    round_half_even=False, swap_rb=False."""
+    lib = _lib.load()
+    x = _c(frames)
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise RuntimeError("frames_f32_to_u8 expects fp32 [N,3,H,W]")
+    n, _, h, w = x.shape
+    out = torch.empty(n, h, w, 3, dtype=torch.uint8, device=x.device)
+    check(lib.motif_frames_f32_to_u8(_p(x), _p8(out), n, h, w, int(round_half_even), int(swap_rb), _stream()), "motif_frames_f32_to_u8")
     return out

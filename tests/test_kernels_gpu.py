@@ -524,3 +524,24 @@ def test_dcn_fused_multi_vs_kernel_text():
     out = ops.dcn_v2_multi(plans, xs, oms, dg, ops.ACT_LRELU)
     for pi in range(P):
         close(out[pi], outs_ref[pi], 3e-5, 3e-5, "fused dcn problem %d" % pi)
+
+
+# ------------------------------------------------------------------------------------------- frame formats
+def test_frame_decode_encode_bit_exact():
+    """motif_frames_u8_to_f32 / _f32_to_u8 against the numpy restatement of the reference's loader and tensor2img /
+    demo.py encoders: bit-exact, including the .5 rounding ties, out-of-range values and every uint8 level."""
+    from oracle import frames_ref
+    from motif_amd import ops
+    rng = np.random.default_rng(1)
+    u8 = rng.integers(0, 256, (3, 37, 53, 3), dtype=np.uint8)
+    u8[0, 0, :256 // 5 + 1] = np.arange(0, 256, 5, dtype=np.uint8)[:, None][: 256 // 5 + 1]
+    dec = ops.frames_u8_to_f32(torch.from_numpy(u8).to(dev()))
+    assert torch.equal(dec.cpu(), torch.from_numpy(frames_ref.decode(u8)))
+    x = rng.random((3, 3, 37, 53), dtype=np.float32) * 1.4 - 0.2
+    x[0, :, 0, :40] = (np.arange(40, dtype=np.float32) + 0.5) / 255.0          # exact ties
+    xt = torch.from_numpy(x).to(dev())
+    assert np.array_equal(ops.frames_f32_to_u8(xt).cpu().numpy(), frames_ref.encode_tensor2img(x))
+    assert np.array_equal(ops.frames_f32_to_u8(xt, round_half_even=False, swap_rb=False).cpu().numpy(), frames_ref.encode_demo(x))
+    # codec round trip: every level survives decode -> encode
+    lv = torch.arange(256, dtype=torch.uint8).view(1, 1, 256, 1).repeat(1, 2, 1, 3).to(dev())
+    assert torch.equal(ops.frames_f32_to_u8(ops.frames_u8_to_f32(lv)), lv)

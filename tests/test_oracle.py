@@ -153,3 +153,22 @@ def test_corr81_center_channel_is_mean_product():
     assert float((out[:, 40] - (a * b).mean(1)).abs().max()) < 1e-6
     assert float((out[:, 41, :, :-1] - (a[..., :-1] * b[..., 1:]).mean(1)).abs().max()) < 1e-6
     assert float(out[:, 41, :, -1].abs().max()) == 0
+
+
+def test_frame_codec_restatement_known_answers():
+    """oracle/frames_ref.py against hand-computed values of the cited reference lines."""
+    from oracle import frames_ref
+    u8 = np.zeros((1, 1, 2, 3), np.uint8)
+    u8[0, 0, 0] = (255, 0, 51)          # B, G, R
+    u8[0, 0, 1] = (1, 128, 254)
+    d = frames_ref.decode(u8)
+    assert d.shape == (1, 3, 1, 2) and d.dtype == np.float32
+    assert d[0, :, 0, 0].tolist() == [np.float32(51) / np.float32(255), 0.0, 1.0]           # R, G, B
+    assert d[0, 0, 0, 1] == np.float32(254) / np.float32(255) and d[0, 2, 0, 1] == np.float32(1) / np.float32(255)
+    f = np.array([[[[0.5 / 255, 1.5 / 255, 2.5 / 255, -0.2, 1.7, 0.999]]] * 3], np.float32)
+    e = frames_ref.encode_tensor2img(f)
+    assert e.shape == (1, 1, 6, 3) and e[0, 0, :, 0].tolist() == [0, 2, 2, 0, 255, 255]      # half to even, clamp
+    t = frames_ref.encode_demo(f)
+    assert t[0, 0, :, 0].tolist() == [0, 1, 2, 0, 255, 254]                                  # truncation
+    g = np.random.default_rng(0).random((2, 3, 5, 7), dtype=np.float32)
+    assert np.array_equal(frames_ref.decode(frames_ref.encode_tensor2img(g)).round(6), frames_ref.decode(frames_ref.encode_tensor2img(frames_ref.decode(frames_ref.encode_tensor2img(g)))).round(6))
