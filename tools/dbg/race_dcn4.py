@@ -5,7 +5,7 @@ from motif_amd import ops
 from motif_amd.models.modules.layers import Conv2d
 from motif_amd.models.modules.DCNv2.dcn_v2 import DCN_sep
 torch.manual_seed(0)
-ops.set_mma("bf16x3")
+ops.set_mma(__import__("os").environ.get("SIDE_MMA", "bf16x3"))
 gru = Conv2d(242, 96, 3, 1, 1).cuda(); xg = torch.randn(2, 242, 90, 160, device="cuda")
 c7 = Conv2d(3, 32, 7, 2, 3).cuda(); x7 = torch.randn(4, 3, 720, 1280, device="cuda")
 tr = Conv2d(64, 64, 3, 1, 1).cuda(); xt = torch.randn(4, 64, 360, 640, device="cuda")
