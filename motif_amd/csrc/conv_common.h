@@ -47,12 +47,23 @@ __device__ __forceinline__ int xcd_tile_id() {
 
 // The activation / residual mode is block-uniform: dispatch ONCE to a specialised body `run(actf, res_tag)`;
 // actf(v, residual, cout) -> stored value, res_tag = std::true_type when a residual tensor is read.
-template <class RUN>
+template <bool SPECIALISE = true, class RUN>
 __device__ __forceinline__ void conv_act_dispatch(const ConvArgs& a, RUN&& run) {
     auto run_rm = [&](auto actf) {
         if (a.res_mode) run(actf, std::true_type{}); else run(actf, std::false_type{});
     };
     const int rm = a.res_mode;
+    if constexpr (!SPECIALISE) {                        // one generic body (rarely taken paths: keeps code size / compile time down)
+        const int act = a.act, act2 = a.act2, asplit = a.act_split;
+        run_rm([&](float v, float rv, int co) {
+            const int ac = (asplit > 0 && co >= asplit) ? act2 : act;
+            if (rm == 1) return act_apply(v + rv, ac);
+            float y = act_apply(v, ac);
+            if (rm == 2) y += rv; else if (rm == 3) { y += rv; y = y > 0.f ? y : 0.f; } else if (rm == 4) y *= rv;
+            return y;
+        });
+        return;
+    }
     if (a.act_split > 0) {
         run_rm([&](float v, float rv, int co) {
             const int act = co >= a.act_split ? a.act2 : a.act;
@@ -86,7 +97,7 @@ __device__ __forceinline__ void conv_act_dispatch(const ConvArgs& a, RUN&& run) 
 
 // Epilogue of one wave: acc[i][j] = 32 couts (tile i of the block's cout group) x 32 pixels of output row oy0+j,
 // column ox.  `a_*` are the per-problem pointers/strides, bias_s the LDS copy of the cout group's bias.
-template <int NC, int RPW>
+template <int NC, int RPW, bool SPECIALISE = true>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NC][RPW], const float* bias_s, int n, int g, int cg,
                                               int oy0, int ox, int half, const float* a_res, long a_res_bs, float* a_out,
                                               long a_out_bs) {
@@ -163,7 +174,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
             }
         }
     };
-    conv_act_dispatch(a, run);
+    conv_act_dispatch<SPECIALISE>(a, run);
 }
 
 // Block-cooperative epilogue through LDS: the accumulators of one 32-cout tile are transposed in `scratch`

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
     if (vec_ok)
         conv_epilogue_lds<NC, RP, WAVES>(a, acc, bias_s, (float*)lds, n, g, cg, ty, tx, a_res, a_res_bs, a_out, a_out_bs);
     else
-        conv_epilogue<NC, RP>(a, acc, bias_s, n, g, cg, ty * TH + RP * wave, tx * 32 + l31, half, a_res, a_res_bs, a_out, a_out_bs);
+        conv_epilogue<NC, RP, false>(a, acc, bias_s, n, g, cg, ty * TH + RP * wave, tx * 32 + l31, half, a_res, a_res_bs, a_out, a_out_bs);
     TRACE(14);
     __builtin_amdgcn_s_waitcnt(0);
     TRACE(15);
@@ -296,8 +296,7 @@ int motif_conv_split_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStrea
     a.Kpad = 9 * ((Cin_g + 15) / 16);
     a.ncg = (Cout_g + 63) / 64;
     a.tiles_x = (Wo + 31) / 32;
-    int waves = 4;
-    if (const char* e = getenv("MOTIF_SPLIT_WAVES")) { const int w = atoi(e); if (w == 8 || w == 2) waves = w; }
+    const int waves = 4;           // 2-wave (4 blocks per CU) and 8-wave (one block per CU) tiles were measured slower
     const int TH = 2 * waves, tiles_y = (Ho + TH - 1) / TH;
     size_t ldsb = (size_t)2 * NP * (2 * (TH + 2) * 34 + 4) * 16;
     const size_t scratch = (size_t)32 * (TH * 32 + 8) * 4;                      // epilogue transpose of one 32-cout tile
@@ -310,9 +309,7 @@ int motif_conv_split_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStrea
             (void)hipFuncSetAttribute((const void*)conv_split_kernel<NPV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); \
         conv_split_kernel<NPV, WV><<<grid, 64 * WV, ldsb, s>>>(a);                                                     \
     } while (0)
-    if (waves == 2) { if (NP == 3) MOTIF_LAUNCH_SPLIT(3, 2); else if (NP == 2) MOTIF_LAUNCH_SPLIT(2, 2); else MOTIF_LAUNCH_SPLIT(1, 2); }
-    else if (waves == 8) { if (NP == 3) MOTIF_LAUNCH_SPLIT(3, 8); else if (NP == 2) MOTIF_LAUNCH_SPLIT(2, 8); else MOTIF_LAUNCH_SPLIT(1, 8); }
-    else { if (NP == 3) MOTIF_LAUNCH_SPLIT(3, 4); else if (NP == 2) MOTIF_LAUNCH_SPLIT(2, 4); else MOTIF_LAUNCH_SPLIT(1, 4); }
+    if (NP == 3) MOTIF_LAUNCH_SPLIT(3, 4); else if (NP == 2) MOTIF_LAUNCH_SPLIT(2, 4); else MOTIF_LAUNCH_SPLIT(1, 4);
 #undef MOTIF_LAUNCH_SPLIT
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
