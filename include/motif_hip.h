@@ -161,7 +161,10 @@ int motif_dcn_v2_fwd_multi(int P, const float* const* input, const long* input_b
 int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, const long* input_bs, const float* const* offset,
                                  const float* const* mask, const float* const* packed3x3, const float* const* bias,
                                  float* const* out, int B, int C, int H, int W, int Cout, int deformable_groups,
-                                 long offset_bs, long mask_bs, int act, void* stream);
+                                 long offset_bs, long mask_bs, int act, int mma, void* stream);
+/* mma = 0: `packed3x3` as above, fp32 MFMA.  mma = 6: the GEMM on the bf16 matrix cores with the fp32-equivalent 3-way split
+ * (MotifConvDesc.mma), `packed3x3` from motif_dcn_split_pack (size query with packed = NULL; returns floats). */
+long motif_dcn_split_pack(const float* weight /*[Cout,C,3,3]*/, float* packed, int Cout, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * C2  RAFT windowed correlation lookup.  Replaces alt_cuda_corr.forward (third-party, not vendored;

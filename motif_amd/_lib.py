@@ -42,7 +42,8 @@ _SIGS = {
                                + [c_int] * 11 + [c_long, c_long, c_int, P]),
     "motif_dcn_v2_fwd": (c_int, [P, P, P, P, P, P, P] + [c_int] * 11 + [c_long, c_long, c_int, P]),
     "motif_dcn_v2_fused_fwd_multi": (c_int, [c_int, POINTER(c_void_p), POINTER(c_long)] + [POINTER(c_void_p)] * 5
-                                     + [c_int] * 6 + [c_long, c_long, c_int, P]),
+                                     + [c_int] * 6 + [c_long, c_long, c_int, c_int, P]),
+    "motif_dcn_split_pack": (c_long, [P, P, c_int, c_int, P]),
     "motif_raft_corr_lookup": (c_int, [P, P, P, c_float, P] + [c_int] * 7 + [c_int, c_int, c_float, P]),
     "motif_raft_corr_lookup_pyramid": (c_int, [P, POINTER(c_void_p), POINTER(c_int), POINTER(c_int), c_int, P, P] + [c_int] * 6 + [c_float, P]),
     "motif_corr81_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -125,20 +125,92 @@ struct DcnFusedArgs {
     int front_pad;
 };
 
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 #define DF_PAIRS 5          // ceil(9 taps * 256 pixels / 512 threads)
 #define DF_CH 4             // channels per chunk
 #define DF_ROWS (DF_CH * 9) // K rows per chunk
 
+typedef __attribute__((ext_vector_type(8))) __bf16 dcn_bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 dcn_bf16x2;
+typedef unsigned dcn_u32x4 __attribute__((ext_vector_type(4)));
+__device__ constexpr int DCN_PW[6] = {2, 0, 1, 1, 0, 0};      // (weight part, value part) of the six products, small terms first
+__device__ constexpr int DCN_PX[6] = {0, 2, 1, 0, 1, 0};
+__device__ __forceinline__ unsigned dcn_pk_bf16(float a, float b) {
+    dcn_bf16x2 p = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ void dcn_split8(const float (&v)[8], dcn_u32x4 (&out)[3]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float x0 = v[2 * q], x1 = v[2 * q + 1];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned pk = dcn_pk_bf16(x0, x1);
+            out[p][q] = pk;
+            if (p < 2) { x0 -= __builtin_bit_cast(float, pk << 16); x1 -= __builtin_bit_cast(float, pk & 0xffff0000u); }
+        }
+    }
+}
+
+// weight [Cout, C, 3, 3] fp32 -> per cout group of 64 and per 4-channel chunk: A fragments [k-step 3][part 3][tile 2][lane][8]
+// bf16 of the chunk's K-rows R = 16s + 8*(lane>>5) + e, R = ((cl>>1)*9 + tap)*2 + (cl&1) (the im2col row order of the fused
+// kernel), rows 36..47 zero.
+__global__ void dcn_split_pack_kernel(const float* w, unsigned short* wp, int Cout, int C, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), t = (int)((i >> 9) & 1);
+    long r = i >> 10;
+    const int part = (int)(r % 3); r /= 3;
+    const int ks = (int)(r % 3); r /= 3;
+    const int nch = C / DF_CH;
+    const int chunk = (int)(r % nch);
+    const int cgi = (int)(r / nch);
+    const int col = cgi * 64 + t * 32 + (lane & 31);
+    const int R = 16 * ks + 8 * (lane >> 5) + e;
+    float v = 0.f;
+    if (R < DF_ROWS && col < Cout) {
+        const int cp = R / 18, tap = (R % 18) >> 1, hf = R & 1;
+        const int c = chunk * DF_CH + 2 * cp + hf;
+        v = w[((long)col * C + c) * 9 + tap];
+    }
+    unsigned short out = 0;
+    for (int p = 0; p <= part; ++p) {
+        const unsigned pk = dcn_pk_bf16(v, 0.f);
+        out = (unsigned short)(pk & 0xffffu);
+        v -= __builtin_bit_cast(float, pk << 16);
+    }
+    wp[i] = out;
+}
+
+extern "C" long motif_dcn_split_pack(const float* weight, float* packed, int Cout, int C, void* stream) {
+    if (Cout < 1 || C < DF_CH || C % DF_CH) return MOTIF_EINVAL;
+    const long ncg = (Cout + 63) / 64, nch = C / DF_CH;
+    const long floats = ncg * nch * 3 * 3 * 2 * 64 * 4;
+    if (!packed) return floats;
+    if (!weight) return MOTIF_EINVAL;
+    const long total = floats * 2;                                   // bf16 elements
+    dcn_split_pack_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(weight, (unsigned short*)packed, Cout, C, total);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return -(long)e - 1000;
+    return floats;
+}
+
 // WAVES = output rows per block (one wave per row of 32 pixels): 8 -> one 92 KB block per CU; 4 -> two 55 KB blocks per
 // CU whose gather latencies and MFMA stretches overlap each other.
-template <int WAVES>
+// SPLIT: the GEMM runs on the bf16 matrix cores with the 3-way split arithmetic of conv_split.hip (fp32-equivalent): the
+// im2col values stay fp32 in LDS, a wave reads the 8 K-rows of its half (16s + 8*half + e) and splits them into three
+// packed-bf16 parts on the fly; the weights come split at pack time as MFMA A fragments
+// [chunk][k-step 3][part 3][cout tile 2][lane][8 bf16] (the chunk's 36 K-rows padded to 48).  The fp32 MFMA occupies
+// the vector ALU that the gather / blend arithmetic needs; the bf16 one does not.
+template <int WAVES, bool SPLIT>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void dcn_fused_kernel(DcnFusedArgs a) {
     constexpr int NPX = 32 * WAVES, NT = 64 * WAVES;       // pixels per tile, threads
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int WN = 64;
+    constexpr int WCH = SPLIT ? 3 * 3 * 2 * 64 * 4 : DF_ROWS * WN;   // floats of weights per chunk in LDS / in the packed tensor
     float* col0 = smem + a.front_pad;                    // [2][DF_ROWS][NPX]  (front_pad: debugging aid)
-    float* wl0 = col0 + 2 * DF_ROWS * NPX;               // [2][DF_ROWS][WN]
-    float* bias_s = wl0 + 2 * DF_ROWS * WN;              // [WN]
+    float* wl0 = col0 + 2 * DF_ROWS * NPX;               // [2][WCH]
+    float* bias_s = wl0 + 2 * WCH;                       // [WN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
     const int cg = blockIdx.y;
@@ -148,7 +220,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
     const float* imb = a.im[pz] + (long)b * a.im_bs[pz];
     const float* offb = a.offset[pz] + (long)b * a.offset_bs;
     const float* mskb = a.mask[pz] + (long)b * a.mask_bs;
-    const float* wbase = a.wp[pz] + (long)cg * a.Kpad * WN;
+    const float* wbase = SPLIT ? a.wp[pz] + (long)cg * (a.C / DF_CH) * WCH : a.wp[pz] + (long)cg * a.Kpad * WN;
     const int cpg = a.C / a.dg;
 
     // this thread's pixel and taps
@@ -169,15 +241,17 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    // geometry of the current deformable group
-    int go1[DF_PAIRS];                                   // offset of the (h_low, w_low) corner, or -1 if the tap is dead
-    int gfl[DF_PAIRS];                                   // corner validity bits
-    float gw1[DF_PAIRS], gw2[DF_PAIRS], gw3[DF_PAIRS], gw4[DF_PAIRS], gm[DF_PAIRS];
+    // geometry of the current deformable group.  Per (pixel, tap): the two corner ROWS as 8-byte pairs -- offset of the
+    // left element (clamped into [0, HW-2], so the unconditional dwordx2 load stays inside the plane) and the bilinear
+    // weight of each of the two loaded elements; an invalid corner (dcn_v2_im2col_cuda.cu:37-48) has weight 0, which
+    // reproduces its zero contribution without predicating the loads (half the load instructions, no branches).
+    int got[DF_PAIRS], gob[DF_PAIRS];
+    float gtx[DF_PAIRS], gty[DF_PAIRS], gbx[DF_PAIRS], gby[DF_PAIRS], gm[DF_PAIRS];
     auto geometry = [&](int g) {
 #pragma unroll
         for (int j = 0; j < DF_PAIRS; ++j) {
             const int tap = tap0 + 2 * j;
-            go1[j] = -1; gfl[j] = 0; gw1[j] = gw2[j] = gw3[j] = gw4[j] = 0.f; gm[j] = 0.f;
+            got[j] = gob[j] = 0; gtx[j] = gty[j] = gbx[j] = gby[j] = 0.f; gm[j] = 0.f;
             if (tap < 9 && pix_ok) {
                 const float* op = offb + (long)g * 18 * HW;
                 const float offset_h = op[(long)(2 * tap) * HW + p];
@@ -189,36 +263,38 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
                     const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
                     const int h_high = h_low + 1, w_high = w_low + 1;
                     const float lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
-                    gfl[j] = (h_low >= 0 && w_low >= 0 ? 1 : 0) | (h_low >= 0 && w_high <= W - 1 ? 2 : 0) |
-                             (h_high <= H - 1 && w_low >= 0 ? 4 : 0) | (h_high <= H - 1 && w_high <= W - 1 ? 8 : 0);
-                    gw1[j] = hh * hw; gw2[j] = hh * lw; gw3[j] = lh * hw; gw4[j] = lh * lw;
-                    go1[j] = h_low * W + w_low;          // may be "negative-ish" only where the flag is off
+                    const bool vt = h_low >= 0, vb = h_high <= H - 1, vl = w_low >= 0, vr = w_high <= W - 1;
+                    float tx_ = (vt && vl) ? hh * hw : 0.f, ty_ = (vt && vr) ? hh * lw : 0.f;
+                    float bx_ = (vb && vl) ? lh * hw : 0.f, by_ = (vb && vr) ? lh * lw : 0.f;
+                    int ot = vt ? h_low * W + w_low : 0, ob = vb ? h_high * W + w_low : 0;
+                    const int last = (int)HW - 1;
+                    if (ot < 0) { ot = 0; tx_ = ty_; ty_ = 0.f; } else if (ot >= last) { ot = last - 1; ty_ = tx_; tx_ = 0.f; }
+                    if (ob < 0) { ob = 0; bx_ = by_; by_ = 0.f; } else if (ob >= last) { ob = last - 1; by_ = bx_; bx_ = 0.f; }
+                    got[j] = ot; gob[j] = ob; gtx[j] = tx_; gty[j] = ty_; gbx[j] = bx_; gby[j] = by_;
                 }
             }
         }
     };
 
     float pre[DF_PAIRS][DF_CH][4];
-    constexpr int NWR = (DF_ROWS * 64 / 4 + NT - 1) / NT;
+    constexpr int NWR = (WCH / 4 + NT - 1) / NT;
     f32x4 wreg[NWR];
     auto issue = [&](int c0) {                           // corner values of channels c0..c0+3 for my pairs; weight rows
 #pragma unroll
         for (int j = 0; j < DF_PAIRS; ++j) {
 #pragma unroll
             for (int cl = 0; cl < DF_CH; ++cl) {
-                const float* ip = imb + (long)(c0 + cl) * HW + go1[j];
-                const int fl = gfl[j];
-                pre[j][cl][0] = (fl & 1) ? ip[0] : 0.f;
-                pre[j][cl][1] = (fl & 2) ? ip[1] : 0.f;
-                pre[j][cl][2] = (fl & 4) ? ip[W] : 0.f;
-                pre[j][cl][3] = (fl & 8) ? ip[W + 1] : 0.f;
+                const float* ip = imb + (long)(c0 + cl) * HW;
+                const f32x2u t2 = *(const f32x2u*)(ip + got[j]);         // 4-byte aligned 8-byte loads
+                const f32x2u b2 = *(const f32x2u*)(ip + gob[j]);
+                pre[j][cl][0] = t2[0]; pre[j][cl][1] = t2[1]; pre[j][cl][2] = b2[0]; pre[j][cl][3] = b2[1];
             }
         }
-        const f32x4* src = (const f32x4*)(wbase + (long)c0 * 9 * WN);       // rows (c0/2*9*2 ...) = c0*9
+        const f32x4* src = (const f32x4*)(SPLIT ? wbase + (long)(c0 / DF_CH) * WCH : wbase + (long)c0 * 9 * WN);   // fp32: rows c0*9
 #pragma unroll
         for (int j = 0; j < NWR; ++j) {
             const int i = tid + NT * j;
-            if (i < DF_ROWS * WN / 4) wreg[j] = src[i];
+            if (i < WCH / 4) wreg[j] = src[i];
         }
     };
     auto commit = [&](int buf) {
@@ -229,16 +305,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
             if (tap < 9) {
 #pragma unroll
                 for (int cl = 0; cl < DF_CH; ++cl) {
-                    const float val = (gw1[j] * pre[j][cl][0] + gw2[j] * pre[j][cl][1] + gw3[j] * pre[j][cl][2] + gw4[j] * pre[j][cl][3]);
+                    const float val = (gtx[j] * pre[j][cl][0] + gty[j] * pre[j][cl][1] + gbx[j] * pre[j][cl][2] + gby[j] * pre[j][cl][3]);
                     col[(((cl >> 1) * 9 + tap) * 2 + (cl & 1)) * NPX + pxl] = val * gm[j];
                 }
             }
         }
-        f32x4* w4 = (f32x4*)(wl0 + buf * DF_ROWS * WN);
+        f32x4* w4 = (f32x4*)(wl0 + buf * WCH);
 #pragma unroll
         for (int j = 0; j < NWR; ++j) {
             const int i = tid + NT * j;
-            if (i < DF_ROWS * WN / 4) w4[i] = wreg[j];
+            if (i < WCH / 4) w4[i] = wreg[j];
         }
     };
 
@@ -255,6 +331,33 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
             if (cnext % cpg == 0) geometry(cnext / cpg);      // next chunk starts a new deformable group
             issue(cnext);
         }
+        if constexpr (SPLIT) {
+            const float* colp = col0 + cur * DF_ROWS * NPX + wave * 32 + l31;
+            const dcn_u32x4* wfr = (const dcn_u32x4*)(wl0 + cur * WCH) + lane;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = 16 * ks + 8 * half + e;                      // K-row of this lane's half
+                    v[e] = (ks < 2 || r < DF_ROWS) ? colp[(r < DF_ROWS ? r : 0) * NPX] : 0.f;
+                    if (ks == 2 && r >= DF_ROWS) v[e] = 0.f;
+                }
+                dcn_u32x4 x[3];
+                dcn_split8(v, x);
+                dcn_u32x4 w[2][3];
+#pragma unroll
+                for (int part = 0; part < 3; ++part)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) w[t][part] = wfr[((ks * 3 + part) * 2 + t) * 64];
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dcn_bf16x8, w[t][DCN_PW[k]]),
+                                                                          __builtin_bit_cast(dcn_bf16x8, x[DCN_PX[k]]), acc[t], 0, 0, 0);
+            }
+        } else {
         const float* colb = col0 + cur * DF_ROWS * NPX + half * NPX + wave * 32 + l31;
         const float* wl = wl0 + cur * DF_ROWS * WN + half * WN + l31;
 #pragma unroll
@@ -271,6 +374,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][0], bv[t], acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][1], bv[t], acc[1], 0, 0, 0);
             }
+        }
         }
         if (more) commit(cur ^ 1);
         __syncthreads();
@@ -297,8 +401,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 extern "C" int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, const long* input_bs, const float* const* offset,
                                             const float* const* mask, const float* const* packed3x3, const float* const* bias,
                                             float* const* out, int B, int C, int H, int W, int Cout, int deformable_groups,
-                                            long offset_bs, long mask_bs, int act, void* stream) {
+                                            long offset_bs, long mask_bs, int act, int mma, void* stream) {
     if (P < 1 || P > 4 || !input || !offset || !mask || !packed3x3 || !out || B < 1) return MOTIF_EINVAL;
+    if (mma != 0 && mma != 6) return MOTIF_EINVAL;
     if (deformable_groups < 1 || C % deformable_groups || (C / deformable_groups) % DF_CH || (long)H * W >= (1L << 30)) return MOTIF_ELIMIT;
     if (act != MOTIF_ACT_NONE && act != MOTIF_ACT_LRELU && act != MOTIF_ACT_RELU) return MOTIF_ELIMIT;
     const long HW = (long)H * W;
@@ -323,18 +428,19 @@ extern "C" int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, co
     if (const char* ev = getenv("MOTIF_DCN_WAVES")) waves = atoi(ev) == 4 ? 4 : 8;
     a.front_pad = getenv("MOTIF_DCN_FRONT_PAD") ? atoi(getenv("MOTIF_DCN_FRONT_PAD")) : 0;
     const int back_pad = getenv("MOTIF_DCN_BACK_PAD") ? atoi(getenv("MOTIF_DCN_BACK_PAD")) : 0;
-    const size_t lds = (size_t)(2 * DF_ROWS * 32 * waves + 2 * DF_ROWS * 64 + 64 + a.front_pad + back_pad) * 4;
+    const int wch = mma == 6 ? 3 * 3 * 2 * 64 * 4 : DF_ROWS * 64;
+    const size_t lds = (size_t)(2 * DF_ROWS * 32 * waves + 2 * wch + 64 + a.front_pad + back_pad) * 4;
     dim3 grid(a.tiles_x * ((H + waves - 1) / waves), a.ncg, P * B);
-    hipError_t e;
-    if (waves == 8) {
-        e = hipFuncSetAttribute((const void*)dcn_fused_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        dcn_fused_kernel<8><<<grid, 512, lds, (hipStream_t)stream>>>(a);
-    } else {
-        e = hipFuncSetAttribute((const void*)dcn_fused_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        dcn_fused_kernel<4><<<grid, 256, lds, (hipStream_t)stream>>>(a);
-    }
+    hipError_t e = hipSuccess;
+#define MOTIF_LAUNCH_DCN(WV, SP)                                                                                          \
+    do {                                                                                                                  \
+        e = hipFuncSetAttribute((const void*)dcn_fused_kernel<WV, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return (int)e;                                                                               \
+        dcn_fused_kernel<WV, SP><<<grid, 64 * WV, lds, (hipStream_t)stream>>>(a);                                        \
+    } while (0)
+    if (waves == 8) { if (mma == 6) MOTIF_LAUNCH_DCN(8, true); else MOTIF_LAUNCH_DCN(8, false); }
+    else { if (mma == 6) MOTIF_LAUNCH_DCN(4, true); else MOTIF_LAUNCH_DCN(4, false); }
+#undef MOTIF_LAUNCH_DCN
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

@@ -182,13 +182,14 @@ def dcn_v2_multi(dplans, xs, oms, dg=8, act=ACT_NONE, kh=3, kw=3, stride=1, pad=
     fused = (kh == 3 and kw == 3 and stride == 1 and pad == 1 and dil == 1 and (c // dg) % 4 == 0
              and act in (ACT_NONE, ACT_LRELU, ACT_RELU) and not os.environ.get("MOTIF_DCN_UNFUSED"))
     if fused:
-        packs = [dp.plan3x3().packed() for dp in dplans]
+        split = _conv_mma == MMA_BF16X3 and not os.environ.get("MOTIF_DCN_FP32")
+        packs = [dp.packed_split() if split else dp.plan3x3().packed() for dp in dplans]
         biases = [dp.bias.detach() for dp in dplans]
         masks = (ctypes.c_void_p * P)(*[o.data_ptr() + 4 * 2 * dg * t * ho * wo for o in oms])
         bs = oms[0].stride(0)
         check(lib.motif_dcn_v2_fused_fwd_multi(P, _ptr_array(xs), (ctypes.c_long * P)(*[x.stride(0) for x in xs]), _ptr_array(oms), masks,
                                                _ptr_array(packs), _ptr_array(biases), _ptr_array(outs), b, c, h, w, co, dg, bs, bs, act,
-                                               _stream()), "motif_dcn_v2_fused_fwd_multi")
+                                               MMA_BF16X3 if split else MMA_FP32, _stream()), "motif_dcn_v2_fused_fwd_multi")
         return out
     cols = workspace(P * b * c * t * ho * wo, xs[0].device, "dcn_cols")
     plans = [dp.plan() for dp in dplans]
@@ -214,6 +215,23 @@ class DcnPlan:
         if getattr(self, "_p3", None) is None or self._p3.weight is not self.weight:
             self._p3 = ConvPlan(self.weight, self.bias, 1, 1, 1, 1, 0, mma=MMA_FP32)   # fused DCN reads the fp32 format
         return self._p3
+
+    def packed_split(self):
+        """Weights split into bf16 A fragments for the fused kernel's mma = 6 form (motif_dcn_split_pack)."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if getattr(self, "_skey", None) != key:
+            lib = _lib.load()
+            co, ci = w.shape[0], w.shape[1]
+            n = lib.motif_dcn_split_pack(None, None, co, ci, None)
+            if n <= 0:
+                raise RuntimeError("motif_dcn_split_pack size query failed (%d)" % n)
+            buf = torch.empty(n, dtype=torch.float32, device=w.device)
+            rc = lib.motif_dcn_split_pack(_p(_c(w.detach())), _p(buf), co, ci, _stream())
+            if rc != n:
+                raise RuntimeError("motif_dcn_split_pack failed (%d)" % rc)
+            self._spacked, self._skey = buf, key
+        return self._spacked
 
     def plan(self):
         w = self.weight
