@@ -108,12 +108,20 @@ extern "C" int motif_splat_fwd(const float* src, const float* flow, const float*
 // LDS list with a wave-aggregated append), accumulates 8 accumulator planes at a time in LDS (the padded
 // 18x66 tile absorbs footprint cells that spill over the border, so the inner loop has no bounds tests),
 // and writes each finished plane tile with plain coalesced stores.
-// LDS accumulation is 32.32 FIXED POINT with ds_add_u64: measured on MI355X (tools/ubench_atomics.hip)
-// ds_add_f32 retires one wave-instruction per ~194 cycles per CU, integer LDS atomics one per ~5 --
-// float LDS atomics are 40x slower than integer ones and slower than global_atomic_add_f32.  Each addend
-// (value*e^z, then *weight, both rounded to fp32 exactly as softsplat_cp.py:35-40 does) is converted
-// exactly up to 2^-32 (floor / fract / two cvt), summed as integers -- order independent, deterministic --
-// and rounded to fp32 once at write-out; the reference's own fp32 atomic sums vary run to run by more.
+// LDS accumulation is 32.32 FIXED POINT with ds_add_u64, on a PER-CELL binary scale: measured on MI355X
+// (tools/ubench_atomics.hip) ds_add_f32 retires one wave-instruction per ~194 cycles per CU, integer LDS
+// atomics one per ~5 -- float LDS atomics are 40x slower than integer ones and slower than
+// global_atomic_add_f32.  The reliability weight e^z = exp(-20 relu(p2)) (Ours.py:794) spans the whole fp32
+// range, so a fixed 2^-32 grid would flush exactly the occluded sources soft-splatting exists for.  A scale
+// pass therefore first takes, per accumulator cell, the maximum of e^z*weight over the contributing sources
+// (the reference's max plane, softsplat_max_cp.py:12-58, before its init-1 clamp) and its binary exponent E.
+// Each addend (value*e^z, then *weight, both rounded to fp32 exactly as softsplat_cp.py:35-40 does) is
+// multiplied by 2^-E -- exact, folded into the four corner weights -- so that the largest e^z*weight of a cell
+// lands in [1,2), then converted exactly up to 2^-32 (floor / fract / two cvt), summed as integers -- order
+// independent, deterministic -- and rounded to fp32 ONCE, together with the 2^E back-scale, at write-out.
+// Error bound: every addend is exact to 2^-32 of the cell's largest weight, so a normalised output
+// sum/warped_z (Ours.py:811-814) is off by at most (hits per cell) * 2^-32 * max|value| -- below one fp32 ulp
+// of the reference's own atomic sums, which vary run to run by more.
 // No global atomics, no zero-fill pass, and the two directions are summed in LDS.  A source whose
 // footprint leaves its own +-R neighbourhood ("far") is skipped here and scattered by
 // splat_far_kernel afterwards with global atomics -- both kernels evaluate the same predicate on the
@@ -176,20 +184,29 @@ __device__ __forceinline__ void add_fix(unsigned long long* cell, float x) {
     atomicAdd(cell, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)lo);
 }
 
-__device__ __forceinline__ float fix_to_float(unsigned long long v) {
-    return (float)((double)(long long)v * (1.0 / 4294967296.0));
+__device__ __forceinline__ float fix_to_float(unsigned long long v, int E) {
+    return (float)ldexp((double)(long long)v, E - 32);        // one rounding: exact integer sum * 2^(E-32)
+}
+
+// binary exponent E of a cell's largest e^z*weight m (float bits; m >= 0): m * 2^-E in [1,2); E = 0 for an empty cell
+__device__ __forceinline__ int cell_exponent(unsigned bits) {
+    return bits ? (int)(bits >> 23) - 127 : 0;
 }
 
 __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs a, int cap) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned long long* tile = (unsigned long long*)lds;            // [OT_CC][OT_TP] 32.32 fixed point
-    unsigned* list = (unsigned*)(tile + OT_CC * OT_TP);              // [cap]
+    unsigned* tmaxb = (unsigned*)(tile + OT_CC * OT_TP);             // [OT_TP] float bits of max e^z*w (>= 0: unsigned order)
+    unsigned* tcnt = tmaxb + OT_TP;                                  // [OT_TP] hit count
+    int* texp = (int*)(tcnt + OT_TP);                                // [OT_TP] per-cell scale exponent E
+    unsigned* list = (unsigned*)(texp + OT_TP);                      // [cap]
     __shared__ unsigned count;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bn = blockIdx.z, b = bn / a.N, n = bn % a.N;
     const int tx0 = blockIdx.x * OT_W, ty0 = blockIdx.y * OT_H;
     const long Q = (long)a.HH * a.WW, HWl = (long)a.H * a.W;
     if (tid == 0) count = 0;
+    for (int i = tid; i < OT_TP; i += OT_THREADS) { tmaxb[i] = 0u; tcnt[i] = 0u; }
     __syncthreads();
 
     // ---- pass 1: compact the contributing sources of both directions
@@ -220,16 +237,32 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
     __syncthreads();
     const int cnt = (int)count;
 
+    // ---- scale pass: per cell max of e^z*weight (= the max plane before its init-1 clamp) and the hit count
+    for (int e = tid; e < cnt; e += OT_THREADS) {
+        const unsigned ent = list[e];
+        const int d = ent >> 16, y = ry0 + ((ent >> 8) & 255), x = rx0 + (ent & 255);
+        const SrcGeom g = src_geom(a, (d * a.B + b) * a.N + n, x, y, true);
+        const int off = (g.y0 - (ty0 - 1)) * OT_TPW + (g.x0 - (tx0 - 1));
+        unsigned* tm = tmaxb + off;
+        atomicMax(tm, __float_as_uint(g.e * g.wnw));
+        atomicMax(tm + 1, __float_as_uint(g.e * g.wne));
+        atomicMax(tm + OT_TPW, __float_as_uint(g.e * g.wsw));
+        atomicMax(tm + OT_TPW + 1, __float_as_uint(g.e * g.wse));
+        unsigned* tn = tcnt + off;
+        atomicAdd(tn, 1u);
+        atomicAdd(tn + 1, 1u);
+        atomicAdd(tn + OT_TPW, 1u);
+        atomicAdd(tn + OT_TPW + 1, 1u);
+    }
+    __syncthreads();
+    for (int i = tid; i < OT_TP; i += OT_THREADS) texp[i] = cell_exponent(tmaxb[i]);
+
     // ---- pass 2: 128 feature planes in 16 chunks of 8, then [128, 129, norm | max | count]
     float* abase = a.acc + (long)bn * 133 * Q;
-    float* tmax = (float*)(tile + 3 * OT_TP);          // last chunk only: fp32 max plane, uint count plane
-    unsigned* tcnt = (unsigned*)(tmax + OT_TP);
     for (int k = 0; k < 17; ++k) {
         const bool last = (k == 16);
         const int n64 = (last ? 3 : OT_CC) * OT_TP;
         for (int i = tid; i < n64; i += OT_THREADS) tile[i] = 0ull;
-        if (last)
-            for (int i = tid; i < OT_TP; i += OT_THREADS) { tmax[i] = 1.0f; tcnt[i] = 0u; }
         __syncthreads();
         for (int e = tid; e < cnt; e += OT_THREADS) {
             const unsigned ent = list[e];
@@ -237,6 +270,10 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
             const int db = d * a.B + b, img = db * a.N + n;
             const SrcGeom g = src_geom(a, img, x, y, true);
             const int off = (g.y0 - (ty0 - 1)) * OT_TPW + (g.x0 - (tx0 - 1));
+            const int* te = texp + off;
+            // weight * 2^-E(cell): exact, so (v*e)*w' == ((v*e)*w) * 2^-E bit for bit
+            const float wnw = ldexpf(g.wnw, -te[0]), wne = ldexpf(g.wne, -te[1]);
+            const float wsw = ldexpf(g.wsw, -te[OT_TPW]), wse = ldexpf(g.wse, -te[OT_TPW + 1]);
             const long p = (long)y * a.WW + x;
             const long lr = (long)a.iy[y] * a.W + a.ix[x];
             if (!last) {
@@ -253,31 +290,21 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
                 for (int cc = 0; cc < OT_CC; ++cc) {
                     const float ve = v[cc] * g.e;
                     unsigned long long* tc = tile + cc * OT_TP + off;
-                    add_fix(tc, ve * g.wnw);
-                    add_fix(tc + 1, ve * g.wne);
-                    add_fix(tc + OT_TPW, ve * g.wsw);
-                    add_fix(tc + OT_TPW + 1, ve * g.wse);
+                    add_fix(tc, ve * wnw);
+                    add_fix(tc + 1, ve * wne);
+                    add_fix(tc + OT_TPW, ve * wsw);
+                    add_fix(tc + OT_TPW + 1, ve * wse);
                 }
             } else {
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc) {
                     const float ve = (cc < 2) ? a.feat_lr[((long)db * 64 + 62 + cc) * HWl + lr] * g.e : g.e;
                     unsigned long long* tc = tile + cc * OT_TP + off;
-                    add_fix(tc, ve * g.wnw);
-                    add_fix(tc + 1, ve * g.wne);
-                    add_fix(tc + OT_TPW, ve * g.wsw);
-                    add_fix(tc + OT_TPW + 1, ve * g.wse);
+                    add_fix(tc, ve * wnw);
+                    add_fix(tc + 1, ve * wne);
+                    add_fix(tc + OT_TPW, ve * wsw);
+                    add_fix(tc + OT_TPW + 1, ve * wse);
                 }
-                float* tm = tmax + off;
-                atomic_max_float(tm, g.e * g.wnw);
-                atomic_max_float(tm + 1, g.e * g.wne);
-                atomic_max_float(tm + OT_TPW, g.e * g.wsw);
-                atomic_max_float(tm + OT_TPW + 1, g.e * g.wse);
-                unsigned* tn = tcnt + off;
-                atomicAdd(tn, 1u);
-                atomicAdd(tn + 1, 1u);
-                atomicAdd(tn + OT_TPW, 1u);
-                atomicAdd(tn + OT_TPW + 1, 1u);
             }
         }
         __syncthreads();
@@ -288,8 +315,8 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
             if (Y >= a.HH || X >= a.WW) continue;
             const int cell = (ly + 1) * OT_TPW + lx + 1;
             float v;
-            if (!last || cc < 3) v = fix_to_float(tile[cc * OT_TP + cell]);
-            else if (cc == 3) v = tmax[cell];
+            if (!last || cc < 3) v = fix_to_float(tile[cc * OT_TP + cell], texp[cell]);
+            else if (cc == 3) v = fmaxf(1.0f, __uint_as_float(tmaxb[cell]));     // max-splat output starts at ones (softsplat_max_cp.py:254)
             else v = (float)tcnt[cell];
             abase[(long)(k * OT_CC + cc) * Q + (long)Y * a.WW + X] = v;
         }
@@ -340,7 +367,7 @@ extern "C" int motif_splat_motif_fwd(const float* imnet_out, const float* pred, 
     if (B < 1 || N < 1 || H < 1 || W < 1 || HH < 1 || WW < 1 || row0 < 0) return MOTIF_EINVAL;
     MotifSplatArgs a{imnet_out, pred, feat_lr, iy, ix, alpha, 20.0f, flow_scale, acc, B, N, H, W, HH, WW, 16, row0};
     const int cap = 2 * (OT_H + 2 * a.R) * (OT_W + 2 * a.R);
-    const size_t lds = (size_t)OT_CC * OT_TP * 8 + (size_t)cap * 4;
+    const size_t lds = (size_t)OT_CC * OT_TP * 8 + (size_t)3 * OT_TP * 4 + (size_t)cap * 4;
     hipError_t e = hipFuncSetAttribute((const void*)splat_owner_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     dim3 grid((WW + OT_W - 1) / OT_W, (HH + OT_H - 1) / OT_H, B * N);

@@ -502,6 +502,55 @@ def test_splat_motif_owner_computes_vs_kernel_text(far):
     close(acc[:, :131], ssum, 3e-5, 1e-5, "sum planes")
 
 
+def test_splat_motif_keeps_dynamic_range_of_low_reliability_sources():
+    """Occluded / unreliable sources: relu(pred2) in [0, 3] with alpha = -20 gives e^z down to e^-60 (Ours.py:794).
+    The reference's fp32 atomics keep such addends (softsplat_cp.py:35-50) and the post-splat normalisation
+    (Ours.py:811-830) divides them out again, so cells reached ONLY by unreliable sources still get a correctly
+    normalised feature.  Bars: hit count exact; warped_z == 0 set identical; warped_z and z_max within 3e-5 relative
+    (no absolute floor: the values span 26 decades); normalised output within 3e-5; two runs bit-identical."""
+    from oracle import native
+    from motif_amd import ops
+    B, N, H, W, s = 1, 2, 16, 24, 4
+    HH, WW = H * s, W * s
+    iy, ix, _, _ = _tables(H, W, HH, WW)
+    iyc, ixc = iy.cpu().long(), ix.cpu().long()
+    imnet_out = rnd(2 * B, 64, HH, WW, seed=1)
+    feat_lr = rnd(2 * B, 64, H, W, seed=2)
+    pred = rnd(2 * B * N, 3, HH, WW, seed=3, scale=0.05)
+    p2 = torch.rand(2 * B * N, HH, WW, generator=torch.Generator().manual_seed(4)) * 3.0          # z in [-60, 0]
+    p2[:, 10:30, 20:60] = 2.0 + p2[:, 10:30, 20:60] / 3.0      # a region where EVERY contributor is tiny (e^z < 4e-18)
+    p2[:, 40:44] = 0.0                                         # and fully reliable rows next to it
+    p2[0, 50:54, 30:40] = -1.0                                 # relu clamps negatives: e^z = 1
+    pred[:, 2] = p2
+    pred[0, 0, 6, 10], pred[0, 1, 6, 10] = 0.3, 0.2            # one far source (24, 16 px) -> fp32 global-atomic fallback path
+    alpha = torch.tensor([-20.0])
+    flow = pred[:, :2] * 20.0 * (HH / H)
+    ez = (F.relu(pred[:, 2:3]) * alpha).exp()
+    assert float(ez.min()) < 1e-25
+    feat_low = feat_lr[:, :, iyc][:, :, :, ixc]
+    rep = lambda t: t.repeat(1, N, 1, 1).reshape(2 * B * N, -1, HH, WW)
+    feat_all = torch.cat([rep(imnet_out), pred[:, :2], rep(feat_low)], 1)
+    ssum = native.splat(torch.cat([feat_all * ez, ez], 1), flow, "sum").reshape(2, B * N, 131, HH, WW).sum(0)
+    smax = native.splat(ez, flow, "max").reshape(2, B * N, 1, HH, WW).max(0)[0]
+    scnt = native.splat(torch.ones_like(ez), flow, "count").reshape(2, B * N, 1, HH, WW).sum(0)
+    args = (imnet_out.to(dev()), pred.to(dev()), feat_lr.to(dev()), iy, ix, alpha.to(dev()), HH / H, B, N, HH, WW)
+    acc = ops.splat_motif(*args).cpu()
+    assert torch.equal(acc, ops.splat_motif(*args).cpu()), "owner-computes splat must be run-to-run bit-identical"
+    assert torch.equal(acc[:, 132:133], scnt), "count plane must be exact"
+    wz_ref, wz = ssum[:, 130:131], acc[:, 130:131]
+    assert torch.equal(wz == 0, wz_ref == 0), "warped_z == 0 set (Ours.py:811) differs"
+    hit_only_tiny = (wz_ref > 0) & (wz_ref < 1e-12)
+    assert int(hit_only_tiny.sum()) > 500, "test must reach cells whose every contributor is unreliable"
+    rel = lambda x, r: float(((x - r).abs() / r.abs().clamp_min(1e-37)).max())
+    assert rel(wz, wz_ref) < 3e-5, rel(wz, wz_ref)
+    assert rel(acc[:, 131:132], smax) < 3e-5
+    assert torch.equal(acc[:, 131:132] == 1.0, smax == 1.0)
+    one = lambda t: torch.where(t == 0, torch.ones_like(t), t)
+    out_ref, out = ssum[:, :130] / one(wz_ref), acc[:, :130] / one(wz)          # Ours.py:811-814
+    close(out, out_ref, 3e-5, 3e-5, "normalised splat output")
+    close(out[hit_only_tiny.expand_as(out)], out_ref[hit_only_tiny.expand_as(out)], 3e-5, 3e-5, "normalised output, unreliable-only cells")
+
+
 def test_dcn_fused_multi_vs_kernel_text():
     """Fused DCN (deformable im2col in LDS + MFMA, multi-problem) == the kernel-text restatement, including
     offsets that leave the image, the (-1, 0) border band, and odd image sizes."""
