@@ -6,8 +6,12 @@ x6 temporal = 7 timestamps (BASELINE.json configs[1], "c2"), B = 1 clip per step
 metric = HR pixels / second = T*B*HH*WW / wall, whole job over all ranks (clips shard embarrassingly:
 rank r renders its own clips, weak scaling; the only collective is the final gather of the uint8 frames).
 
-Arithmetic (--mma): "bf16x3" (default) runs the dense contractions (3x3 convolutions, the three MLPs) on the bf16
-matrix cores with every fp32 operand split exactly into three bf16 parts and six products accumulated in fp32 --
+Launch: `python bench.py --gpus N` starts N ranks itself (a `python -m torch.distributed.run` child, started before
+this process touches the GPU; nothing is re-exec'ed) when it is not already running under a launcher; under
+`torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.  Rank 0 prints the one JSON line.
+
+Arithmetic (--mma): "bf16x3" (default) runs the dense contractions (3x3 convolutions, fused DCN, the three MLPs) on the
+bf16 matrix cores with every fp32 operand split exactly into three bf16 parts and six products accumulated in fp32 --
 fp32-equivalent (error below an fp32 FMA chain, tests/test_kernels_gpu.py::test_conv_split_engine_is_fp32_equivalent);
 "fp32" runs them on v_mfma_f32_32x32x2_f32.  The line carries the fp32-MFMA number of the same run as `fp32_mfma`.
 
@@ -16,21 +20,26 @@ Extra objects on the JSON line:
                --mma fp32): algorithmic FLOP of its launches / their measured duration (events on the launch
                stream, one instrumented clip after the timed region).  Peak: bf16 dense MFMA 2500 TFLOP/s / 6
                products per fp32 MAC = 416.7 TFLOP/s for bf16x3, 157.3 TFLOP/s fp32 MFMA for fp32.
-  cpu_baseline the CPU oracle (oracle/, "port" of the reference) on a bounded crop of the same workload.
+  stages       the same measurement for every stage of the path (event pairs around each C-ABI call of the
+               instrumented clip): ms per clip, algorithmic work, achieved rate, the bound and the fraction of it.
+  parity       PSNR / L-inf of the HIP path against the CPU oracle on the cpu_baseline clip (both engines).
+  cpu_baseline the CPU oracle (oracle/, "port" of the reference) on a bounded crop of the same workload, plus the
+               reference's own CPU-runnable case c1.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0         # same guide, "Peak BF16/FP16 MFMA" dense
+HBM_PEAK_GBS = 8000.0                  # same guide, HBM3E
 
 
 def parse():
@@ -46,19 +55,69 @@ def parse():
     ap.add_argument("--streams", type=int, default=1, help="clips in flight per GPU (each on its own HIP stream and model instance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU/gloo plumbing test of the --gpus launcher: N ranks, barrier, gather, one JSON line; no GPU work")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------- launcher
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """`bench.py --gpus N` outside a launcher: run N ranks as a child `torch.distributed.run` job and exit with its
+    status.  This parent never initialises the GPU (no torch.cuda call before this point) and never exec()s."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def launcher_selftest(a, world, rank):
+    import torch
+    import torch.distributed as dist
+    from motif_amd import dist as mdist
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    mine = torch.full((1, 2, 4, 4, 3), rank, dtype=torch.uint8)                 # this rank's "clip" of uint8 frames
+    t0 = time.perf_counter()
+    out = mdist.gather_to_rank0(mine, world)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        assert [int(out[r].max()) for r in range(world)] == list(range(world))
+        print(json.dumps({"metric": "launcher selftest", "value": 0.0, "unit": "px/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": 1000.0 * dt, "backend": "gloo", "data": "none"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------- stage timers
 def conv_flops(desc_log):
     return sum(2.0 * n * co * (ci // g) * kh * kw * ho * wo for (n, co, ci, g, kh, kw, ho, wo) in desc_log)
 
 
+IMNET_MAC, FLOW_MAC, SYNTH_MAC = 41088, 25536, 38016          # per point, SURVEY.md §8(a) B1-B3
+SPLAT_BYTES_PER_PXFRAME = 2 * (64 * 4 + 3 * 4) + 133 * 4      # fused form: imnet_out + pred of both directions read, 133 planes written
+
+
 def instrumented_clip(model, sample):
-    """Re-run one clip with event pairs around every conv-engine launch (same stream as the launches)."""
+    """Re-run one clip with event pairs around every C-ABI call of the stages below (same stream as the launches; RAFT
+    moved onto the main stream so that no other kernel runs beside the one being timed)."""
+    import torch
     from motif_amd import ops
-    log, events = [], []
-    orig = ops.conv2d
     split = ops.get_conv_mma() != ops.MMA_FP32
+    rec = []                                                         # (stage, e0, e1, work, conv desc or None)
+    saved = {}
+
+    def ev():
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def dominant(plan):          # launches served by the dominant kernel (same rule as the C side)
         co, cig, kh, kw = plan.weight.shape
@@ -66,82 +125,160 @@ def instrumented_clip(model, sample):
             return kh == 3 and kw == 3 and plan.stride == 1 and plan.dil == 1 and cig >= 16 and co > 32 * plan.groups
         return co > 32 * plan.groups
 
-    def timed_conv(plan, x, x2=None, *a, **k):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig(plan, x, x2, *a, **k)
-        e1.record()
+    def hook(name, stage_work):
+        orig = getattr(ops, name)
+        saved[name] = orig
+
+        def timed(*args, **kw):
+            e0, e1 = ev()
+            e0.record()
+            out = orig(*args, **kw)
+            e1.record()
+            stage, work, desc = stage_work(out, *args, **kw)
+            rec.append((stage, e0, e1, work, desc))
+            return out
+        setattr(ops, name, timed)
+
+    def conv_sw(out, plan, x, *a, **k):
         co, cig, kh, kw = plan.weight.shape
-        events.append((e0, e1, dominant(plan)))
-        log.append((x.shape[0], co, cig * plan.groups, plan.groups, kh, kw, out.shape[2], out.shape[3]))
-        return out
+        d = (x.shape[0], co, cig * plan.groups, plan.groups, kh, kw, out.shape[2], out.shape[3])
+        return ("conv3x3" if dominant(plan) else "conv_other"), conv_flops([d]), d
 
-    orig_multi = ops.conv2d_multi
+    def convm_sw(out, plans, xs, *a, **k):
+        p0 = plans[0]
+        co, cig, kh, kw = p0.weight.shape
+        d = (len(plans) * xs[0].shape[0], co, cig * p0.groups, p0.groups, kh, kw, out.shape[3], out.shape[4])
+        return ("conv3x3" if dominant(p0) else "conv_other"), conv_flops([d]), d
 
-    def timed_multi(plans, xs, x2s=None, *a, **k):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig_multi(plans, xs, x2s, *a, **k)
-        e1.record()
-        co, cig, kh, kw = plans[0].weight.shape
-        events.append((e0, e1, dominant(plans[0])))
-        log.append((len(plans) * xs[0].shape[0], co, cig * plans[0].groups, plans[0].groups, kh, kw, out.shape[3], out.shape[4]))
-        return out
+    def dcn_sw(out, dplans, xs, oms, *a, **k):
+        P, b, co, ho, wo = out.shape
+        return "dcn", 2.0 * P * b * co * xs[0].shape[1] * 9 * ho * wo, None
 
-    ops.conv2d = timed_conv
-    ops.conv2d_multi = timed_multi
+    hook("conv2d", conv_sw)
+    hook("conv2d_multi", convm_sw)
+    hook("dcn_v2_multi", dcn_sw)
+    hook("siren_imnet", lambda out, *a, **k: ("imnet", 2.0 * IMNET_MAC * out.shape[0] * out.shape[2] * out.shape[3], None))
+    hook("siren_flow", lambda out, *a, **k: ("flow_imnet", 2.0 * FLOW_MAC * out.shape[0] * out.shape[2] * out.shape[3], None))
+    hook("siren_synth", lambda out, *a, **k: ("synth_net", 2.0 * SYNTH_MAC * out.shape[0] * out.shape[1] * out.shape[3] * out.shape[4], None))
+    hook("splat_motif", lambda out, *a, **k: ("splat", float(SPLAT_BYTES_PER_PXFRAME) * out.shape[0] * out.shape[2] * out.shape[3], None))
+    hook("raft_corr_lookup_pyramid", lambda out, *a, **k: ("raft_lookup", 0.0, None))
+    hook("instance_norm", lambda out, *a, **k: ("instance_norm", 0.0, None))
+    hook("resize_bilinear", lambda out, *a, **k: ("resize", 0.0, None))
+    hook("reliability", lambda out, *a, **k: ("reliability", 0.0, None))
     net = model.netG
     overlap = getattr(net, "overlap_raft", False)
     net.overlap_raft = False          # per-kernel durations: no concurrent side stream while instrumenting
+    c0, c1 = ev()
     try:
+        c0.record()
         model.feed_data(sample)
         model.test()
+        c1.record()
         torch.cuda.synchronize()
     finally:
-        ops.conv2d = orig
-        ops.conv2d_multi = orig_multi
+        for name, fn in saved.items():
+            setattr(ops, name, fn)
         net.overlap_raft = overlap
-    big = [(e0.elapsed_time(e1), l) for (e0, e1, is_nc2), l in zip(events, log) if is_nc2]
-    ms = sum(t for t, _ in big)
-    fl = conv_flops([l for _, l in big])
-    all_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
+    mfma_peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
+    bounds = {"conv3x3": "mfma", "conv_other": "mfma", "dcn": "mfma", "imnet": "mfma", "flow_imnet": "mfma", "synth_net": "mfma", "splat": "hbm"}
+    stages = {}
+    for stage, e0, e1, work, _ in rec:
+        s = stages.setdefault(stage, {"ms": 0.0, "launches": 0, "work": 0.0})
+        s["ms"] += e0.elapsed_time(e1)
+        s["launches"] += 1
+        s["work"] += work
+    table = {}
+    for stage, s in stages.items():
+        row = {"ms_per_clip": round(s["ms"], 3), "calls": s["launches"]}
+        b = bounds.get(stage)
+        if b == "mfma" and s["ms"] > 0:
+            peak = FP32_MFMA_PEAK_TFLOPS if stage == "conv_other" else mfma_peak          # non-3x3 / narrow layers run on the fp32 MFMA
+            ach = s["work"] / (s["ms"] * 1e-3) / 1e12
+            row.update(bound="mfma", tflop=round(s["work"] / 1e12, 4), achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4))
+        elif b == "hbm" and s["ms"] > 0:
+            ach = s["work"] / (s["ms"] * 1e-3) / 1e9
+            row.update(bound="hbm", gbyte=round(s["work"] / 1e9, 3), achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
+        table[stage] = row
+    table["_clip"] = {"ms_instrumented": round(c0.elapsed_time(c1), 3), "ms_in_stages": round(sum(s["ms"] for s in stages.values()), 3)}
+    big = [(e0.elapsed_time(e1), d) for stage, e0, e1, _, d in rec if stage == "conv3x3"]
+    allc = [(e0.elapsed_time(e1), d) for stage, e0, e1, _, d in rec if d is not None]
     if os.environ.get("MOTIF_BENCH_SHAPES"):
         shapes = {}
-        for (e0, e1, _), l in zip(events, log):
-            t = shapes.setdefault(l, [0, 0.0])
+        for ms_, d in allc:
+            t = shapes.setdefault(d, [0, 0.0])
             t[0] += 1
-            t[1] += e0.elapsed_time(e1)
+            t[1] += ms_
         print("# conv shapes: (N,Cout,Cin,groups,KH,KW,Ho,Wo) launches total_ms TFLOP/s", file=sys.stderr)
-        for l, (cnt, ms_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
-            print("# %-40s %5d %9.3f %8.1f" % (l, cnt, ms_, conv_flops([l]) * cnt / (ms_ * 1e-3) / 1e12), file=sys.stderr)
-    return dict(launches=len(big), ms=ms, flops=fl, all_conv_ms=all_ms, all_conv_flops=conv_flops(log), all_launches=len(log))
+        for d, (cnt, ms_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+            print("# %-40s %5d %9.3f %8.1f" % (d, cnt, ms_, conv_flops([d]) * cnt / (ms_ * 1e-3) / 1e12), file=sys.stderr)
+    return dict(launches=len(big), ms=sum(t for t, _ in big), flops=conv_flops([d for _, d in big]),
+                all_conv_ms=sum(t for t, _ in allc), all_conv_flops=conv_flops([d for _, d in allc]), table=table)
 
 
-def cpu_baseline(times):
-    """The CPU oracle on a bounded crop of the workload: LR 48x80 -> 192x320, same 7 timestamps, same
-    <=3-timestamp chunking with everything recomputed per chunk (the reference's schedule)."""
+# ------------------------------------------------------------------------------------------------- CPU oracle legs
+def _oracle_clip(h, w, s, times, seed=0):
+    """The CPU oracle on one synthetic clip with the reference's schedule (<= 3 timestamps per forward, everything
+    recomputed per chunk, VideoSR_base_model.py:189-193).  -> sample, frames [T,1,3,HH,WW], last chunk's flow, seconds"""
+    import torch
     from oracle.motif_ref import MotifRef
     from motif_amd.data.synthetic import synthetic_sample
     from motif_amd.utils.synth_weights import fill_state_dict
-    h, w, s = 48, 80, 4
-    sample = synthetic_sample(h, w, s, times)
+    sample = synthetic_sample(h, w, s, times, seed=seed)
     net = fill_state_dict(MotifRef().eval())
-    cores = torch.get_num_threads()
+    outs, flow = [], None
     t0 = time.time()
     with torch.no_grad():
         for l in range(0, times, 3):
-            net(sample["LQs"], None, sample["time"][l:l + 3], sample["scale"], use_GT=False, iter=4)
-    dt = time.time() - t0
-    return {"value": times * h * s * w * s / dt, "unit": "HR px/s", "cores": cores, "kind": "port",
-            "sample": "oracle/motif_ref.py (CPU restatement, bit-identical to the reference on the goldens), one clip "
-                      "LR %dx%d -> %dx%d, %d timestamps in chunks of 3, %.1f s on %d torch threads" % (h, w, h * s, w * s, times, dt, cores)}
+            o, flow, _ = net(sample["LQs"], None, sample["time"][l:l + 3], sample["scale"], use_GT=False, iter=4)
+            outs.append(o)
+    return sample, torch.cat(outs, 0), flow, time.time() - t0
 
 
+def cpu_baseline_and_parity(times, model, mma):
+    """cpu_baseline: the oracle on a bounded crop of c2 (LR 48x80 -> 192x320, same 7 timestamps) and on c1, the
+    reference's own CPU-runnable configuration (LR 64x64, x2 spatial, 3 timestamps).  parity: the HIP path on the same
+    crop clip against the oracle's frames, for both arithmetic engines."""
+    import numpy as np
+    import torch
+    from motif_amd import ops
+    h, w, s = 48, 80, 4
+    cores = torch.get_num_threads()
+    sample, ref, rflow, dt = _oracle_clip(h, w, s, times)
+    _, _, _, dt1 = _oracle_clip(64, 64, 2, 3)
+    base = {"value": times * h * s * w * s / dt, "unit": "HR px/s", "cores": cores, "kind": "port",
+            "sample": "oracle/motif_ref.py (CPU restatement, bit-identical to the reference on the goldens), one c2 clip cropped to "
+                      "LR %dx%d -> %dx%d, %d timestamps in chunks of 3, %.1f s on %d torch threads" % (h, w, h * s, w * s, times, dt, cores),
+            "c1": {"value": 3 * 128 * 128 / dt1, "unit": "HR px/s",
+                   "sample": "BASELINE configs[0]: LR 64x64 -> 128x128 (x2 spatial, x2 temporal = 3 timestamps), %.1f s" % dt1}}
+    data = {"LQs": sample["LQs"].cuda(), "GT": sample["GT"][:, :1].cuda(), "time": [t.cuda() for t in sample["time"]], "scale": sample["scale"]}
+    parity = {"clip": "the cpu_baseline crop clip, all %d timestamps" % times, "tolerance": "PSNR >= 60 dB, flow L-inf <= 2e-3 (tests/test_model_gpu.py)"}
+    try:
+        for mode in ("bf16x3", "fp32"):
+            ops.set_mma(mode)
+            model.feed_data(data)
+            model.test()
+            out = model.fake_H.float().cpu()
+            mse = float(((out.double() - ref.double()) ** 2).mean())
+            parity[mode] = {"psnr_vs_oracle": 99.0 if mse == 0 else round(10 * np.log10(1.0 / mse), 2),
+                            "linf_vs_oracle": float((out - ref).abs().max()),
+                            "linf_flow": float((model.flow.float().cpu() - rflow).abs().max())}
+    finally:
+        ops.set_mma(mma)
+    return base, parity
+
+
+# ------------------------------------------------------------------------------------------------- main
 def main():
     a = parse()
+    in_launcher = "WORLD_SIZE" in os.environ
+    if a.gpus > 1 and not in_launcher:
+        raise SystemExit(spawn_ranks(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.launcher_selftest:
+        return launcher_selftest(a, world, rank)
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU route")
     torch.cuda.set_device(local)
@@ -178,7 +315,7 @@ def main():
             m.feed_data(clips[i % 2])
             m.test()
             if world > 1:
-                u8 = mdist.frames_to_uint8(m.fake_H.permute(1, 0, 2, 3, 4))       # [B,T,3,HH,WW] = this rank's clip
+                u8 = mdist.frames_to_uint8(m.fake_H.permute(1, 0, 2, 3, 4))       # [B,T,HH,WW,3] = this rank's clip, encode kernel
                 mdist.gather_to_rank0(u8, world)
         return m.fake_H
 
@@ -210,12 +347,15 @@ def main():
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"arithmetic": ("fp32-equivalent on the bf16 matrix cores: every fp32 operand = 3 exact bf16 parts, 6 products, fp32 "
-                                  "accumulate (3x3 convolutions and the three MLPs); everything else fp32" if a.mma == "bf16x3"
+                                  "accumulate (3x3 convolutions, fused DCN and the three MLPs); everything else fp32" if a.mma == "bf16x3"
                                   else "fp32 MFMA (v_mfma_f32_32x32x2_f32) and fp32 VALU"),
                    "workload": "c2: 4-frame %dx%d LR clip -> %dx%d (x%d spatial), x%dt = %d timestamps, B=1 clip per step per GPU, "
                                "RAFT-small iters=4, seeded key-hashed weights" % (h, w, HH, WW, a.scale, a.times - 1, a.times),
                    "parallelism": "clips sharded per GPU (dp%d), uint8 frame gather to rank 0" % world},
     }
+    if world > 1:
+        line["collective"] = {"backend": dist.get_backend(), "library": "RCCL (torch.distributed 'nccl' on ROCm)",
+                              "version": ".".join(str(v) for v in torch.cuda.nccl.version())}
     if a.mma == "bf16x3" and not a.no_fp32_leg:
         # the same job on the fp32 MFMA (all ranks, same barriers), reported next to the headline value
         from motif_amd import ops
@@ -228,22 +368,25 @@ def main():
         if not a.no_roofline:
             r = instrumented_clip(model, clips[0])
             ach = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
-            traffic = None
             split = a.mma == "bf16x3"
-            tj = os.path.join(ROOT, "profiles", "r01_conv_split_traffic.json" if split else "r01_conv_traffic.json")
-            if os.path.exists(tj):          # PMC run of the same kernel (separate --pmc passes), see the file's note
-                traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+            traffic, traffic_src = None, None
+            for name in ("r02_conv_split_traffic.json", "r01_conv_split_traffic.json") if split else ("r01_conv_traffic.json",):
+                tj = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(tj):          # rocprofv3 PMC passes of this kernel (FETCH_SIZE / WRITE_SIZE), not collected in this run
+                    traffic, traffic_src = json.load(open(tj)).get("hbm_bytes_per_launch"), "profiles/" + name
+                    break
             peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
             line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                                "frac": ach / peak, "traffic": traffic,
+                                "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
                                 "peak_basis": ("bf16 dense MFMA 2500 TFLOP/s / 6 bf16 products per fp32 MAC" if split
                                                else "fp32 MFMA 157.3 TFLOP/s"),
                                 "kernel": "conv_split_kernel<3,4>" if split else "conv_igemm_kernel<2>", "launches_per_clip": r["launches"],
                                 "avg_launch_us": 1000.0 * r["ms"] / max(r["launches"], 1),
                                 "avg_launch_gflop": r["flops"] / max(r["launches"], 1) / 1e9,
                                 "all_conv_ms_per_clip": r["all_conv_ms"], "all_conv_tflop_per_clip": r["all_conv_flops"] / 1e12}
+            line["stages"] = r["table"]
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(a.times)
+            line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(a.times, model, a.mma)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

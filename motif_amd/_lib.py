@@ -1,7 +1,8 @@
 """ctypes binding of libmotif_hip.so (the C ABI declared in include/motif_hip.h).
 
-The product path has NO fallback: if the shared library is missing or a call fails, a RuntimeError is
-raised (SURVEY.md §8(b) "Errors").  `load(build=True)` may compile it with hipcc (in-tree) first.
+The product path has NO fallback: if the shared library cannot be had or a call fails, a RuntimeError is
+raised (SURVEY.md §8(b) "Errors").  A missing libmotif_hip.so (fresh checkout: binaries are not in git) is compiled
+in-tree with hipcc on first use (`motif_amd/csrc/build.py`, gfx950); `load(build=True)` forces the incremental build.
 """
 import ctypes
 import os
@@ -68,13 +69,15 @@ def load(build=False):
     global _lib
     if _lib is not None:
         return _lib
-    if build or not os.path.exists(SO_PATH):
-        if build:
+    if build or (not os.path.exists(SO_PATH) and not os.environ.get("MOTIF_HIP_LIB")):
+        try:
             from .csrc import build as _b
             _b.build()
+        except Exception as e:                # no hipcc / compile error: still no fallback, say why
+            raise RuntimeError("libmotif_hip.so is missing at %s and building it failed (%s: %s) -- needs hipcc "
+                               "(--offload-arch=gfx950); there is no fallback path" % (SO_PATH, type(e).__name__, e)) from e
     if not os.path.exists(SO_PATH):
-        raise RuntimeError("libmotif_hip.so not found at %s -- run `python -m motif_amd.csrc.build` "
-                           "(hipcc --offload-arch=gfx950); there is no fallback path" % SO_PATH)
+        raise RuntimeError("libmotif_hip.so not found at %s; there is no fallback path" % SO_PATH)
     lib = ctypes.CDLL(SO_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch with include/motif_hip.h

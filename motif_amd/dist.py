@@ -31,10 +31,17 @@ def shard_indices(n_items, rank=None, world_size=None):
     return list(range(rank, n_items, world_size))
 
 
-def frames_to_uint8(frames):
-    """[...,3,H,W] float in [0,1] -> uint8 (round-half-even like torchvision's save path is not needed
-    here: (x*255).round() as `demo.py:94-99` does before writing PNGs)."""
-    return (frames * 255.0).round().clamp_(0, 255).to(torch.uint8)
+def frames_to_uint8(frames, round_half_even=True, swap_rb=False):
+    """[...,3,H,W] fp32 device frames -> uint8 [...,H,W,3], the wire format of the gathers below (4x fewer bytes than
+    fp32), through the encode kernel `motif_frames_f32_to_u8` (one definition of the quantisation for the whole
+    build): clamp to [0,1], x255, round half to even = `tensor2img` (`/root/reference/utils/util.py:105-129`); with
+    round_half_even=False the truncating `astype(uint8)` of `/root/reference/demo.py:94-99`.  swap_rb=True gives cv2's
+    BGR order.  Device tensors only: there is no host route."""
+    from . import ops
+    lead = tuple(frames.shape[:-3])
+    c, h, w = frames.shape[-3:]
+    u8 = ops.frames_f32_to_u8(frames.reshape(-1, c, h, w), round_half_even=round_half_even, swap_rb=swap_rb)
+    return u8.view(lead + (h, w, 3))
 
 
 def gather_to_rank0(local, n_items, dst=0):
@@ -78,26 +85,31 @@ def allreduce_max(value):
     return value
 
 
-def gather_bands_to_rank0(local, n_rows, dst=0, align=1):
-    """local [..., rows_of_this_rank, W] -> on rank `dst` the concatenation [..., n_rows, W] in band order, else None."""
+def gather_bands_to_rank0(local, n_rows, dst=0, align=1, row_dim=-3):
+    """local [..., rows_of_this_rank, W, 3] (row axis = `row_dim`) -> on rank `dst` the concatenation over ranks in band
+    order ([..., n_rows, W, 3]), else None."""
     if not is_dist():
         return local
     rank, w = world()
     rows = [band_of(n_rows, r, w, align) for r in range(w)]
     mx = max(b - a for a, b in rows)
-    pad = torch.zeros(tuple(local.shape[:-2]) + (mx, local.shape[-1]), dtype=local.dtype, device=local.device)
-    pad[..., :local.shape[-2], :].copy_(local)
+    row_dim = row_dim % local.dim()
+    shape = list(local.shape)
+    shape[row_dim] = mx
+    pad = torch.zeros(shape, dtype=local.dtype, device=local.device)
+    pad.narrow(row_dim, 0, local.shape[row_dim]).copy_(local)
     bufs = [torch.empty_like(pad) for _ in range(w)] if rank == dst else None
     dist.gather(pad, bufs, dst=dst)
     if rank != dst:
         return None
-    return torch.cat([bufs[r][..., :rows[r][1] - rows[r][0], :] for r in range(w)], dim=-2)
+    return torch.cat([bufs[r].narrow(row_dim, 0, rows[r][1] - rows[r][0]) for r in range(w)], dim=row_dim)
 
 
-def render_clip_tiled(net, x, times, scale, iters=4, halo=64, chunk=3, max_retries=2):
+def render_clip_tiled(net, x, times, scale, iters=4, halo=64, chunk=3, max_retries=2, encode=frames_to_uint8):
     """One clip over all ranks: every rank runs the LR stage, then renders its HR row band for every timestamp chunk
     (the <= 3-timestamp chunking of VideoSR_base_model.py:189-193).  Returns on rank 0 the uint8 frames
-    [T, B, 3, HH, WW], elsewhere None.  The halo is doubled and the clip re-rendered if some |flow_y| + 1 exceeds it."""
+    [T, B, HH, WW, 3] (`encode`: fp32 [...,3,rows,WW] -> uint8 [...,rows,WW,3], the encode kernel), elsewhere None.
+    The halo is doubled and the clip re-rendered if some |flow_y| + 1 exceeds it."""
     rank, w = world()
     HH = int(scale[0][0]) if isinstance(scale, list) else round(x.shape[3] * scale)
     band = band_of(HH, rank, w, align=8)
@@ -109,10 +121,10 @@ def render_clip_tiled(net, x, times, scale, iters=4, halo=64, chunk=3, max_retri
             for l in range(0, len(times), chunk):
                 if band[1] > band[0]:
                     frames, _, _ = net(x, None, times[l:l + chunk], scale, use_GT=False, iter=iters)
-                    outs.append(frames_to_uint8(frames))
+                    outs.append(encode(frames))
                     worst = torch.maximum(worst, net.last_max_flow_y)
                 else:                                                           # more ranks than row units: nothing to render
-                    outs.append(torch.zeros(len(times[l:l + chunk]), x.shape[0], 3, 0, WW, dtype=torch.uint8, device=x.device))
+                    outs.append(torch.zeros(len(times[l:l + chunk]), x.shape[0], 0, WW, 3, dtype=torch.uint8, device=x.device))
         worst = float(allreduce_max(worst.clone()))
         if worst + 1.0 <= halo:
             break
@@ -120,4 +132,46 @@ def render_clip_tiled(net, x, times, scale, iters=4, halo=64, chunk=3, max_retri
             raise RuntimeError("tile mode: |flow_y| = %.1f px exceeds the halo of %d rows" % (worst, halo))
         halo *= 2
     net.band = None
-    return gather_bands_to_rank0(torch.cat(outs, 0), HH, align=8)
+    return gather_bands_to_rank0(torch.cat(outs, 0), HH, align=8, row_dim=-3)
+
+
+# ------------------------------------------------------------------------------------------ timestamps of one clip
+def render_clip_by_timestamps(net, x, times, scale, iters=4, chunk=3, share="replicate", src=0, encode=frames_to_uint8):
+    """One clip over all ranks, split over its TIMESTAMPS: only `flow_imnet`, the splat and
+    `synth_net` depend on t (Ours.py:727-858), so rank r renders timestamps r, r+W, ... in chunks of <= `chunk` from one
+    t-independent clip stage, and the uint8 frames are gathered to rank 0 in timestamp order ([T, B, HH, WW, 3]).
+
+    share = "replicate": every rank computes the t-independent stage itself (RAFT, reliability maps, encoder, flow
+                         encoder, imnet) -- no data-path collective at all, lowest latency: the stage costs the same
+                         wall time on every rank as on one.
+    share = "broadcast": rank `src` computes it once and broadcasts the cached tensors the t-dependent half reads
+                         (`LunaTokis.export_clip_cache`: three LR feature maps + imnet_out, 0.53 GB at c2) -- the other
+                         GPUs stay free until the broadcast; one collective over RCCL.
+    The t-dependent work per clip drops from T to ceil(T / W) timestamps per rank."""
+    rank, w = world()
+    HH = int(scale[0][0]) if isinstance(scale, list) else round(x.shape[3] * scale)
+    WW = int(scale[1][0]) if isinstance(scale, list) else round(x.shape[4] * scale)
+    if share not in ("replicate", "broadcast"):
+        raise ValueError("share must be 'replicate' or 'broadcast'")
+    with torch.no_grad():
+        if share == "broadcast" and w > 1:
+            shapes = net.clip_cache_shapes(x, HH, WW)
+            if rank == src:
+                tensors = net.export_clip_cache(x, HH, WW, iters)
+            else:
+                tensors = {k: torch.empty(shp, dtype=torch.float32, device=x.device) for k, shp in shapes.items()}
+            for k in sorted(shapes):
+                dist.broadcast(tensors[k], src=src)
+            if rank != src:
+                net.import_clip_cache(x, HH, WW, iters, tensors)
+        mine = list(range(rank, len(times), w))
+        outs = []
+        for l in range(0, len(mine), chunk):
+            tt = [times[i] for i in mine[l:l + chunk]]
+            frames, _, _ = net(x, None, tt, scale, use_GT=False, iter=iters)
+            outs.append(encode(frames))
+    if outs:
+        local = torch.cat(outs, 0)
+    else:
+        local = torch.zeros((0, x.shape[0], HH, WW, 3), dtype=torch.uint8, device=x.device)
+    return gather_to_rank0(local, len(times))

@@ -347,6 +347,10 @@ class LunaTokis(nn.Module):
         self.last_max_flow_y = None
         self._side_stream = None
         self._cache_key, self._cache = None, None
+        # anything that rewrites parameters wholesale invalidates the cached t-independent stage (in-place edits of a
+        # single parameter are caught through its version counter where the parameter is consumed)
+        self._weights_epoch = 0
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._bump_weights_epoch())
 
     # ----------------------------------------------------------------------------- t-independent stage
     def _flow_encoder(self, x):
@@ -410,6 +414,51 @@ class LunaTokis(nn.Module):
     def clear_cache(self):
         self._cache_key, self._cache = None, None
 
+    def _bump_weights_epoch(self):
+        self._weights_epoch += 1
+        self.clear_cache()
+
+    def _apply(self, fn, *a, **k):                     # .to() / .cuda() / .float(): parameters are replaced
+        self._bump_weights_epoch()
+        return super()._apply(fn, *a, **k)
+
+    def _clip_key(self, x, HH, WW, iters):
+        """Identity of the t-independent stage: the clip tensor (address + version; the tensor is kept alive by the cache,
+        so the address cannot be recycled), the output size, the RAFT iteration count, band / untiled mode, the
+        arithmetic engines and the weights epoch."""
+        return (x.data_ptr(), x._version, tuple(x.shape), HH, WW, iters, self.band is None,
+                ops.get_conv_mma(), ops.get_siren_mma(), self._weights_epoch)
+
+    # ---- t-independent stage as a transferable object (motif_amd.dist.render_clip_by_timestamps, share="broadcast")
+    CLIP_CACHE_TENSORS = ("flow_l0", "synth_l0", "feat01", "imnet_out")
+
+    def clip_cache_shapes(self, x, HH, WW):
+        B, H, W = x.shape[0], x.shape[3], x.shape[4]
+        return {"flow_l0": (2 * B, 64, H, W), "synth_l0": (B, 64, H, W), "feat01": (2 * B, 64, H, W), "imnet_out": (2 * B, 64, HH, WW)}
+
+    def export_clip_cache(self, x, HH, WW, iters):
+        """Run (or reuse) the t-independent stage for clip `x` and return the tensors the t-dependent half reads."""
+        if self.band is not None:
+            raise RuntimeError("the clip cache is exported in untiled mode")
+        key = self._clip_key(x, HH, WW, iters)
+        if key != self._cache_key:
+            self._cache, self._cache_key = self._clip_stage(x.float(), HH, WW, iters), key
+            self._cache["x"] = x
+        return {k: self._cache[k] for k in self.CLIP_CACHE_TENSORS}
+
+    def import_clip_cache(self, x, HH, WW, iters, tensors):
+        """Install a t-independent stage computed elsewhere (another rank) for clip `x`: later forward calls with the same
+        clip / size / iters render timestamps from it without running RAFT, the encoder or imnet."""
+        B, H, W = x.shape[0], x.shape[3], x.shape[4]
+        shapes = self.clip_cache_shapes(x, HH, WW)
+        for k in self.CLIP_CACHE_TENSORS:
+            if tuple(tensors[k].shape) != shapes[k]:
+                raise ValueError("clip cache tensor %s has shape %s, expected %s" % (k, tuple(tensors[k].shape), shapes[k]))
+        c = {k: tensors[k] for k in self.CLIP_CACHE_TENSORS}
+        c["tables"] = gather_tables(H, W, HH, WW, x.device)
+        c["x"] = x
+        self._cache, self._cache_key = c, self._clip_key(x, HH, WW, iters)
+
     def _forward_band(self, c, times, B, N, H, HH, WW, flow_blob, synth_blob, pre, stages):
         """HR rows [r0, r1) of the output.  The HR kernels run on the row range [e0, e1) = the band extended by
         `band_halo` rows (clipped to the image) as if it were an image of e1-e0 rows: the gather / rel_coord tables are
@@ -442,8 +491,7 @@ class LunaTokis(nn.Module):
                 stages=None):
         if self.training or use_GT:
             raise NotImplementedError("this is the inference path (VideoSR_base_model.py:189: use_GT=False, eval mode)")
-        if not x.is_cuda:
-            raise RuntimeError("LunaTokis runs on the MI355X HIP kernels only; move inputs to 'cuda'")
+        ops.require_device(x, "LunaTokis runs on the MI355X HIP kernels only; move inputs to 'cuda'")
         x = x.float()
         B, _, _, H, W = x.shape
         target_t = torch.stack(list(target_t), 1).squeeze(-1).to(x.device).float().reshape(B, -1)
@@ -452,8 +500,7 @@ class LunaTokis(nn.Module):
             HH, WW = int(scale[0][0]), int(scale[1][0])
         else:
             HH, WW = round(H * scale), round(W * scale)
-        # the cached clip tensor is kept alive, so its address cannot be recycled for another clip
-        key = (x.data_ptr(), x._version, tuple(x.shape), HH, WW, iter, self.band is None)
+        key = self._clip_key(x, HH, WW, iter)
         if key != self._cache_key:
             self._cache, self._cache_key = self._clip_stage(x, HH, WW, iter), key
             self._cache["x"] = x

@@ -27,6 +27,12 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def require_device(t, what="motif_amd ops need CUDA(ROCm) tensors"):
+    """The product path has no host route: refuse host tensors up front with a clear message."""
+    if not t.is_cuda:
+        raise RuntimeError(what)
+
+
 def _p8(t):
     if not t.is_cuda or t.dtype != torch.uint8:
         raise RuntimeError("expected a CUDA(ROCm) uint8 tensor, got %s %s" % (t.device, t.dtype))

@@ -164,7 +164,7 @@ r, w = md.world()
 n = 5
 idx = md.shard_indices(n)
 local = torch.stack([torch.full((2, 3), float(i)) for i in idx]) if idx else torch.zeros(0, 2, 3)
-u8 = md.frames_to_uint8(local / 255.0)
+u8 = local.to(torch.uint8)                      # md.frames_to_uint8 is the device encode kernel; covered in the GPU suite
 out = md.gather_to_rank0(u8, n)
 if r == 0:
     assert out.shape == (n, 2, 3) and out.dtype == torch.uint8
@@ -202,16 +202,18 @@ class FakeNet:
         self.last_max_flow_y = torch.tensor(20.0 if r == 1 else 3.0)          # rank 1 sees a 20 px motion
         return ((rows %% 251) / 255.0 + 0 * t).expand(len(times), 1, 3, r1 - r0, WW), None, 0
 
+encode = lambda f: (f * 255.0).round().to(torch.uint8).permute(0, 1, 3, 4, 2).contiguous()     # stand-in for the device encode kernel
+
 net = FakeNet()
 x = torch.zeros(1, 4, 3, 26, 4)
 times = [torch.full((1, 1), i / 4) for i in range(5)]
-out = md.render_clip_tiled(net, x, times, [[HH], [WW]], halo=16)
+out = md.render_clip_tiled(net, x, times, [[HH], [WW]], halo=16, encode=encode)
 assert net.band is None
 assert [c[1] for c in net.calls] == [16, 16, 32, 32], net.calls           # 2 chunks per attempt, halo doubled once
 assert net.calls[0][0] == md.band_of(HH, r, w, 8)
 if r == 0:
-    assert out.shape == (5, 1, 3, HH, WW) and out.dtype == torch.uint8
-    assert [int(v) for v in out[0, 0, 0, :, 0]] == [i %% 251 for i in range(HH)]
+    assert out.shape == (5, 1, HH, WW, 3) and out.dtype == torch.uint8
+    assert [int(v) for v in out[0, 0, :, 0, 0]] == [i %% 251 for i in range(HH)]
     print("TILED_OK", md.band_of(HH, 0, w, 8), md.band_of(HH, 1, w, 8))
 else:
     assert out is None
@@ -221,6 +223,86 @@ dist.destroy_process_group()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29537", str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "TILED_OK (0, 56) (56, 104)" in r.stdout, r.stdout + r.stderr
+
+
+def test_timestamp_split_over_gloo_world2(tmp_path):
+    """motif_amd.dist.render_clip_by_timestamps (SURVEY.md 8(e) row 2: one clip, timestamps r::W per rank) with the REAL
+    LunaTokis host logic -- clip-cache export / broadcast / import, cache keying, per-rank timestamp chunks, timestamp-order
+    gather -- and the device kernels stubbed at the motif_amd.ops boundary.  Both sharing modes."""
+    script = tmp_path / "ts.py"
+    script.write_text('''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from motif_amd import dist as md, ops
+from motif_amd.models.modules import Ours
+from motif_amd.models.modules.SIREN import Siren
+dist.init_process_group("gloo")
+r, w = md.world()
+B, H, W, s, T = 1, 4, 6, 4, 5
+HH, WW = H * s, W * s
+calls = {"clip_stage": 0, "flow": [], "synth": []}
+
+# ---- kernel boundary stubs (host stand-ins with checkable values)
+ops.require_device = lambda t, what="": None
+Siren.packed = Siren.packed_split = lambda self, *a: None
+def siren_flow(blob, flow_l0, iy, ix, rel_y, rel_x, times, N, HH, WW, pre=False):
+    calls["flow"].append([float(v) for v in times.reshape(-1)])
+    return times.reshape(1, -1, 1, 1, 1).expand(2, N, 3, HH, WW).reshape(2 * N, 3, HH, WW) * 0.01 + flow_l0.mean()
+def splat_motif(imnet_out, pred, feat_lr, iy, ix, alpha, flow_scale, B, N, HH, WW, acc=None, row0=0):
+    return pred[:N, :1].repeat(1, 133, 1, 1) * 0 + imnet_out.mean() + feat_lr.mean()
+def siren_synth(blob, acc, synth_l0, iy, ix, times, B, N, HH, WW, pre=False):
+    calls["synth"].append(N)
+    t = times.reshape(B, N).permute(1, 0).reshape(N, B, 1, 1, 1)
+    return (t * 0.4 + acc.mean() + synth_l0.mean()).expand(N, B, 3, HH, WW).contiguous()
+ops.siren_flow, ops.splat_motif, ops.siren_synth = siren_flow, splat_motif, siren_synth
+
+net = Ours.LunaTokis().eval()
+def clip_stage(x, HH, WW, iters):                       # rank-dependent on purpose: a missing broadcast would show
+    calls["clip_stage"] += 1
+    shp = net.clip_cache_shapes(x, HH, WW)
+    base = 0.1 if os.environ["SHARE"] == "replicate" else 0.1 * (r + 1)
+    c = {k: torch.full(v, base * (i + 1)) for i, (k, v) in enumerate(sorted(shp.items()))}
+    c["tables"] = Ours.gather_tables(x.shape[3], x.shape[4], HH, WW, x.device)
+    return c
+net._clip_stage = clip_stage
+x = torch.zeros(B, 4, 3, H, W)
+times = [torch.full((B, 1), i / (T - 1)) for i in range(T)]
+encode = lambda f: (f * 100.0).round().to(torch.uint8).permute(0, 1, 3, 4, 2).contiguous()
+out = md.render_clip_by_timestamps(net, x, times, [[HH], [WW]], share=os.environ["SHARE"], encode=encode)
+mine = [i / (T - 1) for i in range(r, T, w)]
+assert [t for c in calls["flow"] for t in c] == mine, (calls, mine)          # this rank rendered exactly its timestamps
+assert calls["synth"] == ([3] if r == 0 else [2])                             # in chunks of <= 3
+assert calls["clip_stage"] == (1 if (os.environ["SHARE"] == "replicate" or r == 0) else 0)
+if r == 0:
+    assert out.shape == (T, B, HH, WW, 3) and out.dtype == torch.uint8
+    const = 0.3 + 0.1 + 0.4                             # imnet_out + feat01 (acc) + synth_l0: rank 0's values on every rank
+    want = [round((i / (T - 1) * 0.4 + const) * 100.0) for i in range(T)]
+    assert [int(out[i, 0, 0, 0, 0]) for i in range(T)] == want, ([int(out[i, 0, 0, 0, 0]) for i in range(T)], want)
+    print("TS_OK", os.environ["SHARE"])
+else:
+    assert out is None
+dist.destroy_process_group()
+''' % ROOT)
+    for share, port in (("replicate", "29541"), ("broadcast", "29543")):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, SHARE=share)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                            "--master-port", port, str(script)], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0 and "TS_OK " + share in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_launcher_spawns_ranks_gloo(tmp_path):
+    """`python bench.py --gpus 2` outside a launcher starts 2 ranks itself (child torch.distributed.run job, parent never
+    touches the GPU) and rank 0 prints one JSON line with n_gpus == 2; --launcher-selftest keeps it to the plumbing
+    (gloo barrier + uint8 gather through motif_amd.dist), no GPU work."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--launcher-selftest"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["backend"] == "gloo"
 
 
 def test_arithmetic_mode_option_plumbing():

@@ -4,6 +4,7 @@ Bit-exact where the domain is integer/index (splat count & max, corner indices),
 per test elsewhere.  All calls go through the C ABI (motif_amd.ops -> libmotif_hip.so).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -31,6 +32,32 @@ def close(a, b, atol, rtol=0.0, what=""):
     bad = err > tol
     assert not bad.any(), "%s: max|diff|=%.3e (tol %.1e) at %d/%d elements, ref max %.3e" % (
         what, err.max().item(), atol, int(bad.sum()), bad.numel(), b.abs().max().item())
+
+
+@pytest.fixture(params=["bf16x3", "fp32"])
+def engine(request):
+    """Arithmetic engine of the dense contractions for one test: the 3-way bf16 split on the bf16 matrix cores
+    (conv_split_kernel / dcn_fused_kernel<8,true>, the bench default) and the fp32 MFMA (conv_igemm_kernel /
+    dcn_fused_kernel<8,false>).  The previous mode is restored afterwards -- no test leaks its mode into the next."""
+    from motif_amd import ops
+    before = ops.get_mma()
+    ops.set_mma(request.param)
+    try:
+        yield request.param
+    finally:
+        ops.set_mma(before)
+
+
+@pytest.fixture
+def keep_mma():
+    """For tests that switch engines themselves: put back whatever was selected before."""
+    from motif_amd import ops
+    conv, siren = ops.get_conv_mma(), ops.get_siren_mma()
+    try:
+        yield
+    finally:
+        ops.set_conv_mma(conv)
+        ops.set_siren_mma(siren)
 
 
 # ------------------------------------------------------------------------------------------- conv engine
@@ -61,7 +88,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c))
-def test_conv2d_matches_torch_cpu(case):
+def test_conv2d_matches_torch_cpu(case, engine):
     from motif_amd.models.modules.layers import Conv2d
     cin, cout, k, stride, pad, dil, groups, pm, H, W, N = case
     m = Conv2d(cin, cout, k, stride, pad, dil, groups, True, pm)
@@ -76,7 +103,7 @@ def test_conv2d_matches_torch_cpu(case):
     close(out, ref, 2e-5, 2e-5, "conv")
 
 
-def test_conv2d_fused_epilogues_and_concat():
+def test_conv2d_fused_epilogues_and_concat(engine):
     from motif_amd import ops
     from motif_amd.models.modules.layers import Conv2d
     m = Conv2d(96 + 40, 80, 3, 1, 1)
@@ -115,7 +142,7 @@ SPLIT_CASES = [  # cin, cout, groups, pad_mode, H, W, N, two-source split (0 = s
 
 
 @pytest.mark.parametrize("case", SPLIT_CASES)
-def test_conv_split_engine_is_fp32_equivalent(case):
+def test_conv_split_engine_is_fp32_equivalent(case, keep_mma):
     """mma=6 (3-way bf16 split, 6 products on the bf16 matrix cores) against an fp64 convolution: its error must
     not exceed the fp32-MFMA engine's; mma=3 / mma=1 keep 16 / 8 mantissa bits."""
     from motif_amd import ops
@@ -133,13 +160,10 @@ def test_conv_split_engine_is_fp32_equivalent(case):
     xd, rd = x.to(dev()), res.to(dev())
     args = (xd[:, :c0].contiguous(), xd[:, c0:].contiguous()) if c0 else (xd, None)
     err = {}
-    try:
-        for mode in (ops.MMA_FP32, ops.MMA_BF16X3, ops.MMA_BF16X2, ops.MMA_BF16):
-            ops.set_conv_mma(mode)
-            out = m(*args, act=ops.ACT_LRELU, res=rd, res_mode=1)
-            err[mode] = float((out.double().cpu() - ref).abs().max())
-    finally:
-        ops.set_conv_mma(ops.MMA_FP32)
+    for mode in (ops.MMA_FP32, ops.MMA_BF16X3, ops.MMA_BF16X2, ops.MMA_BF16):
+        ops.set_conv_mma(mode)
+        out = m(*args, act=ops.ACT_LRELU, res=rd, res_mode=1)
+        err[mode] = float((out.detach().double().cpu() - ref).abs().max())
     scale = float(ref.abs().max())
     assert err[ops.MMA_FP32] < 2e-6 * scale, err
     assert err[ops.MMA_BF16X3] <= 1.25 * err[ops.MMA_FP32] + 1e-7 * scale, err
@@ -147,7 +171,7 @@ def test_conv_split_engine_is_fp32_equivalent(case):
     assert 1e-4 * scale < err[ops.MMA_BF16] < 3e-2 * scale, err      # really ran in bf16
 
 
-def test_conv_split_multi_problem_and_views():
+def test_conv_split_multi_problem_and_views(keep_mma):
     from motif_amd import ops
     from motif_amd.models.modules.layers import Conv2d
     ms = [Conv2d(64, 64, 3, 1, 1) for _ in range(3)]
@@ -158,19 +182,16 @@ def test_conv_split_multi_problem_and_views():
             m.bias.copy_(rnd(64, seed=30 + i, scale=0.1))
     refs = [F.relu(F.conv2d(x, m.weight, m.bias, 1, 1)) for m, x in zip(ms, xs)]
     ms = [m.to(dev()) for m in ms]
-    try:
-        ops.set_conv_mma(ops.MMA_BF16X3)
-        out = ops.conv2d_multi([m.plan() for m in ms], [x.to(dev()) for x in xs], act=ops.ACT_RELU)
-        for i in range(3):
-            close(out[i], refs[i], 2e-5, 2e-5, "split multi %d" % i)
-        big = torch.zeros(2, 2, 64, 21, 50, device=dev())
-        big[:, 1] = xs[0].to(dev())
-        buf = torch.zeros(2, 80, 21, 50, device=dev())
-        ms[0](big[:, 1], out=buf[:, 8:72], act=ops.ACT_RELU)
-        close(buf[:, 8:72], refs[0], 2e-5, 2e-5, "split strided views")
-        assert float(buf[:, :8].abs().max()) == 0 and float(buf[:, 72:].abs().max()) == 0
-    finally:
-        ops.set_conv_mma(ops.MMA_FP32)
+    ops.set_conv_mma(ops.MMA_BF16X3)
+    out = ops.conv2d_multi([m.plan() for m in ms], [x.to(dev()) for x in xs], act=ops.ACT_RELU)
+    for i in range(3):
+        close(out[i], refs[i], 2e-5, 2e-5, "split multi %d" % i)
+    big = torch.zeros(2, 2, 64, 21, 50, device=dev())
+    big[:, 1] = xs[0].to(dev())
+    buf = torch.zeros(2, 80, 21, 50, device=dev())
+    ms[0](big[:, 1], out=buf[:, 8:72], act=ops.ACT_RELU)
+    close(buf[:, 8:72], refs[0], 2e-5, 2e-5, "split strided views")
+    assert float(buf[:, :8].abs().max()) == 0 and float(buf[:, 72:].abs().max()) == 0
 
 
 
@@ -204,7 +225,7 @@ def test_dcn_zero_offset_identity_known_answer():
     assert float((x - 2 * out.cpu()).abs().max()) < 1e-10
 
 
-def test_dcn_sep_module_fused_offset_mask():
+def test_dcn_sep_module_fused_offset_mask(engine):
     from oracle.motif_ref import DcnSep
     from motif_amd.models.modules.DCNv2.dcn_v2 import DCN_sep
     ref = DcnSep(64, 8)
@@ -551,11 +572,14 @@ def test_splat_motif_keeps_dynamic_range_of_low_reliability_sources():
     close(out[hit_only_tiny.expand_as(out)], out_ref[hit_only_tiny.expand_as(out)], 3e-5, 3e-5, "normalised output, unreliable-only cells")
 
 
-def test_dcn_fused_multi_vs_kernel_text():
+def test_dcn_fused_multi_vs_kernel_text(engine):
     """Fused DCN (deformable im2col in LDS + MFMA, multi-problem) == the kernel-text restatement, including
-    offsets that leave the image, the (-1, 0) border band, and odd image sizes."""
+    offsets that leave the image, the (-1, 0) border band, and odd image sizes.  engine = bf16x3 runs
+    dcn_fused_kernel<8,true> (the bench default: GEMM on the bf16 matrix cores), fp32 runs dcn_fused_kernel<8,false>."""
     from oracle import native
     from motif_amd import ops
+    assert ops.get_conv_mma() == (ops.MMA_BF16X3 if engine == "bf16x3" else ops.MMA_FP32)
+    assert not os.environ.get("MOTIF_DCN_UNFUSED") and not os.environ.get("MOTIF_DCN_FP32")
     B, C, H, W, dg, P = 2, 64, 21, 45, 8, 3
     outs_ref, plans, xs, oms = [], [], [], []
     for pi in range(P):

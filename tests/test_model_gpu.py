@@ -287,3 +287,144 @@ def test_full_size_run_to_run_bit_reproducible():
         assert torch.equal(outs[k][0], outs[0][0]), "encoder output differs between runs"
         assert torch.equal(outs[k][1], outs[0][1]), "RAFT flow differs between runs"
         assert float((outs[k][2] - outs[0][2]).abs().max()) <= 1e-6     # far-source fallback uses float atomics
+
+
+# ------------------------------------------------------------------------------------------ full-size parity (driver-run)
+class _Keep(dict):
+    """`stages` dict for the oracle that keeps only the listed stage tensors (c2-size stages are ~1 GB each)."""
+
+    def __init__(self, names):
+        super().__init__()
+        self.names = set(names)
+
+    def __setitem__(self, k, v):
+        if k in self.names:
+            super().__setitem__(k, v)
+
+
+_ORACLE_C2 = {}
+
+
+def _oracle_c2():
+    """BASELINE config 2 at FULL size on the host: the CPU oracle, one timestamp (t = 0.5) of the seeded synthetic clip.
+    ~40 s on the GPU box's host cores; computed once per test session and shared by both engines."""
+    if not _ORACLE_C2:
+        from oracle.motif_ref import MotifRef
+        from motif_amd.data.synthetic import synthetic_sample
+        from motif_amd.utils.synth_weights import fill_state_dict
+        s = synthetic_sample(180, 320, 4, 7)
+        st = _Keep(["flow_lr", "fwarp_count", "encoder"])
+        with torch.no_grad():
+            ref, rflow, _ = fill_state_dict(MotifRef().eval())(s["LQs"], None, s["time"][3:4], s["scale"], use_GT=False, iter=4, stages=st)
+        _ORACLE_C2.update(sample=s, ref=ref, rflow=rflow, stages=st)
+    return _ORACLE_C2
+
+
+def test_c2_full_size_parity_vs_oracle(mma_mode):
+    """BASELINE config 2 (LR 180x320 -> 720x1280) at full size, timestamp t = 0.5, HIP path vs the CPU oracle (the
+    restatement pinned bit-exact to the reference on the goldens).  Bars: PSNR(build, oracle) >= 60 dB, returned flow
+    L-inf <= 2e-3 (LR-pixel units), LR RAFT flow L-inf <= 2e-3, encoder features within 2e-3, the integer hit-count plane
+    equal except where a source crosses a pixel boundary (< 2 % of cells), Y-PSNR vs the seeded GT within 0.05 dB."""
+    from motif_amd.utils import util
+    o = _oracle_c2()
+    s = o["sample"]
+    net = build_net()
+    st = {}
+    with torch.no_grad():
+        out, flow, _ = net(s["LQs"].cuda(), None, [t.cuda() for t in s["time"][3:4]], s["scale"], use_GT=False, iter=4, stages=st)
+    out, flow = out.cpu(), flow.cpu()
+    assert out.shape == o["ref"].shape == (1, 1, 3, 720, 1280)
+    p = psnr(out, o["ref"])
+    linf = float((out - o["ref"]).abs().max())
+    fl = float((flow - o["rflow"]).abs().max())
+    print("c2 full size [%s]: PSNR(build, oracle) = %.1f dB, Linf = %.2e, flow Linf = %.2e" % (mma_mode, p, linf, fl))
+    assert p >= 60.0 and fl <= 2e-3, (p, fl)
+    assert float((st["flow"].cpu() - o["stages"]["flow_lr"]).abs().max()) <= 2e-3
+    enc = (st["feat"].cpu() - o["stages"]["encoder"]).abs()
+    assert float(enc.max()) <= 2e-3 + 1e-3 * float(o["stages"]["encoder"].abs().max()), float(enc.max())
+    cnt_ref = o["stages"]["fwarp_count"].reshape(2, 1, 1, 720, 1280).sum(0)
+    mism = float((st["acc"][:, 132:133].cpu() != cnt_ref).float().mean())
+    assert mism < 0.02, "hit-count plane differs at %.2f%% of cells" % (100 * mism)
+    gt = s["GT"][0, 4:5]
+    assert np.abs(util.y_psnr_per_frame(gt, out[:, 0]) - util.y_psnr_per_frame(gt, o["ref"][:, 0])).max() < 0.05
+
+
+def test_c5_row_bands_match_untiled_at_full_size(mma_mode):
+    """BASELINE config 5 at FULL size (one 540x960 LR clip -> 2160x3840, x4 spatial, x4 temporal = 5 timestamps): the
+    8-band tile mode of the 8-GPU job (`LunaTokis.band`, bands of motif_amd.dist.band_of, halo 64 rows), rendered band
+    after band in this one process, is bit-identical to the untiled render -- frames and returned flow."""
+    from motif_amd import dist as md
+    from motif_amd.data.synthetic import synthetic_sample
+    if mma_mode != "bf16x3":
+        pytest.skip("one engine is enough at this size (the band mechanism is engine independent)")
+    h, w, s, T, bands, halo = 540, 960, 4, 5, 8, 64
+    HH, WW = h * s, w * s
+    net = build_net()
+    smp = synthetic_sample(h, w, s, T)
+    x = smp["LQs"].cuda()
+    times = [t.cuda() for t in smp["time"]]
+
+    def render():
+        outs, flows = [], []
+        with torch.no_grad():
+            for l in range(0, T, 3):
+                o, f, _ = net(x, None, times[l:l + 3], smp["scale"], use_GT=False, iter=4)
+                outs.append(o)
+                flows.append(f)
+        return torch.cat(outs, 0), flows
+
+    full, full_flows = render()
+    assert full.shape == (T, 1, 3, HH, WW) and torch.isfinite(full).all()
+    worst = 0.0
+    try:
+        for r in range(bands):
+            net.band, net.band_halo = md.band_of(HH, r, bands, 8), halo
+            r0, r1 = net.band
+            part, part_flows = render()
+            worst = max(worst, float(net.last_max_flow_y))
+            assert torch.equal(part, full[..., r0:r1, :]), "band %d differs from the untiled render by %.2e" % (
+                r, float((part - full[..., r0:r1, :]).abs().max()))
+            for pf, ff in zip(part_flows, full_flows):
+                assert float((pf - ff[..., r0:r1, :]).abs().max()) <= 1e-7          # untiled returns pred*s/s
+    finally:
+        net.band = None
+        net.clear_cache()
+    assert worst + 1 <= halo, "synthetic clip moves %.1f px: halo too small for an exact comparison" % worst
+
+
+def test_c3_crop_bf16_path_vs_oracle(mma_mode):
+    """BASELINE config 3's arithmetic ("bf16 MFMA path": plain-bf16 convolutions, `mma: bf16`) against the CPU oracle on a
+    crop of the Vimeo-7 septuplet shape the oracle finishes in seconds: 7 LR frames 64x112, x4 spatial, x8 temporal = 9
+    timestamps.  Tolerance for bf16: PSNR(build, oracle) >= 55 dB and Y-PSNR vs the seeded GT within 0.05 dB; the
+    fp32-equivalent engines must reach >= 60 dB on the same clip."""
+    if mma_mode != "bf16x3":
+        pytest.skip("runs all arithmetic modes itself")
+    from oracle.motif_ref import MotifRef
+    from motif_amd import ops
+    from motif_amd.data.synthetic import synthetic_sample
+    from motif_amd.models import create_model
+    from motif_amd.option import default_opt
+    from motif_amd.utils.synth_weights import fill_state_dict
+    from motif_amd.utils import util
+    smp = synthetic_sample(64, 112, 4, 9, n_frames=7)
+    oracle = fill_state_dict(MotifRef().eval())
+    with torch.no_grad():
+        ref = torch.cat([oracle(smp["LQs"], None, smp["time"][l:l + 3], smp["scale"], use_GT=False, iter=4)[0] for l in range(0, 9, 3)], 0)
+    model = create_model(default_opt(scale=4, gpu_ids=[0]))
+    fill_state_dict(model.netG)
+    data = {"LQs": smp["LQs"].cuda(), "GT": smp["GT"][:, :1].cuda(), "time": [t.cuda() for t in smp["time"]], "scale": smp["scale"]}
+    gt = smp["GT"][0, 1:10]
+    yref = util.y_psnr_per_frame(gt, ref[:, 0])
+    res = {}
+    try:
+        for mode in ("bf16", "bf16x3", "fp32"):
+            ops.set_mma(mode)
+            model.feed_data(data)
+            model.test()
+            out = model.fake_H.float().cpu()
+            res[mode] = (psnr(out, ref), float(np.abs(util.y_psnr_per_frame(gt, out[:, 0]) - yref).max()))
+    finally:
+        ops.set_mma("bf16x3")
+    print("c3 crop vs oracle: " + ", ".join("%s %.1f dB (dY %.4f)" % (k, v[0], v[1]) for k, v in res.items()))
+    assert res["bf16"][0] >= 55.0 and res["bf16x3"][0] >= 60.0 and res["fp32"][0] >= 60.0, res
+    assert max(v[1] for v in res.values()) < 0.05, res
