@@ -62,6 +62,12 @@ int motif_splat_fwd(const float* src, const float* flow, const float* z,
 int motif_splat_motif_fwd(const float* imnet_out, const float* pred, const float* feat_lr,
                           const int32_t* iy, const int32_t* ix, const float* alpha, float flow_scale,
                           float* acc, int B, int N, int H, int W, int HH, int WW, int row0, void* stream);
+/* The same with `accumulate`: 0 = acc is written (as above); 1 = this call's two directions are added to an accumulator an
+ * earlier call wrote (sums and count added, max plane max-ed).  The 4-source generator sums four directions
+ * (Ours_44.py:713-719): two calls, the second with accumulate = 1. */
+int motif_splat_motif_acc_fwd(const float* imnet_out, const float* pred, const float* feat_lr,
+                              const int32_t* iy, const int32_t* ix, const float* alpha, float flow_scale,
+                              float* acc, int B, int N, int H, int W, int HH, int WW, int row0, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * B1-B4  space-time local implicit MLPs (SIREN, omega0=30) with the nearest gather fused in.
@@ -205,6 +211,13 @@ int motif_pwc_backward_warp(const float* img, const float* flow, const float* gx
  * flow [4B,2,H,W] (pairs 00,01,10,11; 00 and 11 already zeroed) -> psies [4B,3,H,W], flow_feat [2B,14,H,W]. */
 int motif_reliability_fwd(const float* fr0, const float* fr1, long fr_bs, const float* flow, const float* g_filter,
                           float* psies, float* flow_feat, int B, int H, int W, void* stream);
+/* the same maps for the 4-frame generators (Ours_4.py:514-592: 8 flows from frames 1,2; Ours_44.py:519-593: 16 flows, all
+ * ordered pairs), table driven: `table` is a HOST int32 [J][4] = (source frame, target frame, index of the flow in `flow`, index of
+ * its reverse flow), `durations` a HOST float [J][2] (ref_start_durations already divided); frames [B][n][3,H,W] with the given
+ * element strides; flow [F*B,2,H,W]; S flows per source frame -> psies [J*B,3,H,W], flow_feat [(J/S)*B, S*7, H, W].  J <= 16. */
+int motif_reliability_pairs_fwd(const float* frames, long frame_stride, long batch_stride, const float* flow,
+                                const float* g_filter, const int32_t* table_host, const float* durations_host, int J, int S,
+                                float* psies, float* flow_feat, int B, int H, int W, void* stream);
 /* InstanceNorm2d (eps 1e-5, no affine) + optional relu, optional residual: out = relu?(res + relu?(norm(x)))
  * mode 0: norm; 1: relu(norm); 2: relu(res + relu(norm))   (models/core/extractor.py:60-116,246-248) */
 int motif_instance_norm(const float* x, const float* res, float* out, int NC, int HW, int mode, void* stream);

@@ -192,6 +192,70 @@ extern "C" int motif_reliability_fwd(const float* fr0, const float* fr1, long fr
     return MOTIF_OK;
 }
 
+// Table-driven form for the 4-frame generators (Ours_4.py:514-592, Ours_44.py:519-593): J flows per batch item, flow j
+// goes from frame tab[j][0] to frame tab[j][1], is tab[j][2] in `flow` and its reverse is tab[j][3]; S flows share one
+// source frame ("direction"): flow_feat[(j/S)*B + b][(j%S)*7 + c].
+struct RelTab { int src[16], dst[16], fwd[16], rev[16]; float d0[16], d1[16]; };
+
+__global__ void reliability_pairs_kernel(const float* __restrict__ frames, long frame_stride, long batch_stride,
+                                         const float* __restrict__ flow, const float* __restrict__ gf, RelTab tab,
+                                         float* __restrict__ psies, float* __restrict__ flow_feat, int S, int B, int H, int W) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int jb = blockIdx.z, j = jb / B, b = jb % B;
+    if (x >= W) return;
+    const long HW = (long)H * W, p = (long)y * W + x;
+    const float* fl = flow + (long)(tab.fwd[j] * B + b) * 2 * HW;
+    const float u = fl[p], v = fl[HW + p];
+    float ix, iy;
+    backwarp_coord(x, y, u, v, H, W, &ix, &iy);
+    const float* src = frames + (long)b * batch_stride + (long)tab.src[j] * frame_stride;
+    const float* dst = frames + (long)b * batch_stride + (long)tab.dst[j] * frame_stride;
+    float ph = 0.f;
+    for (int c = 0; c < 3; ++c) ph += fabsf(src[c * HW + p] - bilinear_zero(dst + c * HW, H, W, ix, iy));
+    ph = ph / 3.0f;
+    const float* fr = flow + (long)(tab.rev[j] * B + b) * 2 * HW;
+    float pf = fabsf(u - (-bilinear_zero(fr, H, W, ix, iy))) + fabsf(v - (-bilinear_zero(fr + HW, H, W, ix, iy)));
+    pf = (pf / 2.0f) / 10.0f;
+    float pv = 0.f;
+    for (int c = 0; c < 2; ++c) {
+        float m2 = 0.f, m1 = 0.f;
+        for (int dy = 0; dy < 3; ++dy)
+            for (int dx = 0; dx < 3; ++dx) {
+                const float f = fl[c * HW + (long)reflect1(y + dy - 1, H) * W + reflect1(x + dx - 1, W)];
+                const float g = gf[dy * 3 + dx];
+                m2 += (f * f) * g;
+                m1 += f * g;
+            }
+        float var = m2 - m1 * m1;
+        var = var < 1e-9f ? 1e-9f : var;
+        pv += sqrtf(var);
+    }
+    pv = pv / 2.0f;
+    float* ps = psies + (long)jb * 3 * HW + p;
+    ps[0] = ph; ps[HW] = pf; ps[2 * HW] = pv;
+    const int d = j / S, i = j % S;
+    float* ff = flow_feat + ((long)(d * B + b) * (S * 7) + i * 7) * HW + p;
+    ff[0] = u / 20.0f; ff[HW] = v / 20.0f;
+    ff[2 * HW] = ph; ff[3 * HW] = pf; ff[4 * HW] = pv;
+    ff[5 * HW] = tab.d0[j]; ff[6 * HW] = tab.d1[j];
+}
+
+extern "C" int motif_reliability_pairs_fwd(const float* frames, long frame_stride, long batch_stride, const float* flow,
+                                           const float* g_filter, const int32_t* table, const float* durations, int J, int S,
+                                           float* psies, float* flow_feat, int B, int H, int W, void* stream) {
+    if (!frames || !flow || !g_filter || !table || !durations || !psies || !flow_feat || B < 1) return MOTIF_EINVAL;
+    if (J < 1 || J > 16 || S < 1 || J % S) return MOTIF_EINVAL;
+    RelTab tab;
+    for (int j = 0; j < J; ++j) {           // host tables (a few dozen ints), passed by value
+        tab.src[j] = table[4 * j]; tab.dst[j] = table[4 * j + 1]; tab.fwd[j] = table[4 * j + 2]; tab.rev[j] = table[4 * j + 3];
+        tab.d0[j] = durations[2 * j]; tab.d1[j] = durations[2 * j + 1];
+    }
+    dim3 grid(cdiv(W, 128), H, J * B);
+    reliability_pairs_kernel<<<grid, 128, 0, (hipStream_t)stream>>>(frames, frame_stride, batch_stride, flow, g_filter, tab, psies, flow_feat, S, B, H, W);
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}
+
 // ------------------------------------------------------------------ InstanceNorm2d (+relu, +residual)
 __device__ __forceinline__ float block_sum(float v, float* sh) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -141,6 +141,8 @@ struct MotifSplatArgs {
     int B, N, H, W, HH, WW, R;
     int row0;      // image row of local row 0 (row-band rendering): float coordinates are formed with GLOBAL rows so that
                    // floor() and the bilinear weights are bit-identical to the untiled render
+    int accumulate;   // 0: acc is written; 1: this call's sums / count are added to acc and the max plane is max-ed into it
+                      // (a further pair of source directions of the same frames: Ours_44.py:713-719 sums four)
 };
 
 struct SrcGeom {
@@ -318,7 +320,9 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
             if (!last || cc < 3) v = fix_to_float(tile[cc * OT_TP + cell], texp[cell]);
             else if (cc == 3) v = fmaxf(1.0f, __uint_as_float(tmaxb[cell]));     // max-splat output starts at ones (softsplat_max_cp.py:254)
             else v = (float)tcnt[cell];
-            abase[(long)(k * OT_CC + cc) * Q + (long)Y * a.WW + X] = v;
+            float* o = abase + (long)(k * OT_CC + cc) * Q + (long)Y * a.WW + X;
+            if (a.accumulate) v = (last && cc == 3) ? fmaxf(*o, v) : *o + v;
+            *o = v;
         }
         __syncthreads();
     }
@@ -360,12 +364,12 @@ __global__ __launch_bounds__(256) void splat_far_kernel(MotifSplatArgs a, int ti
     s.count(abase + 132L * Q, 1.0f);
 }
 
-extern "C" int motif_splat_motif_fwd(const float* imnet_out, const float* pred, const float* feat_lr,
-                                     const int32_t* iy, const int32_t* ix, const float* alpha, float flow_scale,
-                                     float* acc, int B, int N, int H, int W, int HH, int WW, int row0, void* stream) {
+extern "C" int motif_splat_motif_acc_fwd(const float* imnet_out, const float* pred, const float* feat_lr,
+                                         const int32_t* iy, const int32_t* ix, const float* alpha, float flow_scale,
+                                         float* acc, int B, int N, int H, int W, int HH, int WW, int row0, int accumulate, void* stream) {
     if (!imnet_out || !pred || !feat_lr || !iy || !ix || !alpha || !acc) return MOTIF_EINVAL;
     if (B < 1 || N < 1 || H < 1 || W < 1 || HH < 1 || WW < 1 || row0 < 0) return MOTIF_EINVAL;
-    MotifSplatArgs a{imnet_out, pred, feat_lr, iy, ix, alpha, 20.0f, flow_scale, acc, B, N, H, W, HH, WW, 16, row0};
+    MotifSplatArgs a{imnet_out, pred, feat_lr, iy, ix, alpha, 20.0f, flow_scale, acc, B, N, H, W, HH, WW, 16, row0, accumulate ? 1 : 0};
     const int cap = 2 * (OT_H + 2 * a.R) * (OT_W + 2 * a.R);
     const size_t lds = (size_t)OT_CC * OT_TP * 8 + (size_t)3 * OT_TP * 4 + (size_t)cap * 4;
     hipError_t e = hipFuncSetAttribute((const void*)splat_owner_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -378,4 +382,10 @@ extern "C" int motif_splat_motif_fwd(const float* imnet_out, const float* pred, 
     splat_far_kernel<<<grid2, 256, 0, (hipStream_t)stream>>>(a, tiles_x);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
+}
+
+extern "C" int motif_splat_motif_fwd(const float* imnet_out, const float* pred, const float* feat_lr,
+                                     const int32_t* iy, const int32_t* ix, const float* alpha, float flow_scale,
+                                     float* acc, int B, int N, int H, int W, int HH, int WW, int row0, void* stream) {
+    return motif_splat_motif_acc_fwd(imnet_out, pred, feat_lr, iy, ix, alpha, flow_scale, acc, B, N, H, W, HH, WW, row0, 0, stream);
 }

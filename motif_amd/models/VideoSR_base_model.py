@@ -56,12 +56,19 @@ class VideoSRBaseModel(BaseModel):
         with torch.no_grad():
             if self.times is None or "Ours" not in self.net_base:
                 raise NotImplementedError("only the 'Ours' generator is on the hot path")
-            self.fake_H, flow, flow_GT = self.netG(self.var_L, getattr(self, "real_H", None), self.times[:3], self.scale,
-                                                   use_GT=False, iter=4)
-            if len(self.times) != 3:
-                for l in range(3, len(self.times), 3):
-                    tmp, flow, flow_GT = self.netG(self.var_L, None, self.times[l:l + 3], self.scale, use_GT=False, iter=4)
+            if self.net_base == "Ours_44":              # one timestamp per call (VideoSR_base_model.py:182-187)
+                self.fake_H, flow, flow_GT = self.netG(self.var_L, getattr(self, "real_H", None), self.times[:1], self.scale,
+                                                       use_GT=False, iter=4)
+                for l in range(1, len(self.times), 1):
+                    tmp, flow, flow_GT = self.netG(self.var_L, None, self.times[l:l + 1], self.scale, use_GT=False, iter=4)
                     self.fake_H = torch.cat((self.fake_H, tmp), 0)
+            else:
+                self.fake_H, flow, flow_GT = self.netG(self.var_L, getattr(self, "real_H", None), self.times[:3], self.scale,
+                                                       use_GT=False, iter=4)
+                if len(self.times) != 3:
+                    for l in range(3, len(self.times), 3):
+                        tmp, flow, flow_GT = self.netG(self.var_L, None, self.times[l:l + 3], self.scale, use_GT=False, iter=4)
+                        self.fake_H = torch.cat((self.fake_H, tmp), 0)
             self.flow = flow
             self.flow_GT = flow_GT
         self.netG.train()

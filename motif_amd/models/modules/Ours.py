@@ -314,6 +314,12 @@ def gather_tables(H, W, HH, WW, device):
 
 
 class LunaTokis(nn.Module):
+    """`Ours.LunaTokis(setting=5)`.  The 4-frame generators (`Ours_4.py`, `Ours_44.py` next to this file) subclass it: they
+    differ in the t-independent motion stage (`_motion_stage`), in which frames are encoded (`_encode`) and in the
+    number D of source frames splatted into every output frame; the kernels are the same."""
+    D = 2                                  # source frames ("directions")
+    FLOW_IN, FLOW_GROUPS = 14, 2           # first flow_process conv (Ours.py:494)
+
     def __init__(self, setting=5):
         super().__init__()
         if setting != 5:
@@ -333,7 +339,7 @@ class LunaTokis(nn.Module):
         self.imnet = Siren(in_features=66, out_features=64, hidden_features=[64, 64, 256], hidden_layers=2, outermost_linear=True)
         self.synth_net = Siren(in_features=198, out_features=3, hidden_features=[64, 64, 64, 256], hidden_layers=3, outermost_linear=True)
         self.flow_process = nn.Sequential(
-            Conv2d(14, channel, 3, 1, 1, groups=2), Conv2d(channel, channel, 3, 1, 1, groups=2), nn.Identity(),
+            Conv2d(self.FLOW_IN, channel, 3, 1, 1, groups=self.FLOW_GROUPS), Conv2d(channel, channel, 3, 1, 1, groups=2), nn.Identity(),
             LateralBlock(channel), LateralBlock(channel), LateralBlock(channel), LateralBlock(channel), LateralBlock(channel),
             nn.Identity(), Conv2d(channel, channel, 3, 1, 1, padding_mode="reflect"))
         self.alpha = nn.Parameter(torch.ones(1) * -20.0)
@@ -360,14 +366,47 @@ class LunaTokis(nn.Module):
             y = fp[i](y, act=LRELU if i == 7 else NONE)
         return fp[9](y)
 
+    def _raft_pairs(self, hr, pairs, n_flows, H, W, iters):
+        """RAFT on the listed (source, target) frame pairs of the HR frames `hr` [B,n,3,HH,WW]; flow k of `n_flows` is
+        pair (src, dst) = pairs[k] or None for a flow the reference multiplies by zero (Ours.py:552-553, Ours_4.py:509-510,
+        Ours_44.py:513-516) -- those pairs are not run unless skip_zero_pairs is off.  -> LR flows [n_flows*B,2,H,W]."""
+        B, HH = hr.shape[0], hr.shape[3]
+        live = [(k, sd) for k, sd in enumerate(pairs) if sd[2] or not self.skip_zero_pairs]
+        i1 = torch.cat([hr[:, s] for _, (s, d, _) in live], 0) * 255.0
+        i2 = torch.cat([hr[:, d] for _, (s, d, _) in live], 0) * 255.0
+        f = self.flow_predictor(i1, i2, iters=iters, last_only=True)[-1]
+        f = ops.resize_bilinear(f, (H, W), False, H / HH)
+        flow = torch.zeros(n_flows * B, 2, H, W, dtype=torch.float32, device=hr.device)
+        for i, (k, (s, d, nz)) in enumerate(live):
+            if nz:
+                flow[k * B:(k + 1) * B].copy_(f[i * B:(i + 1) * B])
+        return flow
+
+    def _select_frames(self, x):
+        n = x.shape[1]
+        return x[:, n // 2 - 1:n // 2 + 1]                                     # centre pair (Ours.py:514-516)
+
+    def _motion_stage(self, fr, HH, WW, iters):
+        """fr [B,2,3,H,W] -> flow [4B,2,H,W] (pairs 00,01,10,11), psies [4B,3,H,W], flow-encoder input [2B,14,H,W]
+        (Ours.py:540-578, 614-631)."""
+        B, n, _, H, W = fr.shape
+        hr = ops.resize_bilinear(fr.reshape(B * n, 3, H, W), (HH, WW), False).view(B, n, 3, HH, WW)
+        flow = self._raft_pairs(hr, [(0, 0, False), (0, 1, True), (1, 0, True), (1, 1, False)], 4, H, W, iters)
+        psies, flow_feat_in = ops.reliability(fr[:, 0], fr[:, 1], flow, self.g_filter, B, H, W)
+        return flow, psies, flow_feat_in
+
+    def _encode(self, fr):
+        """-> encoder features [B,T,64,H,W], the D source features [D*B,64,H,W] (Ours.py:601-611)"""
+        feat = self.encoder(fr, None)                                          # [B,3,64,H,W]
+        return feat, torch.cat((feat[:, 0], feat[:, 2]), 0)
+
+    def _residual(self, c, target_t):
+        return c["feat"][:, 1]                                                  # Ours.py:609
+
     def _clip_stage(self, x, HH, WW, iters):
         """Everything of `Ours.py:514-638` + the `imnet` branch of 699-737 that does not depend on t."""
-        B, n = x.shape[0], x.shape[1]
-        H, W = x.shape[3], x.shape[4]
-        fr0, fr1 = x[:, n // 2 - 1], x[:, n // 2]                              # centre pair, [B,3,H,W] views
-        pair = torch.stack([fr0, fr1], dim=1)                                   # [B,2,3,H,W]
-        hr = ops.resize_bilinear(pair.reshape(B * 2, 3, H, W), (HH, WW), False).view(B, 2, 3, HH, WW)
-        a, b = hr[:, 0], hr[:, 1]
+        B, H, W = x.shape[0], x.shape[3], x.shape[4]
+        fr = self._select_frames(x)
         # RAFT + reliability maps are independent of the encoder until `flow_process`: run them on a side
         # stream so their many small, latency-bound launches hide under the encoder's MFMA-bound convolutions
         main = torch.cuda.current_stream()
@@ -376,28 +415,12 @@ class LunaTokis(nn.Module):
             side = self._side_stream = torch.cuda.Stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            if self.skip_zero_pairs:
-                i1 = torch.cat([a, b], 0) * 255.0                               # pairs 01, 10
-                i2 = torch.cat([b, a], 0) * 255.0
-                f = self.flow_predictor(i1, i2, iters=iters, last_only=True)[-1]
-                f = ops.resize_bilinear(f, (H, W), False, H / HH)
-                flow = torch.zeros(4 * B, 2, H, W, dtype=torch.float32, device=x.device)
-                flow[B:3 * B].copy_(f)
-            else:
-                i1 = torch.cat([a, a, b, b], 0) * 255.0
-                i2 = torch.cat([a, b, a, b], 0) * 255.0
-                f = self.flow_predictor(i1, i2, iters=iters, last_only=True)[-1]
-                flow = ops.resize_bilinear(f, (H, W), False, H / HH)
-                flow[:B] *= 0.0
-                flow[3 * B:] *= 0.0
-            psies, flow_feat_in = ops.reliability(fr0, fr1, flow, self.g_filter, B, H, W)
+            flow, psies, flow_feat_in = self._motion_stage(fr, HH, WW, iters)
             for t in (flow, psies, flow_feat_in):
                 t.record_stream(main)
-        feat = self.encoder(pair, None)                                        # [B,3,64,H,W]
-        residual = feat[:, 1].contiguous()
-        feat01 = torch.cat((feat[:, 0], feat[:, 2]), 0)                         # [2B,64,H,W]
+        feat, feat_src = self._encode(fr)
         main.wait_stream(side)
-        flow_feat = self._flow_encoder(flow_feat_in)                            # [2B,64,H,W]
+        flow_feat = self._flow_encoder(flow_feat_in)                            # [D*B,64,H,W]
         iy, ix, rel_y, rel_x = gather_tables(H, W, HH, WW, x.device)
         # the gathered-LR-feature part of each MLP's first layer does not depend on the HR pixel or on t:
         # evaluate it once per clip at LR resolution (1x1 convs), the HR kernels start from it (pre=1)
@@ -405,11 +428,14 @@ class LunaTokis(nn.Module):
         imnet_out = None                                                        # band mode renders it per band
         if self.band is None:
             imnet_out = ops.siren_imnet(self.imnet.packed_split(ops.SIREN_IMNET) if split else self.imnet.packed(),
-                                        ops.conv2d(self.imnet.l0_plan(0, 64), feat01), iy, ix, rel_y, rel_x, HH, WW, pre=2 if split else 1)
+                                        ops.conv2d(self.imnet.l0_plan(0, 64), feat_src), iy, ix, rel_y, rel_x, HH, WW, pre=2 if split else 1)
         flow_l0 = ops.conv2d(self.flow_imnet.l0_plan(0, 64), flow_feat)
-        synth_l0 = ops.conv2d(self.synth_net.l0_plan(133, 197), residual)
-        return dict(flow_l0=flow_l0, synth_l0=synth_l0, flow=flow, psies=psies, flow_feat_in=flow_feat_in, feat=feat, residual=residual, feat01=feat01,
-                    flow_feat=flow_feat, imnet_out=imnet_out, tables=(iy, ix, rel_y, rel_x))
+        c = dict(flow_l0=flow_l0, flow=flow, psies=psies, flow_feat_in=flow_feat_in, feat=feat, feat01=feat_src,
+                 flow_feat=flow_feat, imnet_out=imnet_out, tables=(iy, ix, rel_y, rel_x))
+        if self.D == 2:                                                         # Ours_44 picks the residual feature by t
+            c["residual"] = self._residual(c, None).contiguous()
+            c["synth_l0"] = ops.conv2d(self.synth_net.l0_plan(133, 197), c["residual"])
+        return c
 
     def clear_cache(self):
         self._cache_key, self._cache = None, None
@@ -438,8 +464,8 @@ class LunaTokis(nn.Module):
 
     def export_clip_cache(self, x, HH, WW, iters):
         """Run (or reuse) the t-independent stage for clip `x` and return the tensors the t-dependent half reads."""
-        if self.band is not None:
-            raise RuntimeError("the clip cache is exported in untiled mode")
+        if self.band is not None or self.D != 2:
+            raise RuntimeError("the clip cache is exported in untiled mode of the 2-source generators")
         key = self._clip_key(x, HH, WW, iters)
         if key != self._cache_key:
             self._cache, self._cache_key = self._clip_stage(x.float(), HH, WW, iters), key
@@ -465,6 +491,8 @@ class LunaTokis(nn.Module):
         sliced, so every per-pixel value equals the untiled one, and the owner-computes splat sees every source within
         `band_halo` rows of the band.  Exact as long as max |flow_y| + 1 <= band_halo; `last_max_flow_y` (device scalar,
         over the band's own rows, in HR pixels) lets the caller verify that over all bands."""
+        if self.D != 2:
+            raise NotImplementedError("row-band rendering is wired for the 2-source generators")
         r0, r1 = self.band
         if not (0 <= r0 < r1 <= HH):
             raise ValueError("band %r outside [0, %d)" % (self.band, HH))
@@ -485,6 +513,9 @@ class LunaTokis(nn.Module):
         if stages is not None:
             stages.update(pred=pred, acc=acc, rows=(e0, e1))
         return frames[..., lo:hi, :].contiguous(), flow_hr.contiguous(), 0
+
+    def _synth_l0(self, c, target_t):
+        return c["synth_l0"]
 
     # ----------------------------------------------------------------------------- forward
     def forward(self, x, input_target_frames, target_t, scale=None, rank=0, train_idx=0, use_GT=True, iter=12, flows=None,
@@ -513,9 +544,16 @@ class LunaTokis(nn.Module):
         pre = 2 if split else 1
         if self.band is not None:
             return self._forward_band(c, times, B, N, H, HH, WW, flow_blob, synth_blob, pre, stages)
-        pred = ops.siren_flow(flow_blob, c["flow_l0"], iy, ix, rel_y, rel_x, times, N, HH, WW, pre=pre)   # [2BN,3,HH,WW]
-        acc = ops.splat_motif(c["imnet_out"], pred, c["feat01"], iy, ix, self.alpha, HH / H, B, N, HH, WW)
-        frames = ops.siren_synth(synth_blob, acc, c["synth_l0"], iy, ix, times, B, N, HH, WW, pre=pre)
+        # source directions two at a time (the kernels take a direction pair); further pairs add into the accumulator
+        preds, acc = [], None
+        for d0 in range(0, self.D, 2):
+            sl = slice(d0 * B, (d0 + 2) * B)
+            pred = ops.siren_flow(flow_blob, c["flow_l0"][sl], iy, ix, rel_y, rel_x, times, N, HH, WW, pre=pre)   # [2BN,3,HH,WW]
+            acc = ops.splat_motif(c["imnet_out"][sl], pred, c["feat01"][sl], iy, ix, self.alpha, HH / H, B, N, HH, WW,
+                                  acc=acc, accumulate=d0 > 0)
+            preds.append(pred)
+        pred = preds[0] if len(preds) == 1 else torch.cat(preds, 0)              # [D*B*N,3,HH,WW]
+        frames = ops.siren_synth(synth_blob, acc, self._synth_l0(c, target_t), iy, ix, times, B, N, HH, WW, pre=pre)
         if stages is not None:
             stages.update(c)
             stages.update(pred=pred, acc=acc)

@@ -419,15 +419,19 @@ def splat(src, flow, z=None, want=("sum", "norm")):
     return outs
 
 
-def splat_motif(imnet_out, pred, feat_lr, iy, ix, alpha, flow_scale, B, N, HH, WW, acc=None, row0=0):
+def splat_motif(imnet_out, pred, feat_lr, iy, ix, alpha, flow_scale, B, N, HH, WW, acc=None, row0=0, accumulate=False):
+    """Fused soft-splat of two source directions into acc [B*N,133,HH,WW]; accumulate=True adds a further pair of
+    directions to an accumulator written by an earlier call (Ours_44 sums four)."""
     lib = _lib.load()
     feat_lr = _c(feat_lr)
     _, _, h, w = feat_lr.shape
     if acc is None:
+        if accumulate:
+            raise RuntimeError("splat_motif(accumulate=True) needs the accumulator of the first call")
         acc = torch.empty(B * N, 133, HH, WW, dtype=torch.float32, device=pred.device)
     # no zero fill: the owner-computes kernel writes every accumulator cell (max plane starts at 1)
-    check(lib.motif_splat_motif_fwd(_p(imnet_out), _p(pred), _p(feat_lr), _p(iy), _p(ix), _p(alpha.detach()), float(flow_scale), _p(acc),
-                                    B, N, h, w, HH, WW, int(row0), _stream()), "motif_splat_motif_fwd")
+    check(lib.motif_splat_motif_acc_fwd(_p(_c(imnet_out)), _p(_c(pred)), _p(feat_lr), _p(iy), _p(ix), _p(alpha.detach()), float(flow_scale), _p(acc),
+                                        B, N, h, w, HH, WW, int(row0), int(bool(accumulate)), _stream()), "motif_splat_motif_acc_fwd")
     return acc
 
 
@@ -477,6 +481,25 @@ def reliability(fr0, fr1, flow, g_filter, B, H, W):
     flow_feat = torch.empty(2 * B, 14, H, W, dtype=torch.float32, device=flow.device)
     check(lib.motif_reliability_fwd(_p(fr0), _p(fr1), fr0.stride(0), _p(flow), _p(_c(g_filter.detach())), _p(psies), _p(flow_feat),
                                     B, H, W, _stream()), "motif_reliability_fwd")
+    return psies, flow_feat
+
+
+def reliability_pairs(frames, flow, g_filter, table, durations, S):
+    """Table-driven reliability maps + flow-encoder input of the 4-frame generators.  frames [B,n,3,H,W] (frame / batch
+    strides free, planes dense); flow [F*B,2,H,W]; table: list of (src frame, dst frame, flow index, reverse flow index);
+    durations: list of (d0, d1) per flow (already divided); S flows per source frame."""
+    lib = _lib.load()
+    B, n, _, H, W = frames.shape
+    if not (frames.stride(4) == 1 and frames.stride(3) == W and frames.stride(2) == H * W):
+        frames = frames.contiguous()
+    flow = _c(flow)
+    J = len(table)
+    tab = (ctypes.c_int * (4 * J))(*[int(v) for row in table for v in row])
+    dur = (ctypes.c_float * (2 * J))(*[float(v) for row in durations for v in row])
+    psies = torch.empty(J * B, 3, H, W, dtype=torch.float32, device=flow.device)
+    flow_feat = torch.empty((J // S) * B, S * 7, H, W, dtype=torch.float32, device=flow.device)
+    check(lib.motif_reliability_pairs_fwd(_p(frames), frames.stride(1), frames.stride(0), _p(flow), _p(_c(g_filter.detach())), tab, dur, J, S,
+                                          _p(psies), _p(flow_feat), B, H, W, _stream()), "motif_reliability_pairs_fwd")
     return psies, flow_feat
 
 

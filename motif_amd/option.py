@@ -48,12 +48,12 @@ def parse(opt_path, is_train=True):
     return opt
 
 
-def default_opt(scale=4, gpu_ids=(0,), pretrain_model_G=None, name="synthetic", mma=None):
+def default_opt(scale=4, gpu_ids=(0,), pretrain_model_G=None, name="synthetic", mma=None, which_model_G="Ours"):
     """The option dict `test.yml` yields (test.yml:1-83) for the `Ours` generator, setting 5."""
     return dict_to_nonedict(OrderedDict(
         name=name, use_tb_logger=False, model="VideoSR_base", distortion="sr", scale=scale,
         gpu_ids=list(gpu_ids) if gpu_ids is not None else None, dist=False, is_train=True,
-        network_G=OrderedDict(which_model_G="Ours", nf=64, nframes=7, groups=8, front_RBs=5, back_RBs=40, setting=5, scale=scale, mma=mma),
+        network_G=OrderedDict(which_model_G=which_model_G, nf=64, nframes=7, groups=8, front_RBs=5, back_RBs=40, setting=5, scale=scale, mma=mma),
         path=OrderedDict(pretrain_model_G=pretrain_model_G, strict_load=True, models="./saved_checkpoints/", root="./"),
         train=OrderedDict(lr_G=0.0, lr_scheme="CosineAnnealingLR_Restart", beta1=0.9, beta2=0.99, pixel_criterion="cb",
                           pixel_weight=1.0, manual_seed=0),

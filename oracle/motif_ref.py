@@ -400,7 +400,11 @@ def back_warp(img, flow):
 
 class MotifRef(nn.Module):
     """Restatement of LunaTokis(setting=5).  `forward` returns the reference's 3-tuple; with
-    `stages` a dict, intermediate tensors are recorded under the names make_golden.py hooks."""
+    `stages` a dict, intermediate tensors are recorded under the names make_golden.py hooks.
+    The 4-frame generators (MotifRef4 / MotifRef44 below) differ in the t-independent motion stage and in the number
+    D of source frames that are splatted; the HR half is shared."""
+    D = 2                      # source frames ("directions") splatted into every output frame
+    FLOW_IN, FLOW_GROUPS = 14, 2
 
     def __init__(self):
         super().__init__()
@@ -413,13 +417,18 @@ class MotifRef(nn.Module):
         self.imnet = Siren(66, [64, 64, 256], 64)
         self.synth_net = Siren(198, [64, 64, 64, 256], 3)
         self.flow_process = nn.Sequential(
-            nn.Conv2d(14, 64, 3, 1, 1, groups=2), nn.Conv2d(64, 64, 3, 1, 1, groups=2), nn.LeakyReLU(0.1),
+            nn.Conv2d(self.FLOW_IN, 64, 3, 1, 1, groups=self.FLOW_GROUPS), nn.Conv2d(64, 64, 3, 1, 1, groups=2), nn.LeakyReLU(0.1),
             Lateral(64), Lateral(64), Lateral(64), Lateral(64), Lateral(64), nn.LeakyReLU(0.1),
             nn.Conv2d(64, 64, 3, 1, 1, padding_mode="reflect"))
         self.alpha = nn.Parameter(torch.ones(1) * -20.0)
         self.shuffle = nn.Conv2d(64, 64, 1)
 
     # -- t-independent stage: Ours.py:514-638 + gather/imnet 667-737 -------------------------------
+    def _psi_var(self, f):
+        sq_mean, mean = torch.split(
+            F.conv3d(F.pad(torch.cat([f ** 2, f], 1), (1, 1, 1, 1), mode="reflect").unsqueeze(1), self.g_filter).squeeze(1), 2, dim=1)
+        return (sq_mean - mean ** 2).clip(1e-9, None).sqrt().mean(1)
+
     def motion_and_reliability(self, x, HH, WW, iters, stages=None):
         B, _, _, H, W = x.shape  # x [B,3,2,H,W]
         xn = F.interpolate(x.reshape(B, -1, H, W), size=(HH, WW), mode="bilinear", align_corners=False).reshape(B, -1, 2, HH, WW)
@@ -438,29 +447,19 @@ class MotifRef(nn.Module):
         psi_photo = (torch.cat([fr0, fr0, fr1, fr1], 0) - warped).abs().mean(1)
         warped = back_warp(-torch.cat([flow4[0], flow4[2], flow4[1], flow4[3]], 0), flow)
         psi_flow = (flow - warped).abs().mean(1)
-        f = flow
-        sq_mean, mean = torch.split(
-            F.conv3d(F.pad(torch.cat([f ** 2, f], 1), (1, 1, 1, 1), mode="reflect").unsqueeze(1), self.g_filter).squeeze(1), 2, dim=1)
-        psi_var = (sq_mean - mean ** 2).clip(1e-9, None).sqrt().mean(1)
+        psi_var = self._psi_var(flow)
         psies = torch.stack([psi_photo, psi_flow / 10.0, psi_var], 1)
         return flow, psies
 
-    def forward(self, x, input_target_frames, target_t, scale=None, rank=0, train_idx=0, use_GT=True, iter=12,
-                flows=None, stages=None):
-        rec = (lambda k, v: stages.__setitem__(k, v.detach().clone())) if stages is not None else (lambda k, v: None)
-        x = x.permute(0, 2, 1, 3, 4)
+    def select_frames(self, x):                      # x [B,3,n,H,W]: centre pair (Ours.py:514-516)
         n = x.shape[2]
-        x = x[:, :, n // 2 - 1:n // 2 + 1]
-        target_t = torch.stack(target_t, 1).squeeze(-1)
-        B, N = target_t.shape
-        _, _, _, H, W = x.shape
-        if isinstance(scale, list):
-            HH, WW = scale[0][0], scale[1][0]
-        else:
-            HH, WW = round(H * scale), round(W * scale)
-        HH, WW = int(HH), int(WW)
+        return x[:, :, n // 2 - 1:n // 2 + 1]
+
+    def lr_stage(self, x, target_t, HH, WW, iters, rec, stages):
+        """-> flow-encoder input [D*B,FLOW_IN,H,W], source features [D*B,64,H,W], residual [B,64,H,W]"""
+        B, _, _, H, W = x.shape
         with torch.no_grad():
-            flow, psies = self.motion_and_reliability(x, HH, WW, iter, stages)
+            flow, psies = self.motion_and_reliability(x, HH, WW, iters, stages)
         rec("flow_lr", flow)
         rec("psies", psies)
         fr0, fr1 = x[:, :, 0], x[:, :, 1]
@@ -474,6 +473,22 @@ class MotifRef(nn.Module):
             psies.reshape(2, 2, B, -1, H, W).permute(0, 2, 1, 3, 4, 5).reshape(2 * B, 2, -1, H, W),
             dur.reshape(2, 4, 1, 1).unsqueeze(1).repeat(1, B, 1, H, W).reshape(2 * B, 2, 2, H, W) / 8.0,
         ), dim=2).reshape(2 * B, -1, H, W)
+        return flow_feat, feat, residual
+
+    def forward(self, x, input_target_frames, target_t, scale=None, rank=0, train_idx=0, use_GT=True, iter=12,
+                flows=None, stages=None):
+        rec = (lambda k, v: stages.__setitem__(k, v.detach().clone())) if stages is not None else (lambda k, v: None)
+        D = self.D
+        x = self.select_frames(x.permute(0, 2, 1, 3, 4))
+        target_t = torch.stack(target_t, 1).squeeze(-1)
+        B, N = target_t.shape
+        _, _, _, H, W = x.shape
+        if isinstance(scale, list):
+            HH, WW = scale[0][0], scale[1][0]
+        else:
+            HH, WW = round(H * scale), round(W * scale)
+        HH, WW = int(HH), int(WW)
+        flow_feat, feat, residual = self.lr_stage(x, target_t, HH, WW, iter, rec, stages)
         rec("flow_process_in", flow_feat)
         flow_feat = self.flow_process(flow_feat)
         rec("flow_process", flow_feat)
@@ -484,12 +499,12 @@ class MotifRef(nn.Module):
         coord_ = hr_coord.clone()
         coord_ += 1e-6
         coord_.clamp_(-1 + 1e-6, 1 - 1e-6)
-        c1, c3, c4, c5 = 2 * B * 64, 2 * B * 64, 2, 64 * B
+        c1, c3, c4, c5 = D * B * 64, D * B * 64, 2, 64 * B
         stack = torch.cat((feat.reshape(1, c1, H, W), flow_feat.reshape(1, c3, H, W), feat_coord, residual.reshape(1, c5, H, W)), 1)
         g = F.grid_sample(stack, coord_.flip(-1).unsqueeze(1), mode="nearest", align_corners=False)[:, :, 0, :]
         Q = HH * WW
-        q_feat = g[:, :c1].reshape(2 * B, -1, Q).permute(0, 2, 1)
-        q_flow_feat = g[:, c1:c1 + c3].reshape(2 * B, -1, Q).permute(0, 2, 1)
+        q_feat = g[:, :c1].reshape(D * B, -1, Q).permute(0, 2, 1)
+        q_flow_feat = g[:, c1:c1 + c3].reshape(D * B, -1, Q).permute(0, 2, 1)
         q_coord = g[:, c1 + c3:c1 + c3 + c4].reshape(1, -1, Q).permute(0, 2, 1)
         q_residual = g[:, c1 + c3 + c4:].reshape(B, -1, Q).permute(0, 2, 1)
         rel = hr_coord - q_coord
@@ -497,22 +512,22 @@ class MotifRef(nn.Module):
         rel[:, :, 1] *= W
         rec("rel_coord", rel)
         q_feat_low = q_feat
-        fin = torch.cat([q_flow_feat.repeat(1, N, 1).reshape(2 * B * N, Q, -1), target_t.reshape(B * N, 1, 1).repeat(2, Q, 1),
-                         rel.repeat(2 * B * N, 1, 1)], -1)
-        iin = torch.cat([q_feat, rel.repeat(2 * B, 1, 1)], -1)
-        pred = self.flow_imnet(fin)  # [2BN,Q,3]
-        q_feat = self.imnet(iin)  # [2B,Q,64]
+        fin = torch.cat([q_flow_feat.repeat(1, N, 1).reshape(D * B * N, Q, -1), target_t.reshape(B * N, 1, 1).repeat(D, Q, 1),
+                         rel.repeat(D * B * N, 1, 1)], -1)
+        iin = torch.cat([q_feat, rel.repeat(D * B, 1, 1)], -1)
+        pred = self.flow_imnet(fin)  # [D*B*N,Q,3]
+        q_feat = self.imnet(iin)  # [D*B,Q,64]
         rec("flow_imnet", pred)
         rec("imnet", q_feat)
         # local ensemble with one term is x*(area/area) == x exactly (Ours.py:754-775)
 
         nchw = lambda t, nb: t.reshape(nb, HH, WW, -1).permute(0, 3, 1, 2)
-        feat_hr = nchw(q_feat, 2 * B)
-        feat_low = nchw(q_feat_low, 2 * B)
+        feat_hr = nchw(q_feat, D * B)
+        feat_low = nchw(q_feat_low, D * B)
         q_res = nchw(q_residual, B)
-        fl = nchw(pred, 2 * B * N)
-        feat_all = torch.cat([feat_hr.repeat(1, N, 1, 1).reshape(2 * B * N, -1, HH, WW), fl[:, :-1],
-                              feat_low.repeat(1, N, 1, 1).reshape(2 * B * N, -1, HH, WW)], 1)
+        fl = nchw(pred, D * B * N)
+        feat_all = torch.cat([feat_hr.repeat(1, N, 1, 1).reshape(D * B * N, -1, HH, WW), fl[:, :-1],
+                              feat_low.repeat(1, N, 1, 1).reshape(D * B * N, -1, HH, WW)], 1)
         flow_hr = fl[:, :-1] * 20.0 * (HH / H)
         z = F.relu(fl[:, -1:]) * self.alpha
         rec("splat_flow", flow_hr)
@@ -529,12 +544,12 @@ class MotifRef(nn.Module):
         rec("fwarp_max", z_max)
         rec("fwarp_count", count)
 
-        output = output.reshape(2, B * N, -1, HH, WW).sum(0)
-        warped_z = warped_z.reshape(2, B * N, -1, HH, WW).sum(0)
+        output = output.reshape(D, B * N, -1, HH, WW).sum(0)
+        warped_z = warped_z.reshape(D, B * N, -1, HH, WW).sum(0)
         warped_z[warped_z == 0] = 1.0
         output = output / warped_z
-        z_max = z_max.reshape(2, B * N, -1, HH, WW).max(0)[0]
-        count = count.reshape(2, B * N, -1, HH, WW).sum(0)
+        z_max = z_max.reshape(D, B * N, -1, HH, WW).max(0)[0]
+        count = count.reshape(D, B * N, -1, HH, WW).sum(0)
         count_ = count.clone()
         count_[count_ == 0.0] = 1.0
         warped_z_ = warped_z.clone()
@@ -546,3 +561,95 @@ class MotifRef(nn.Module):
         y = self.synth_net(output_all.reshape(B * N, -1, Q).permute(0, 2, 1)).permute(0, 2, 1)
         y = y.reshape(B, N, -1, HH, WW).permute(1, 0, 2, 3, 4)
         return torch.clamp(y, 0, 1), flow_hr / 20.0 / (HH / H), 0
+
+
+class MotifRef4(MotifRef):
+    """Restatement of `/root/reference/models/modules/Ours_4.py` (`which_model_G: Ours_4`, networks.py:40-41): the input
+    clip's FOUR frames feed the motion stage (12 RAFT pairs, 8 flows kept: from frames 1 and 2 to frames 0..3), the
+    two centre frames are encoded and splatted as in `Ours`.  Ours_4.py:483-592."""
+    FLOW_IN, FLOW_GROUPS = 28, 4
+
+    def select_frames(self, x):
+        return x[:, :, :4]                           # Ours_4.py:492 uses x[:, :, 0..3]
+
+    def lr_stage(self, x, target_t, HH, WW, iters, rec, stages):
+        B, _, _, H, W = x.shape
+        with torch.no_grad():
+            xn = F.interpolate(x.reshape(B, -1, H, W), size=(HH, WW), mode="bilinear", align_corners=False).reshape(B, -1, 4, HH, WW)
+            f0, f1, f2, f3 = xn[:, :, 0], xn[:, :, 1], xn[:, :, 2], xn[:, :, 3]
+            flow = self.flow_predictor(torch.cat([f0, f0, f1, f1, f1, f1, f2, f2, f2, f2, f3, f3], 0) * 255.0,
+                                       torch.cat([f1, f2, f0, f1, f2, f3, f0, f1, f2, f3, f1, f2], 0) * 255.0, iters=iters)[-1]
+            if stages is not None:
+                stages["raft_flow"] = flow
+            fr0, fr1, fr2, fr3 = x[:, :, 0], x[:, :, 1], x[:, :, 2], x[:, :, 3]
+            flow = F.interpolate(flow, size=(H, W), mode="bilinear", align_corners=False) * (H / HH)
+            flow = flow.reshape(12, B, 2, H, W).clone()
+            flow[3] *= 0.0
+            flow[8] *= 0.0
+            f8 = flow[2:-2].reshape(8 * B, 2, H, W)
+            warped = back_warp(torch.cat([fr0, fr1, fr2, fr3, fr0, fr1, fr2, fr3], 0), f8)
+            psi_photo = (torch.cat([fr1, fr1, fr1, fr1, fr2, fr2, fr2, fr2], 0) - warped).abs().mean(1)
+            warped = back_warp(-torch.cat([flow[0], flow[3], flow[7], flow[10], flow[1], flow[4], flow[8], flow[11]], 0), f8)
+            psi_flow = (f8 - warped).abs().mean(1)
+            psies = torch.stack([psi_photo, psi_flow / 10.0, self._psi_var(f8)], 1)
+            flow = f8
+        rec("flow_lr", flow)
+        rec("psies", psies)
+        feat = self.encoder(torch.stack([fr1, fr2], 1))
+        rec("encoder", feat)
+        residual = feat[:, 1].reshape(B, -1, H, W)
+        feat = torch.cat((feat[:, 0], feat[:, 2]), 0)
+        dur = torch.tensor([[2, 0], [2, 2], [2, 6], [2, 8], [6, 0], [6, 2], [6, 6], [6, 8]], dtype=torch.float32, device=x.device).unsqueeze(1)
+        flow_feat = torch.cat((
+            (flow / 20.0).reshape(2, 4, B, -1, H, W).permute(0, 2, 1, 3, 4, 5).reshape(2 * B, 4, -1, H, W),
+            psies.reshape(2, 4, B, -1, H, W).permute(0, 2, 1, 3, 4, 5).reshape(2 * B, 4, -1, H, W),
+            dur.reshape(2, 8, 1, 1).unsqueeze(1).repeat(1, B, 1, H, W).reshape(2 * B, 4, 2, H, W) / 8.0,
+        ), dim=2).reshape(2 * B, -1, H, W)
+        return flow_feat, feat, residual
+
+
+class MotifRef44(MotifRef):
+    """Restatement of `/root/reference/models/modules/Ours_44.py` (`which_model_G: Ours_44`, networks.py:42-43): all 16
+    ordered frame pairs, all four frames encoded (7 features) and FOUR source frames splatted into the output; one
+    timestamp per call (`target_t.item()`, Ours_44.py:572), the residual feature is picked by int(t*6).  `scale` must be
+    a number (Ours_44.py:503 passes it as `scale_factor`)."""
+    D = 4
+    FLOW_IN, FLOW_GROUPS = 28, 4
+
+    def select_frames(self, x):
+        return x[:, :, :4]
+
+    def lr_stage(self, x, target_t, HH, WW, iters, rec, stages):
+        B, _, _, H, W = x.shape
+        with torch.no_grad():
+            xn = F.interpolate(x.reshape(B, -1, H, W), size=(HH, WW), mode="bilinear", align_corners=False).reshape(B, -1, 4, HH, WW)
+            fs = [xn[:, :, i] for i in range(4)]
+            flow = self.flow_predictor(torch.cat([fs[i] for i in range(4) for _ in range(4)], 0) * 255.0,
+                                       torch.cat([fs[j] for _ in range(4) for j in range(4)], 0) * 255.0, iters=iters)[-1]
+            if stages is not None:
+                stages["raft_flow"] = flow
+            fr = [x[:, :, i] for i in range(4)]
+            flow = F.interpolate(flow, size=(H, W), mode="bilinear", align_corners=False) * (H / HH)
+            flow = flow.reshape(16, B, 2, H, W).clone()
+            for k in (0, 5, 10, 15):
+                flow[k] *= 0.0
+            f16 = flow.reshape(16 * B, 2, H, W)
+            warped = back_warp(torch.cat([fr[j] for _ in range(4) for j in range(4)], 0), f16)
+            psi_photo = (torch.cat([fr[i] for i in range(4) for _ in range(4)], 0) - warped).abs().mean(1)
+            warped = back_warp(-torch.cat([flow[4 * j + i] for i in range(4) for j in range(4)], 0), f16)
+            psi_flow = (f16 - warped).abs().mean(1)
+            psies = torch.stack([psi_photo, psi_flow / 10.0, self._psi_var(f16)], 1)
+            flow = f16
+        rec("flow_lr", flow)
+        rec("psies", psies)
+        feat = self.encoder(torch.stack(fr, 1))                     # [B,7,64,H,W]
+        rec("encoder", feat)
+        residual = feat[:, int(target_t.item() * 6)].reshape(B, -1, H, W)      # Ours_44.py:572
+        feat = torch.cat((feat[:, 0], feat[:, 2], feat[:, 4], feat[:, 6]), 0)
+        dur = torch.tensor([[a, b] for a in (0, 2, 4, 6) for b in (0, 2, 4, 6)], dtype=torch.float32, device=x.device).unsqueeze(1)
+        flow_feat = torch.cat((
+            (flow / 20.0).reshape(4, 4, B, -1, H, W).permute(0, 2, 1, 3, 4, 5).reshape(4 * B, 4, -1, H, W),
+            psies.reshape(4, 4, B, -1, H, W).permute(0, 2, 1, 3, 4, 5).reshape(4 * B, 4, -1, H, W),
+            dur.reshape(4, 8, 1, 1).unsqueeze(1).repeat(1, B, 1, H, W).reshape(4 * B, 4, 2, H, W) / 6.0,
+        ), dim=2).reshape(4 * B, -1, H, W)
+        return flow_feat, feat, residual

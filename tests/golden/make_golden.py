@@ -26,7 +26,7 @@ REF = "/root/reference"
 sys.path.insert(0, ROOT)
 
 from oracle import native  # noqa: E402
-from oracle.motif_ref import MotifRef  # noqa: E402
+from oracle.motif_ref import MotifRef, MotifRef4, MotifRef44  # noqa: E402
 from motif_amd.utils.synth_weights import fill_state_dict, synth_tensor  # noqa: E402
 from motif_amd.data.synthetic import synthetic_sample, smooth_video  # noqa: E402
 
@@ -75,11 +75,29 @@ def ref_raft_ckpt(path, *a, **k):
     return {"model": {"flow_predictor." + kk: synth_tensor("flow_predictor." + kk, v) for kk, v in sd.items()}}
 
 
+def build_variant(which):
+    """Ours_4 / Ours_44 (networks.py:40-43) from the reference's own module files, natives stubbed as for Ours.
+    Ours_44.__init__ also loads a private encoder checkpoint (Ours_44.py:423-424, strict=False): stand-in = empty dict."""
+    import importlib
+    mod = importlib.import_module("models.modules." + which)
+    net = mod.LunaTokis()
+    fill_state_dict(net)
+    net.eval()
+    return net
+
+
 def build_reference():
     install_stubs()
     sys.path.insert(0, REF)
     real_load = torch.load
-    torch.load = lambda p, *a, **k: ref_raft_ckpt(p) if "raft_smooth" in str(p) else real_load(p, *a, **k)
+
+    def fake_load(p, *a, **k):
+        if "raft_smooth" in str(p) or "raft" in str(p).lower():
+            return ref_raft_ckpt(p)
+        if str(p).endswith("LunaTokis.pth"):
+            return {}
+        return real_load(p, *a, **k)
+    torch.load = fake_load
     import models.modules.Ours as Ours
     import models.softsplat_cp as sp
     import models.softsplat_max_cp as spm
@@ -117,8 +135,14 @@ def pack(store, key, t, limit=300_000):
         store[key + "__vals"] = t.reshape(-1)[idx].numpy()
 
 
-def run_case(net, name, h, w, scale, n_times, batch=1, seed=0, n_frames=4, pad_to=None):
+def run_case(net, name, h, w, scale, n_times, batch=1, seed=0, n_frames=4, pad_to=None, oracle_cls=MotifRef, time_idx=None,
+             numeric_scale=False):
     sample = synthetic_sample(h, w, scale, n_times, n_frames=n_frames, batch=batch, seed=seed)
+    if time_idx is not None:                      # Ours_44 renders one timestamp per call (VideoSR_base_model.py:182-187)
+        sample["time"] = [sample["time"][i] for i in time_idx]
+        n_times = len(time_idx)
+    if numeric_scale:                             # Ours_44.py:503 passes `scale` to interpolate(scale_factor=...)
+        sample["scale"] = scale
     stages = {}
     hooks = []
 
@@ -146,7 +170,7 @@ def run_case(net, name, h, w, scale, n_times, batch=1, seed=0, n_frames=4, pad_t
         hk.remove()
 
     # the oracle restatement on the same inputs, compared stage by stage
-    orc = fill_state_dict(MotifRef().eval())
+    orc = fill_state_dict(oracle_cls().eval())
     ost = {}
     with torch.no_grad():
         o_out, o_flow, _ = orc(sample["LQs"], None, sample["time"], sample["scale"], use_GT=False, iter=4, stages=ost)
@@ -165,7 +189,7 @@ def run_case(net, name, h, w, scale, n_times, batch=1, seed=0, n_frames=4, pad_t
     print(name, "reference vs oracle restatement, max|diff| per stage:", json.dumps(report))
 
     store = {"LQs": sample["LQs"].numpy(), "times": torch.stack(sample["time"], 0).numpy(),
-             "scale": np.array([sample["scale"][0][0], sample["scale"][1][0]], dtype=np.int64),
+             "scale": np.array([out.shape[-2], out.shape[-1]], dtype=np.int64),
              "iters": np.array(4), "torch_version": np.array(torch.__version__)}
     pack(store, "out", out)
     pack(store, "flow", flow)
@@ -179,9 +203,10 @@ def run_case(net, name, h, w, scale, n_times, batch=1, seed=0, n_frames=4, pad_t
     return report
 
 
-def shell_case(net):
+def shell_case(net, net_base="Ours", fname="shell_T7_lr32_s4.npz", numeric_scale=False):
     """Row H: VideoSRBaseModel.test time-chunking (VideoSR_base_model.py:169-200) driven on the
-    reference class with a stand-in `self`, T=7 timestamps -> chunks 3,3,1."""
+    reference class with a stand-in `self`, T=7 timestamps -> chunks 3,3,1 (Ours, Ours_4) or one timestamp per call
+    (Ours_44, VideoSR_base_model.py:182-187)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("ref_vsr_src", os.path.join(REF, "models", "VideoSR_base_model.py"))
     src = open(spec.origin).read()
@@ -192,15 +217,15 @@ def shell_case(net):
     exec(compile("import logging\nlogger = logging.getLogger('base')\n" + body, spec.origin, "exec"), ns)
     cls = ns["VideoSRBaseModel"]
     sample = synthetic_sample(32, 32, 4, 7, seed=3)
-    me = types.SimpleNamespace(netG=net, net_base="Ours", var_L=sample["LQs"], real_H=sample["GT"],
-                               times=sample["time"], scale=sample["scale"])
+    me = types.SimpleNamespace(netG=net, net_base=net_base, var_L=sample["LQs"], real_H=sample["GT"],
+                               times=sample["time"], scale=4 if numeric_scale else sample["scale"])
     cls.test(me)
     net.eval()
     store = {"LQs": sample["LQs"].numpy(), "GT": sample["GT"].numpy(), "times": torch.stack(sample["time"], 0).numpy(),
              "scale": np.array([sample["scale"][0][0], sample["scale"][1][0]], dtype=np.int64)}
     pack(store, "fake_H", me.fake_H, limit=10_000_000)
-    np.savez_compressed(os.path.join(HERE, "shell_T7_lr32_s4.npz"), **store)
-    print("shell fake_H", tuple(me.fake_H.shape))
+    np.savez_compressed(os.path.join(HERE, fname), **store)
+    print("shell", net_base, "fake_H", tuple(me.fake_H.shape))
 
 
 def pwc_case():
@@ -221,6 +246,21 @@ def pwc_case():
     print("pwc flow", tuple(flow.shape), float(flow.abs().mean()))
 
 
+def variants():
+    """the 4-frame generators, goldens + restatement check (writes its own report file)."""
+    rep = {}
+    n4 = build_variant("Ours_4")
+    json.dump({k: list(v.shape) for k, v in n4.state_dict().items()}, open(os.path.join(HERE, "ours4_state_dict_keys.json"), "w"), indent=0)
+    rep["ours4_lr32_s4_n3"] = run_case(n4, "ours4_lr32_s4_n3", 32, 32, 4, 3, seed=4, oracle_cls=MotifRef4)
+    rep["ours4_lr32x48_s4_n2_b2"] = run_case(n4, "ours4_lr32x48_s4_n2_b2", 32, 48, 4, 2, batch=2, seed=5, oracle_cls=MotifRef4)
+    n44 = build_variant("Ours_44")
+    json.dump({k: list(v.shape) for k, v in n44.state_dict().items()}, open(os.path.join(HERE, "ours44_state_dict_keys.json"), "w"), indent=0)
+    rep["ours44_lr32_s4_t3of6"] = run_case(n44, "ours44_lr32_s4_t3of6", 32, 32, 4, 7, seed=6, oracle_cls=MotifRef44, time_idx=[3], numeric_scale=True)
+    rep["ours44_lr32_s4_t5of6"] = run_case(n44, "ours44_lr32_s4_t5of6", 32, 32, 4, 7, seed=6, oracle_cls=MotifRef44, time_idx=[5], numeric_scale=True)
+    shell_case(n44, net_base="Ours_44", fname="shell44_T7_lr32_s4.npz", numeric_scale=True)
+    json.dump(rep, open(os.path.join(HERE, "restatement_vs_reference_4frame.json"), "w"), indent=1)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -233,8 +273,15 @@ def main():
     reports["lr32x48_s4_n2_b2"] = run_case(net, "lr32x48_s4_n2_b2", 32, 48, 4, 2, batch=2, seed=2)
     shell_case(net)
     pwc_case()
+    variants()
     json.dump(reports, open(os.path.join(HERE, "restatement_vs_reference.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main()
+    if "--variants-only" in sys.argv:
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        build_reference()
+        variants()
+    else:
+        main()

@@ -248,7 +248,7 @@ Siren.packed = Siren.packed_split = lambda self, *a: None
 def siren_flow(blob, flow_l0, iy, ix, rel_y, rel_x, times, N, HH, WW, pre=False):
     calls["flow"].append([float(v) for v in times.reshape(-1)])
     return times.reshape(1, -1, 1, 1, 1).expand(2, N, 3, HH, WW).reshape(2 * N, 3, HH, WW) * 0.01 + flow_l0.mean()
-def splat_motif(imnet_out, pred, feat_lr, iy, ix, alpha, flow_scale, B, N, HH, WW, acc=None, row0=0):
+def splat_motif(imnet_out, pred, feat_lr, iy, ix, alpha, flow_scale, B, N, HH, WW, acc=None, row0=0, accumulate=False):
     return pred[:N, :1].repeat(1, 133, 1, 1) * 0 + imnet_out.mean() + feat_lr.mean()
 def siren_synth(blob, acc, synth_l0, iy, ix, times, B, N, HH, WW, pre=False):
     calls["synth"].append(N)
@@ -303,6 +303,23 @@ def test_bench_launcher_spawns_ranks_gloo(tmp_path):
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["backend"] == "gloo"
+
+
+def test_four_frame_generators_keys_and_define_g():
+    """networks.define_G branches of networks.py:40-43; the 698 keys / shapes equal the reference's Ours_4 / Ours_44."""
+    import json
+    from motif_amd import option
+    from motif_amd.models import networks
+    from motif_amd.models.modules import Ours_4, Ours_44
+    for which, cls, fn in (("Ours_4", Ours_4.LunaTokis, "ours4_state_dict_keys.json"), ("Ours_44", Ours_44.LunaTokis, "ours44_state_dict_keys.json")):
+        net = networks.define_G(option.default_opt(which_model_G=which))
+        assert isinstance(net, cls)
+        want = json.load(open(os.path.join(ROOT, "tests", "golden", fn)))
+        got = {k: list(v.shape) for k, v in net.state_dict().items()}
+        assert got == want, which
+        assert net.flow_process[0].weight.shape == (64, 7, 3, 3) and net.flow_process[0].groups == 4
+    with pytest.raises(NotImplementedError):
+        networks.define_G(option.default_opt(which_model_G="TMNet"))
 
 
 def test_arithmetic_mode_option_plumbing():

@@ -91,6 +91,58 @@ def test_lunatokis_matches_reference_goldens(net, case):
     assert p >= 60.0, "PSNR(build, reference) %.1f dB < 60 dB" % p
 
 
+def _variant_net(which):
+    from motif_amd.models import networks
+    from motif_amd.option import default_opt
+    from motif_amd.utils.synth_weights import fill_state_dict
+    return fill_state_dict(networks.define_G(default_opt(which_model_G=which))).cuda().eval()
+
+
+@pytest.mark.parametrize("which,case", [("Ours_4", "ours4_lr32_s4_n3"), ("Ours_4", "ours4_lr32x48_s4_n2_b2"),
+                                        ("Ours_44", "ours44_lr32_s4_t3of6"), ("Ours_44", "ours44_lr32_s4_t5of6")])
+def test_four_frame_generators_match_reference_goldens(which, case):
+    """`Ours_4` (12 RAFT pairs, 28-channel flow encoder input) and `Ours_44` (16 pairs, four source frames
+    splatted, residual feature picked by int(t*6): t = 5/6 in fp32 picks index 4) against goldens captured from the
+    reference's own Ours_4.py / Ours_44.py (tests/golden/make_golden.py --variants-only)."""
+    g = load(case)
+    net = _variant_net(which)
+    x = torch.from_numpy(g["LQs"]).cuda()
+    times = [t.cuda() for t in torch.from_numpy(g["times"])]
+    scale = 4 if which == "Ours_44" else [[int(g["scale"][0])], [int(g["scale"][1])]]
+    st = {}
+    with torch.no_grad():
+        out, flow, _ = net(x, None, times, scale, use_GT=False, iter=4, stages=st)
+    B, N, D = x.shape[0], len(times), net.D
+    golden_cmp(g, "flow_lr", st["flow"], 2e-3, 1e-3)
+    golden_cmp(g, "psies", st["psies"], 1e-3, 1e-3)
+    golden_cmp(g, "encoder", st["feat"], 2e-4, 1e-3)
+    golden_cmp(g, "flow_process", st["flow_feat"], 1e-3, 1e-3)
+    golden_cmp(g, "imnet", st["imnet_out"].reshape(D * B, 64, -1).permute(0, 2, 1), 2e-4, 1e-3)
+    golden_cmp(g, "flow_imnet", st["pred"].reshape(D * B * N, 3, -1).permute(0, 2, 1), 2e-4, 1e-3)
+    golden_cmp(g, "flow", flow, 2e-4, 1e-3)
+    ref = torch.from_numpy(g["out"])
+    p = psnr(out.cpu(), ref)
+    print("%s %s: PSNR(build, reference) = %.1f dB, Linf = %.2e" % (which, case, p, float((out.cpu() - ref).abs().max())))
+    assert p >= 60.0, "PSNR(build, reference) %.1f dB < 60 dB" % p
+
+
+def test_shell_ours44_one_timestamp_per_call_matches_reference():
+    """VideoSR_base_model.py:182-187: for `Ours_44` the shell calls the generator once per timestamp (T = 7 here) with the
+    numeric scale; fake_H == the reference shell's output."""
+    from motif_amd.models.VideoSR_base_model import VideoSRBaseModel
+    from motif_amd.option import default_opt
+    from motif_amd.utils.synth_weights import fill_state_dict
+    g = load("shell44_T7_lr32_s4")
+    model = VideoSRBaseModel(default_opt(scale=4, gpu_ids=[0], which_model_G="Ours_44"))
+    fill_state_dict(model.netG)
+    model.feed_data({"LQs": torch.from_numpy(g["LQs"]), "GT": torch.from_numpy(g["GT"]), "time": list(torch.from_numpy(g["times"]))})
+    assert model.scale == 4
+    model.test()
+    fake, ref = model.fake_H.cpu(), torch.from_numpy(g["fake_H"])
+    assert fake.shape == ref.shape == (7, 1, 3, 128, 128)
+    assert psnr(fake, ref) >= 60.0
+
+
 def test_synth_input_planes_match_reference(net):
     """Post-splat normalisation + decoder input (Ours.py:811-844) through the splat of the predicted flow."""
     from motif_amd import ops
