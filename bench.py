@@ -105,6 +105,7 @@ def conv_flops(desc_log):
 
 IMNET_MAC, FLOW_MAC, SYNTH_MAC = 41088, 25536, 38016          # per point, SURVEY.md §8(a) B1-B3
 SPLAT_BYTES_PER_PXFRAME = 2 * (64 * 4 + 3 * 4) + 133 * 4      # fused form: imnet_out + pred of both directions read, 133 planes written
+SPLAT_PRE_BYTES_PER_PXFRAME = 2 * (64 * 4 + 3 * 4) + 67 * 4   # pre-contracted form: 67 planes written
 
 
 def instrumented_clip(model, sample):
@@ -161,6 +162,8 @@ def instrumented_clip(model, sample):
     hook("siren_flow", lambda out, *a, **k: ("flow_imnet", 2.0 * FLOW_MAC * out.shape[0] * out.shape[2] * out.shape[3], None))
     hook("siren_synth", lambda out, *a, **k: ("synth_net", 2.0 * SYNTH_MAC * out.shape[0] * out.shape[1] * out.shape[3] * out.shape[4], None))
     hook("splat_motif", lambda out, *a, **k: ("splat", float(SPLAT_BYTES_PER_PXFRAME) * out.shape[0] * out.shape[2] * out.shape[3], None))
+    hook("splat_motif_pre", lambda out, *a, **k: ("splat", float(SPLAT_PRE_BYTES_PER_PXFRAME) * out.shape[0] * out.shape[2] * out.shape[3], None))
+    hook("siren_synth_pre", lambda out, *a, **k: ("synth_net", 2.0 * SYNTH_MAC * out.shape[0] * out.shape[1] * out.shape[3] * out.shape[4], None))
     hook("raft_corr_lookup_pyramid", lambda out, *a, **k: ("raft_lookup", 0.0, None))
     hook("instance_norm", lambda out, *a, **k: ("instance_norm", 0.0, None))
     hook("resize_bilinear", lambda out, *a, **k: ("resize", 0.0, None))

@@ -68,6 +68,16 @@ int motif_splat_motif_fwd(const float* imnet_out, const float* pred, const float
 int motif_splat_motif_acc_fwd(const float* imnet_out, const float* pred, const float* feat_lr,
                               const int32_t* iy, const int32_t* ix, const float* alpha, float flow_scale,
                               float* acc, int B, int N, int H, int W, int HH, int WW, int row0, int accumulate, void* stream);
+/* Pre-contracted form (same result, half the accumulator).  The splat is linear in its sources and synth_net's first
+ * layer is linear in the normalised splat (Ours.py:811-814, 839-856), so W0[:, 0:130] is applied BEFORE the splat:
+ *   u_hr  [2B,64,Q]   = imnet with its head composed with W0[:, 0:64]  (motif_siren_imnet_fwd on composed weights),
+ *   g_lr  [2B,64,H,W] = W0[:, 66:130] . encoder feature (a 1x1 convolution at LR; gathered by the nearest tables here),
+ *   ab    [2,64]      = W0[:, 64], W0[:, 65] (the raw predicted-flow channels, Ours.py:789),
+ * a source carries u + g + a*p0 + b*p1.   acc [B*N, 67, HH, WW]: planes 0..63 sums, 64 sum of e^z*w, 65 max (init 1),
+ * 66 count; consumed by motif_siren_synth_pre_fwd. */
+int motif_splat_motif_pre_fwd(const float* u_hr, const float* pred, const float* g_lr, const float* ab,
+                              const int32_t* iy, const int32_t* ix, const float* alpha, float flow_scale,
+                              float* acc, int B, int N, int H, int W, int HH, int WW, int row0, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * B1-B4  space-time local implicit MLPs (SIREN, omega0=30) with the nearest gather fused in.
@@ -103,6 +113,13 @@ int motif_siren_flow_fwd(const float* packed, const float* flowfeat_lr, const in
 int motif_siren_synth_fwd(const float* packed, const float* acc, const float* residual_lr,
                           const int32_t* iy, const int32_t* ix, const float* times, float* frames,
                           int B, int N, int H, int W, int HH, int WW, int pre, void* stream);
+/* synth on the pre-contracted accumulator of motif_splat_motif_pre_fwd: pre-activation of the first layer =
+ * residual_l0 (the LR partial W0[:, 133:197] . residual + b0, as with pre = 1/2) + acc[0:64] / warped_z +
+ * W0[:, 130:133] . extra + W0[:, 197] t, with the exact-equality patches of Ours.py:811-830 on warped_z / count;
+ * `packed` from motif_siren_pack_split(kind = 3).  bf16x3 arithmetic only. */
+int motif_siren_synth_pre_fwd(const float* packed, const float* acc67, const float* residual_l0,
+                              const int32_t* iy, const int32_t* ix, const float* times, float* frames,
+                              int B, int N, int H, int W, int HH, int WW, void* stream);
 /* debugging/parity aid: materialise the 198-channel synth input [B*N,198,HH,WW] (Ours.py:839-844). */
 int motif_synth_input_fwd(const float* acc, const float* residual_lr, const int32_t* iy, const int32_t* ix,
                           const float* times, float* out, int B, int N, int H, int W, int HH, int WW, void* stream);

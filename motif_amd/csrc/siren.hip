@@ -501,6 +501,14 @@ extern "C" int motif_siren_synth_fwd(const float* packed, const float* acc, cons
     return pre ? launch_siren<MODE_SYNTH, SIREN_TP_SYNTH, true>(a, stream) : launch_siren<MODE_SYNTH, SIREN_TP_SYNTH, false>(a, stream);
 }
 
+extern "C" int motif_siren_synth_pre_fwd(const float* packed, const float* acc, const float* residual_l0,
+                                         const int32_t* iy, const int32_t* ix, const float* times, float* frames,
+                                         int B, int N, int H, int W, int HH, int WW, void* stream) {
+    if (!packed || !acc || !residual_l0 || !iy || !ix || !times || !frames || B < 1 || N < 1) return MOTIF_EINVAL;
+    SirenArgs a{packed, residual_l0, acc, iy, ix, nullptr, nullptr, times, frames, B * N, N, B, H, W, HH, WW};
+    return motif_siren_split_launch(MODE_SYNTHC, a, stream);
+}
+
 // parity aid: the 198-channel synth input, materialised (never used on the product path)
 __global__ void synth_input_kernel(const float* acc, const float* res_lr, const int32_t* iy, const int32_t* ix,
                                    const float* times, float* out, int B, int N, int H, int W, int HH, int WW) {

@@ -86,12 +86,13 @@ struct SirenArgs {
     int stagger;                  // start offset of the second wave per SIMD, in s_sleep(127) units (~8k cycles)
 };
 
-enum { MODE_IMNET = 0, MODE_FLOW = 1, MODE_SYNTH = 2 };
+enum { MODE_IMNET = 0, MODE_FLOW = 1, MODE_SYNTH = 2, MODE_SYNTHC = 3 };   // SYNTHC: first layer pre-contracted into the splat (siren_split.hip)
 
 template <int MODE> struct Net;
 template <> struct Net<MODE_IMNET> { static constexpr int K0 = 66, NH = 3, HEAD = 64; };
 template <> struct Net<MODE_FLOW>  { static constexpr int K0 = 67, NH = 3, HEAD = 3; };
 template <> struct Net<MODE_SYNTH> { static constexpr int K0 = 198, NH = 4, HEAD = 3; };
+template <> struct Net<MODE_SYNTHC> { static constexpr int K0 = 198, NH = 4, HEAD = 3; };
 
 
 // siren_split.hip: same networks on the bf16 matrix cores (blob from motif_siren_pack_split, LR partial required)

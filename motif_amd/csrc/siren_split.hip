@@ -52,22 +52,23 @@ __device__ __forceinline__ float sin_rev(float x) {
 }
 
 template <int MODE> struct SLayout {
+    static constexpr bool SYN = MODE >= MODE_SYNTH;       // both synth forms: five linear layers, first layer streamed
     static constexpr int KS0 = (MODE == MODE_SYNTH) ? 9 : 1;
     // fragment section, in u32x4 (16-byte) units: layer = [KS][3 parts][MT][64 lanes]
     static constexpr long F_W0 = 0;
     static constexpr long F_W1 = F_W0 + (long)KS0 * 3 * 2 * 64;
     static constexpr long F_W1B = F_W1 + 4L * 3 * 2 * 64;
-    static constexpr long F_W2 = F_W1B + (MODE == MODE_SYNTH ? 4L * 3 * 2 * 64 : 0);
+    static constexpr long F_W2 = F_W1B + (SYN ? 4L * 3 * 2 * 64 : 0);
     static constexpr long F_W3 = F_W2 + 4L * 3 * 8 * 64;
     static constexpr long F_END = F_W3 + (MODE == MODE_IMNET ? 16L * 3 * 2 * 64 : 0);
     // float section (after the fragments): B1, [B1b], B2, then B3 (imnet) or the fp32 VALU head Wv[3][32][2][4] + bias[4]
     static constexpr int O_B1 = 0;
     static constexpr int O_B1B = 64;
-    static constexpr int O_B2 = O_B1B + (MODE == MODE_SYNTH ? 64 : 0);
+    static constexpr int O_B2 = O_B1B + (SYN ? 64 : 0);
     static constexpr int O_HEAD = O_B2 + 256;
     static constexpr int NFLOATS = O_HEAD + (MODE == MODE_IMNET ? 64 : 3 * 32 * 8 + 4);
     // LDS residency: synth streams its first layer, imnet its head, from L2
-    static constexpr long LDS_F0 = (MODE == MODE_SYNTH) ? F_W1 : 0;
+    static constexpr long LDS_F0 = SYN ? F_W1 : 0;
     static constexpr long LDS_F1 = (MODE == MODE_IMNET) ? F_W3 : F_END;
     static constexpr long LDS_BYTES = (LDS_F1 - LDS_F0) * 16 + (long)NFLOATS * 4;
     static constexpr long TOTAL_FLOATS = F_END * 4 + NFLOATS;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
     const u32x4* lw1_0 = ldsv + (L::F_W1 - L::LDS_F0) + lane;
     const u32x4* lw1b_0 = ldsv + (L::F_W1B - L::LDS_F0) + lane;
     const u32x4* lw2_0 = ldsv + (L::F_W2 - L::LDS_F0) + lane;
-    const u32x4* w0 = (MODE == MODE_SYNTH ? gfr + L::F_W0 : ldsv + (L::F_W0 - L::LDS_F0)) + lane;
+    const u32x4* w0 = (L::SYN ? gfr + L::F_W0 : ldsv + (L::F_W0 - L::LDS_F0)) + lane;
 
     const long Q = (long)a.HH * a.WW;
     const long HWl = (long)a.H * a.W;
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
         }
     };
     auto gather = [&](f32x16 (&acc)[TP][2], const Tile& T) {
-        const int ilr = (MODE == MODE_FLOW || MODE == MODE_SYNTH) ? T.img / a.N : T.img;
+        const int ilr = (MODE == MODE_FLOW || L::SYN) ? T.img / a.N : T.img;
 #pragma unroll
         for (int p = 0; p < TP; ++p) {
             const float* gp = a.src_lr + (long)ilr * 64 * HWl + T.lr[p] + (long)(4 * hf) * HWl;
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
     f32x16 acc0[TP][2];
     if (work < utotal) {
         locate(work, cur);
-        if constexpr (MODE != MODE_SYNTH) gather(acc0, cur);
+        if constexpr (!L::SYN) gather(acc0, cur);
     }
     for (; work < utotal; work += stride) {
         // LDS contents never change after the staging barrier, so the compiler would hoist bias / head-weight reads out
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
         const bool has_next = work + stride < utotal;
         PH(0);                                               // tile bookkeeping
         // ------------------------------------------------ layer 0: the LR partial (gathered ahead) seeds the accumulator
-        if constexpr (MODE == MODE_SYNTH) gather(acc0, cur);    // synth: no spare registers to carry it across the tile
+        if constexpr (L::SYN) gather(acc0, cur);    // synth: no spare registers to carry it across the tile
         if constexpr (MODE == MODE_IMNET || MODE == MODE_FLOW) {
             // natural K order: imnet k0 = rel_y, k1 = rel_x; flow k0 = t, k1 = rel_y, k2 = rel_x (lower half-wave)
             u32x4 x[TP][3];
@@ -366,6 +367,36 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
                 else { v[0] = a.rel_y[Y[p]]; v[1] = a.rel_x[X[p]]; }
                 if (hf) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; }
                 split8(v, x[p]);
+            }
+            split_step<2, 2, TP>(x, acc0, w0, 0);
+        } else if constexpr (MODE == MODE_SYNTHC) {
+            // pre-contracted first layer (splat.hip, PRE form): the accumulator already holds W0[:, 0:130] . (splat sums), so
+            // the pre-activation is  LR partial + sums / warped_z + W0[:, 130:133] . extra + W0[:, 197] t  -- 32 plane loads in
+            // C/D order and ONE k-step (natural K order: 0 zmax, 1 cnt/16, 2 wz_/cnt_, 3 t) instead of nine.
+            const float tval = a.times[img];
+            u32x4 x[TP][3];
+#pragma unroll
+            for (int p = 0; p < TP; ++p) {
+                const float* A = a.acc + (long)img * 67 * Q + (cur.valid[p] ? cur.pp[p] : (int)Q - 1);
+                float wz = A[64 * Q];
+                const float zmax = A[65 * Q], cnt = A[66 * Q];
+                const float* ap = A + (long)(4 * hf) * Q;
+                float sv[2][16];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sv[t][r] = ap[(long)(32 * t + (r & 3) + 8 * (r >> 2)) * Q];
+                if (wz == 0.f) wz = 1.0f;                                 // Ours.py:813
+                const float cnt_ = (cnt == 0.f) ? 1.0f : cnt;             // Ours.py:828
+                const float wz_ = (wz == 1.0f) ? 0.f : wz;                // Ours.py:830
+                const float iw = 1.0f / wz;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc0[p][t][r] = fmaf(sv[t][r], iw, acc0[p][t][r]);
+                float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (!hf) { d[0] = zmax; d[1] = cnt / 16.0f; d[2] = wz_ / cnt_; d[3] = tval; }
+                split8(d, x[p]);
             }
             split_step<2, 2, TP>(x, acc0, w0, 0);
         } else {
@@ -447,12 +478,12 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
             f32x16 acc1[TP][2];
             init_bias_s(acc1, ldsf + L::O_B1, hf);
             fused_layer<2, TP, false>(acc0, acc1, lw1, 0, h2);
-            if constexpr (MODE != MODE_SYNTH) {
+            if constexpr (!L::SYN) {
                 if (has_next) { locate(work + stride, nxt); gather(acc0, nxt); }
             }
             PH(3);
             f32x16 acc2[2][TP][2];
-            if constexpr (MODE == MODE_SYNTH) {
+            if constexpr (L::SYN) {
                 init_bias_s(acc0, ldsf + L::O_B1B, hf);                   // acc0 is free: reuse as the 1b accumulator
                 fused_layer<2, TP, false>(acc1, acc0, lw1b, 0, h2);
                 init_bias_s(acc2[0], ldsf + L::O_B2, hf);
@@ -612,7 +643,7 @@ template <int MODE>
 __device__ void siren_split_pack_elem(const SplitPackArgs& pa, unsigned short* frags, float* floats, long i) {
     using L = SLayout<MODE>;
     constexpr int K0 = Net<MODE>::K0;
-    constexpr int NL = (MODE == MODE_SYNTH) ? 5 : 4;                // linear layers incl. the head
+    constexpr int NL = L::SYN ? 5 : 4;                              // linear layers incl. the head
     const long nfrag16 = L::F_END * 8;                              // bf16 elements in the fragment section
     if (i < nfrag16) {
         const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
@@ -632,7 +663,8 @@ __device__ void siren_split_pack_elem(const SplitPackArgs& pa, unsigned short* f
             const int kn = 16 * ks + 8 * hfl + e;                   // natural order of the non-LR inputs
             if (MODE == MODE_IMNET) k = kn < 2 ? 64 + kn : -1;
             else if (MODE == MODE_FLOW) k = kn < 3 ? 64 + kn : -1;
-            else k = kn < 133 ? kn : (kn == 133 ? 197 : -1);
+            else if (MODE == MODE_SYNTH) k = kn < 133 ? kn : (kn == 133 ? 197 : -1);
+            else k = kn < 3 ? 130 + kn : (kn == 3 ? 197 : -1);           // SYNTHC: extra(3) | t
         } else {
             const int tt = ks >> 1, u = ks & 1;                     // chained order
             k = 32 * tt + (e & 3) + 8 * (2 * u + (e >> 2)) + 4 * hfl;
@@ -677,20 +709,23 @@ __global__ void siren_split_pack_kernel(SplitPackArgs pa, float* out, long total
     if (i >= total) return;
     if (pa.mode == MODE_IMNET) siren_split_pack_elem<MODE_IMNET>(pa, (unsigned short*)out, out + SLayout<MODE_IMNET>::F_END * 4, i);
     else if (pa.mode == MODE_FLOW) siren_split_pack_elem<MODE_FLOW>(pa, (unsigned short*)out, out + SLayout<MODE_FLOW>::F_END * 4, i);
-    else siren_split_pack_elem<MODE_SYNTH>(pa, (unsigned short*)out, out + SLayout<MODE_SYNTH>::F_END * 4, i);
+    else if (pa.mode == MODE_SYNTH) siren_split_pack_elem<MODE_SYNTH>(pa, (unsigned short*)out, out + SLayout<MODE_SYNTH>::F_END * 4, i);
+    else siren_split_pack_elem<MODE_SYNTHC>(pa, (unsigned short*)out, out + SLayout<MODE_SYNTHC>::F_END * 4, i);
 }
 
 extern "C" long motif_siren_pack_split(int mode, const float* const* w, const float* const* b, float* packed, void* stream) {
-    if (mode < 0 || mode > 2) return MOTIF_EINVAL;
+    if (mode < 0 || mode > 3) return MOTIF_EINVAL;
     const long floats = mode == MODE_IMNET ? SLayout<MODE_IMNET>::TOTAL_FLOATS
-                      : mode == MODE_FLOW ? SLayout<MODE_FLOW>::TOTAL_FLOATS : SLayout<MODE_SYNTH>::TOTAL_FLOATS;
+                      : mode == MODE_FLOW ? SLayout<MODE_FLOW>::TOTAL_FLOATS
+                      : mode == MODE_SYNTH ? SLayout<MODE_SYNTH>::TOTAL_FLOATS : SLayout<MODE_SYNTHC>::TOTAL_FLOATS;
     if (!packed) return floats;
     if (!w || !b) return MOTIF_EINVAL;
-    const int nl = mode == MODE_SYNTH ? 5 : 4;
+    const int nl = mode >= MODE_SYNTH ? 5 : 4;
     SplitPackArgs pa;
     for (int l = 0; l < 5; ++l) { pa.w[l] = l < nl ? w[l] : nullptr; pa.b[l] = l < nl ? b[l] : nullptr; }
     pa.mode = mode;
-    const long fend = mode == MODE_IMNET ? SLayout<MODE_IMNET>::F_END : mode == MODE_FLOW ? SLayout<MODE_FLOW>::F_END : SLayout<MODE_SYNTH>::F_END;
+    const long fend = mode == MODE_IMNET ? SLayout<MODE_IMNET>::F_END : mode == MODE_FLOW ? SLayout<MODE_FLOW>::F_END
+                    : mode == MODE_SYNTH ? SLayout<MODE_SYNTH>::F_END : SLayout<MODE_SYNTHC>::F_END;
     const long nfl = floats - fend * 4;
     const long total = fend * 8 + nfl;                              // one thread per bf16 element, then per float
     siren_split_pack_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(pa, packed, total);
@@ -722,5 +757,6 @@ static int launch_siren_split(const SirenArgs& a_in, void* stream) {
 int motif_siren_split_launch(int mode, const SirenArgs& a, void* stream) {
     if (mode == MODE_IMNET) return launch_siren_split<MODE_IMNET, 1>(a, stream);
     if (mode == MODE_FLOW) return launch_siren_split<MODE_FLOW, 1>(a, stream);
+    if (mode == MODE_SYNTHC) return launch_siren_split<MODE_SYNTHC, 1>(a, stream);
     return launch_siren_split<MODE_SYNTH, 1>(a, stream);
 }

@@ -136,6 +136,7 @@ extern "C" int motif_splat_fwd(const float* src, const float* flow, const float*
 
 struct MotifSplatArgs {
     const float* imnet_out; const float* pred; const float* feat_lr;
+    const float* ab;      // PRE form: [2][64] = columns 64 and 65 of synth_net's first layer (the raw-flow channels)
     const int32_t* iy; const int32_t* ix; const float* alpha;
     float s20, sr; float* acc;
     int B, N, H, W, HH, WW, R;
@@ -195,6 +196,13 @@ __device__ __forceinline__ int cell_exponent(unsigned bits) {
     return bits ? (int)(bits >> 23) - 127 : 0;
 }
 
+// PRE = false: the 130 source planes of Ours.py:786-791 -> acc [.,133,Q].
+// PRE = true : the splat is linear in its sources and synth_net's first layer is linear in the normalised splat
+//   (Ours.py:811-814, 839-856), so the 130 planes are contracted with W0[:, 0:130] BEFORE the splat: a source carries
+//   the 64 values  U[c] + G[c] + A[c]*p0 + B[c]*p1  with  U = (W0[:, 0:64] . imnet head) (HR, folded into the imnet
+//   kernel's head weights),  G = W0[:, 66:130] . feat_low (a 1x1 convolution at LR, gathered here),  A, B = W0[:, 64],
+//   W0[:, 65].  Half the planes to accumulate, write and re-read: acc [.,67,Q] = 64 sums | norm | max | count.
+template <bool PRE>
 __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs a, int cap) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned long long* tile = (unsigned long long*)lds;            // [OT_CC][OT_TP] 32.32 fixed point
@@ -259,11 +267,12 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
     __syncthreads();
     for (int i = tid; i < OT_TP; i += OT_THREADS) texp[i] = cell_exponent(tmaxb[i]);
 
-    // ---- pass 2: 128 feature planes in 16 chunks of 8, then [128, 129, norm | max | count]
-    float* abase = a.acc + (long)bn * 133 * Q;
-    for (int k = 0; k < 17; ++k) {
-        const bool last = (k == 16);
-        const int n64 = (last ? 3 : OT_CC) * OT_TP;
+    // ---- pass 2: the feature planes in chunks of 8, then [remaining features, norm | max | count]
+    constexpr int NPL = PRE ? 64 : 130, NCH = NPL / OT_CC, NREM = NPL - NCH * OT_CC;    // 130 = 16*8 + 2, 64 = 8*8 + 0
+    float* abase = a.acc + (long)bn * (NPL + 3) * Q;
+    for (int k = 0; k <= NCH; ++k) {
+        const bool last = (k == NCH);
+        const int n64 = (last ? NREM + 1 : OT_CC) * OT_TP;
         for (int i = tid; i < n64; i += OT_THREADS) tile[i] = 0ull;
         __syncthreads();
         for (int e = tid; e < cnt; e += OT_THREADS) {
@@ -283,10 +292,15 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
 #pragma unroll
                 for (int cc = 0; cc < OT_CC; ++cc) {
                     const int c = k * OT_CC + cc;
-                    if (c < 64) v[cc] = a.imnet_out[((long)db * 64 + c) * Q + p];
-                    else if (c == 64) v[cc] = g.p0;
-                    else if (c == 65) v[cc] = g.p1;
-                    else v[cc] = a.feat_lr[((long)db * 64 + (c - 66)) * HWl + lr];
+                    if constexpr (PRE) {
+                        const float u = a.imnet_out[((long)db * 64 + c) * Q + p] + a.feat_lr[((long)db * 64 + c) * HWl + lr];
+                        v[cc] = fmaf(a.ab[64 + c], g.p1, fmaf(a.ab[c], g.p0, u));
+                    } else {
+                        if (c < 64) v[cc] = a.imnet_out[((long)db * 64 + c) * Q + p];
+                        else if (c == 64) v[cc] = g.p0;
+                        else if (c == 65) v[cc] = g.p1;
+                        else v[cc] = a.feat_lr[((long)db * 64 + (c - 66)) * HWl + lr];
+                    }
                 }
 #pragma unroll
                 for (int cc = 0; cc < OT_CC; ++cc) {
@@ -299,8 +313,8 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
                 }
             } else {
 #pragma unroll
-                for (int cc = 0; cc < 3; ++cc) {
-                    const float ve = (cc < 2) ? a.feat_lr[((long)db * 64 + 62 + cc) * HWl + lr] * g.e : g.e;
+                for (int cc = 0; cc < NREM + 1; ++cc) {
+                    const float ve = (cc < NREM) ? a.feat_lr[((long)db * 64 + 62 + cc) * HWl + lr] * g.e : g.e;
                     unsigned long long* tc = tile + cc * OT_TP + off;
                     add_fix(tc, ve * wnw);
                     add_fix(tc + 1, ve * wne);
@@ -310,18 +324,18 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
             }
         }
         __syncthreads();
-        const int nplanes = last ? 5 : OT_CC;
+        const int nplanes = last ? NREM + 3 : OT_CC;
         for (int i = tid; i < nplanes * OT_H * OT_W; i += OT_THREADS) {
             const int cc = i >> 10, rem = i & 1023, ly = rem >> 6, lx = rem & 63;
             const int Y = ty0 + ly, X = tx0 + lx;
             if (Y >= a.HH || X >= a.WW) continue;
             const int cell = (ly + 1) * OT_TPW + lx + 1;
             float v;
-            if (!last || cc < 3) v = fix_to_float(tile[cc * OT_TP + cell], texp[cell]);
-            else if (cc == 3) v = fmaxf(1.0f, __uint_as_float(tmaxb[cell]));     // max-splat output starts at ones (softsplat_max_cp.py:254)
+            if (!last || cc < NREM + 1) v = fix_to_float(tile[cc * OT_TP + cell], texp[cell]);
+            else if (cc == NREM + 1) v = fmaxf(1.0f, __uint_as_float(tmaxb[cell]));     // max-splat output starts at ones (softsplat_max_cp.py:254)
             else v = (float)tcnt[cell];
             float* o = abase + (long)(k * OT_CC + cc) * Q + (long)Y * a.WW + X;
-            if (a.accumulate) v = (last && cc == 3) ? fmaxf(*o, v) : *o + v;
+            if (a.accumulate) v = (last && cc == NREM + 1) ? fmaxf(*o, v) : *o + v;
             *o = v;
         }
         __syncthreads();
@@ -329,6 +343,7 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
 }
 
 // far sources (footprint outside their own +-R neighbourhood): rare; global atomics, after the owner pass
+template <bool PRE>
 __global__ __launch_bounds__(256) void splat_far_kernel(MotifSplatArgs a, int tiles_x) {
     const int img = blockIdx.z;
     const int n = img % a.N, db = img / a.N, b = db % a.B;
@@ -349,19 +364,41 @@ __global__ __launch_bounds__(256) void splat_far_kernel(MotifSplatArgs a, int ti
     Corners cn = corners_of(X, Y + a.row0, fx, fy);
     cn.y0 -= a.row0;
     s.init(cn, a.HH, a.WW);
-    float* abase = a.acc + (long)(b * a.N + n) * 133 * Q;
+    constexpr int NPL = PRE ? 64 : 130;
+    float* abase = a.acc + (long)(b * a.N + n) * (NPL + 3) * Q;
     const long lr = (long)a.iy[Y] * a.W + a.ix[X];
-    for (int c = 0; c < 130; ++c) {
+    for (int c = 0; c < NPL; ++c) {
         float v;
-        if (c < 64) v = a.imnet_out[((long)db * 64 + c) * Q + p];
-        else if (c == 64) v = p0;
-        else if (c == 65) v = p1;
-        else v = a.feat_lr[((long)db * 64 + (c - 66)) * HWl + lr];
+        if constexpr (PRE) {
+            const float u = a.imnet_out[((long)db * 64 + c) * Q + p] + a.feat_lr[((long)db * 64 + c) * HWl + lr];
+            v = fmaf(a.ab[64 + c], p1, fmaf(a.ab[c], p0, u));
+        } else {
+            if (c < 64) v = a.imnet_out[((long)db * 64 + c) * Q + p];
+            else if (c == 64) v = p0;
+            else if (c == 65) v = p1;
+            else v = a.feat_lr[((long)db * 64 + (c - 66)) * HWl + lr];
+        }
         s.add(abase + (long)c * Q, v * e);
     }
-    s.add(abase + 130L * Q, e);
-    s.max(abase + 131L * Q, e);
-    s.count(abase + 132L * Q, 1.0f);
+    s.add(abase + (long)NPL * Q, e);
+    s.max(abase + (long)(NPL + 1) * Q, e);
+    s.count(abase + (long)(NPL + 2) * Q, 1.0f);
+}
+
+template <bool PRE>
+static int launch_motif_splat(MotifSplatArgs a, void* stream) {
+    const int cap = 2 * (OT_H + 2 * a.R) * (OT_W + 2 * a.R);
+    const size_t lds = (size_t)OT_CC * OT_TP * 8 + (size_t)3 * OT_TP * 4 + (size_t)cap * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)splat_owner_kernel<PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((a.WW + OT_W - 1) / OT_W, (a.HH + OT_H - 1) / OT_H, a.B * a.N);
+    splat_owner_kernel<PRE><<<grid, OT_THREADS, lds, (hipStream_t)stream>>>(a, cap);
+    MOTIF_LAUNCH_CHECK();
+    const int tiles_x = (a.WW + 63) / 64, tiles_y = (a.HH + 3) / 4;
+    dim3 grid2(tiles_x * tiles_y, 1, 2 * a.B * a.N);
+    splat_far_kernel<PRE><<<grid2, 256, 0, (hipStream_t)stream>>>(a, tiles_x);
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
 }
 
 extern "C" int motif_splat_motif_acc_fwd(const float* imnet_out, const float* pred, const float* feat_lr,
@@ -369,19 +406,17 @@ extern "C" int motif_splat_motif_acc_fwd(const float* imnet_out, const float* pr
                                          float* acc, int B, int N, int H, int W, int HH, int WW, int row0, int accumulate, void* stream) {
     if (!imnet_out || !pred || !feat_lr || !iy || !ix || !alpha || !acc) return MOTIF_EINVAL;
     if (B < 1 || N < 1 || H < 1 || W < 1 || HH < 1 || WW < 1 || row0 < 0) return MOTIF_EINVAL;
-    MotifSplatArgs a{imnet_out, pred, feat_lr, iy, ix, alpha, 20.0f, flow_scale, acc, B, N, H, W, HH, WW, 16, row0, accumulate ? 1 : 0};
-    const int cap = 2 * (OT_H + 2 * a.R) * (OT_W + 2 * a.R);
-    const size_t lds = (size_t)OT_CC * OT_TP * 8 + (size_t)3 * OT_TP * 4 + (size_t)cap * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)splat_owner_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    dim3 grid((WW + OT_W - 1) / OT_W, (HH + OT_H - 1) / OT_H, B * N);
-    splat_owner_kernel<<<grid, OT_THREADS, lds, (hipStream_t)stream>>>(a, cap);
-    MOTIF_LAUNCH_CHECK();
-    const int tiles_x = (WW + 63) / 64, tiles_y = (HH + 3) / 4;
-    dim3 grid2(tiles_x * tiles_y, 1, 2 * B * N);
-    splat_far_kernel<<<grid2, 256, 0, (hipStream_t)stream>>>(a, tiles_x);
-    MOTIF_LAUNCH_CHECK();
-    return MOTIF_OK;
+    MotifSplatArgs a{imnet_out, pred, feat_lr, nullptr, iy, ix, alpha, 20.0f, flow_scale, acc, B, N, H, W, HH, WW, 16, row0, accumulate ? 1 : 0};
+    return launch_motif_splat<false>(a, stream);
+}
+
+extern "C" int motif_splat_motif_pre_fwd(const float* u_hr, const float* pred, const float* g_lr, const float* ab,
+                                         const int32_t* iy, const int32_t* ix, const float* alpha, float flow_scale,
+                                         float* acc, int B, int N, int H, int W, int HH, int WW, int row0, int accumulate, void* stream) {
+    if (!u_hr || !pred || !g_lr || !ab || !iy || !ix || !alpha || !acc) return MOTIF_EINVAL;
+    if (B < 1 || N < 1 || H < 1 || W < 1 || HH < 1 || WW < 1 || row0 < 0) return MOTIF_EINVAL;
+    MotifSplatArgs a{u_hr, pred, g_lr, ab, iy, ix, alpha, 20.0f, flow_scale, acc, B, N, H, W, HH, WW, 16, row0, accumulate ? 1 : 0};
+    return launch_motif_splat<true>(a, stream);
 }
 
 extern "C" int motif_splat_motif_fwd(const float* imnet_out, const float* pred, const float* feat_lr,

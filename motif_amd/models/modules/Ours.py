@@ -313,6 +313,11 @@ def gather_tables(H, W, HH, WW, device):
     return t
 
 
+def HH_over_H(c, H):
+    """flow_scale of the splat = HH / H of the WHOLE image (a row band has fewer rows but the same scale)."""
+    return c["scale_y"]
+
+
 class LunaTokis(nn.Module):
     """`Ours.LunaTokis(setting=5)`.  The 4-frame generators (`Ours_4.py`, `Ours_44.py` next to this file) subclass it: they
     differ in the t-independent motion stage (`_motion_stage`), in which frames are encoded (`_encode`) and in the
@@ -346,6 +351,9 @@ class LunaTokis(nn.Module):
         self.shuffle = Conv2d(channel, channel, 1, 1, 0)
         self.skip_zero_pairs = True
         self.overlap_raft = True
+        # contract synth_net's first layer into the splat sources (splat.hip PRE form; bf16x3 engine only): the accumulator
+        # shrinks from 133 to 67 planes.  False keeps the literal 130-plane splat (the form the `synth_in` golden pins).
+        self.precontract = True
         # spatial tiling of the HR half (BASELINE config 5): render HR rows [r0, r1) only; the
         # band is extended by `band_halo` rows on each side, everything HR is recomputed there (nothing is exchanged)
         self.band = None
@@ -403,6 +411,55 @@ class LunaTokis(nn.Module):
     def _residual(self, c, target_t):
         return c["feat"][:, 1]                                                  # Ours.py:609
 
+    def _pc(self):
+        return self.precontract and ops.get_siren_mma() == ops.MMA_BF16X3
+
+    def _pre_plan(self):
+        """Weights of the pre-contracted form, rebuilt when a parameter they derive from changes: with W0 = synth_net's
+        first layer [64,198] (inputs: 0..63 splatted imnet output, 64..65 raw predicted flow, 66..129 splatted low-res
+        feature, 130..132 extra, 133..196 residual, 197 t -- Ours.py:786-791, 839-844):
+          imnet_blob  imnet with its linear head composed with W0[:, 0:64]  (head' = W0a.Wh, bias' = W0a.bh, in fp64)
+          g_plan      1x1 convolution W0[:, 66:130] applied to the LR encoder feature
+          ab          [2,64] = W0[:, 64], W0[:, 65]
+          synth_blob  synth_net packed for motif_siren_synth_pre_fwd (first layer = the 3 extra columns + t)."""
+        w0 = self.synth_net.net[0].linear.weight
+        wh, bh = self.imnet.net[3].weight, self.imnet.net[3].bias
+        key = tuple((t.data_ptr(), t._version) for t in [w0, wh, bh] + [t for wb in self.imnet.linears() + self.synth_net.linears() for t in wb])
+        if getattr(self, "_pre_key", None) != key:
+            W0 = w0.detach().double()
+            whc = (W0[:, :64] @ wh.detach().double()).float().contiguous()
+            bhc = (W0[:, :64] @ bh.detach().double()).float().contiguous()
+            self._pre = dict(
+                imnet_blob=ops.siren_pack_split(ops.SIREN_IMNET, self.imnet.linears()[:-1] + [(whc, bhc)]),
+                g_plan=ops.ConvPlan(w0.detach()[:, 66:130].contiguous().view(64, 64, 1, 1), None),
+                ab=torch.stack([w0.detach()[:, 64], w0.detach()[:, 65]]).contiguous(),
+                synth_blob=ops.siren_pack_split(ops.SIREN_SYNTH_PRE, self.synth_net.linears()))
+            self._pre_key = key
+        return self._pre
+
+    def _imnet_hr(self, c, iy, ix, rel_y, rel_x, HH, WW):
+        """imnet over the HR grid described by the tables (whole image or a row band); in the pre-contracted form its head
+        already carries W0[:, 0:64]."""
+        split = ops.get_siren_mma() == ops.MMA_BF16X3
+        if self._pc():
+            blob = self._pre_plan()["imnet_blob"]
+        else:
+            blob = self.imnet.packed_split(ops.SIREN_IMNET) if split else self.imnet.packed()
+        return ops.siren_imnet(blob, ops.conv2d(self.imnet.l0_plan(0, 64), c["feat01"]), iy, ix, rel_y, rel_x, HH, WW, pre=2 if split else 1)
+
+    def _splat_synth(self, c, imnet_out, pred, sl, iy, ix, times, B, N, H, HH, WW, synth_blob, synth_l0, pre, acc, accumulate, row0=0, finish=True):
+        """fused splat of one direction pair (+ synth_net when `finish`); -> acc, frames"""
+        if self._pc():
+            pp = self._pre_plan()
+            acc = ops.splat_motif_pre(imnet_out, pred, c["g_lr"][sl], pp["ab"], iy, ix, self.alpha, HH_over_H(c, H), B, N, HH, WW,
+                                      acc=acc, row0=row0, accumulate=accumulate)
+            frames = ops.siren_synth_pre(pp["synth_blob"], acc, synth_l0, iy, ix, times, B, N, HH, WW) if finish else None
+        else:
+            acc = ops.splat_motif(imnet_out, pred, c["feat01"][sl], iy, ix, self.alpha, HH_over_H(c, H), B, N, HH, WW,
+                                  acc=acc, row0=row0, accumulate=accumulate)
+            frames = ops.siren_synth(synth_blob, acc, synth_l0, iy, ix, times, B, N, HH, WW, pre=pre) if finish else None
+        return acc, frames
+
     def _clip_stage(self, x, HH, WW, iters):
         """Everything of `Ours.py:514-638` + the `imnet` branch of 699-737 that does not depend on t."""
         B, H, W = x.shape[0], x.shape[3], x.shape[4]
@@ -424,14 +481,13 @@ class LunaTokis(nn.Module):
         iy, ix, rel_y, rel_x = gather_tables(H, W, HH, WW, x.device)
         # the gathered-LR-feature part of each MLP's first layer does not depend on the HR pixel or on t:
         # evaluate it once per clip at LR resolution (1x1 convs), the HR kernels start from it (pre=1)
-        split = ops.get_siren_mma() == ops.MMA_BF16X3
-        imnet_out = None                                                        # band mode renders it per band
-        if self.band is None:
-            imnet_out = ops.siren_imnet(self.imnet.packed_split(ops.SIREN_IMNET) if split else self.imnet.packed(),
-                                        ops.conv2d(self.imnet.l0_plan(0, 64), feat_src), iy, ix, rel_y, rel_x, HH, WW, pre=2 if split else 1)
         flow_l0 = ops.conv2d(self.flow_imnet.l0_plan(0, 64), flow_feat)
         c = dict(flow_l0=flow_l0, flow=flow, psies=psies, flow_feat_in=flow_feat_in, feat=feat, feat01=feat_src,
-                 flow_feat=flow_feat, imnet_out=imnet_out, tables=(iy, ix, rel_y, rel_x))
+                 flow_feat=flow_feat, imnet_out=None, tables=(iy, ix, rel_y, rel_x), scale_y=HH / H)
+        if self._pc():
+            c["g_lr"] = ops.conv2d(self._pre_plan()["g_plan"], feat_src)
+        if self.band is None:                                                   # band mode renders imnet per band
+            c["imnet_out"] = self._imnet_hr(c, iy, ix, rel_y, rel_x, HH, WW)
         if self.D == 2:                                                         # Ours_44 picks the residual feature by t
             c["residual"] = self._residual(c, None).contiguous()
             c["synth_l0"] = ops.conv2d(self.synth_net.l0_plan(133, 197), c["residual"])
@@ -453,14 +509,17 @@ class LunaTokis(nn.Module):
         so the address cannot be recycled), the output size, the RAFT iteration count, band / untiled mode, the
         arithmetic engines and the weights epoch."""
         return (x.data_ptr(), x._version, tuple(x.shape), HH, WW, iters, self.band is None,
-                ops.get_conv_mma(), ops.get_siren_mma(), self._weights_epoch)
+                ops.get_conv_mma(), ops.get_siren_mma(), self._weights_epoch, self.precontract)
 
     # ---- t-independent stage as a transferable object (motif_amd.dist.render_clip_by_timestamps, share="broadcast")
-    CLIP_CACHE_TENSORS = ("flow_l0", "synth_l0", "feat01", "imnet_out")
+    def clip_cache_names(self):
+        return ("flow_l0", "synth_l0", "g_lr" if self._pc() else "feat01", "imnet_out")
 
     def clip_cache_shapes(self, x, HH, WW):
         B, H, W = x.shape[0], x.shape[3], x.shape[4]
-        return {"flow_l0": (2 * B, 64, H, W), "synth_l0": (B, 64, H, W), "feat01": (2 * B, 64, H, W), "imnet_out": (2 * B, 64, HH, WW)}
+        shp = {"flow_l0": (2 * B, 64, H, W), "synth_l0": (B, 64, H, W), "feat01": (2 * B, 64, H, W), "g_lr": (2 * B, 64, H, W),
+               "imnet_out": (2 * B, 64, HH, WW)}
+        return {k: shp[k] for k in self.clip_cache_names()}
 
     def export_clip_cache(self, x, HH, WW, iters):
         """Run (or reuse) the t-independent stage for clip `x` and return the tensors the t-dependent half reads."""
@@ -470,18 +529,19 @@ class LunaTokis(nn.Module):
         if key != self._cache_key:
             self._cache, self._cache_key = self._clip_stage(x.float(), HH, WW, iters), key
             self._cache["x"] = x
-        return {k: self._cache[k] for k in self.CLIP_CACHE_TENSORS}
+        return {k: self._cache[k] for k in self.clip_cache_names()}
 
     def import_clip_cache(self, x, HH, WW, iters, tensors):
         """Install a t-independent stage computed elsewhere (another rank) for clip `x`: later forward calls with the same
         clip / size / iters render timestamps from it without running RAFT, the encoder or imnet."""
         B, H, W = x.shape[0], x.shape[3], x.shape[4]
         shapes = self.clip_cache_shapes(x, HH, WW)
-        for k in self.CLIP_CACHE_TENSORS:
+        for k in self.clip_cache_names():
             if tuple(tensors[k].shape) != shapes[k]:
                 raise ValueError("clip cache tensor %s has shape %s, expected %s" % (k, tuple(tensors[k].shape), shapes[k]))
-        c = {k: tensors[k] for k in self.CLIP_CACHE_TENSORS}
+        c = {k: tensors[k] for k in self.clip_cache_names()}
         c["tables"] = gather_tables(H, W, HH, WW, x.device)
+        c["scale_y"] = HH / H
         c["x"] = x
         self._cache, self._cache_key = c, self._clip_key(x, HH, WW, iters)
 
@@ -501,12 +561,10 @@ class LunaTokis(nn.Module):
         iyb, ryb, HHb = iy[e0:e1].contiguous(), rel_y[e0:e1].contiguous(), e1 - e0
         bkey = ("imnet_band", e0, e1)
         if bkey not in c:                                                       # t-independent, cached per band
-            split = pre == 2
-            c[bkey] = ops.siren_imnet(self.imnet.packed_split(ops.SIREN_IMNET) if split else self.imnet.packed(),
-                                      ops.conv2d(self.imnet.l0_plan(0, 64), c["feat01"]), iyb, ix, ryb, rel_x, HHb, WW, pre=pre)
+            c[bkey] = self._imnet_hr(c, iyb, ix, ryb, rel_x, HHb, WW)
         pred = ops.siren_flow(flow_blob, c["flow_l0"], iyb, ix, ryb, rel_x, times, N, HHb, WW, pre=pre)
-        acc = ops.splat_motif(c[bkey], pred, c["feat01"], iyb, ix, self.alpha, HH / H, B, N, HHb, WW, row0=e0)
-        frames = ops.siren_synth(synth_blob, acc, c["synth_l0"], iyb, ix, times, B, N, HHb, WW, pre=pre)
+        acc, frames = self._splat_synth(c, c[bkey], pred, slice(0, 2 * B), iyb, ix, times, B, N, H, HHb, WW, synth_blob, c["synth_l0"],
+                                        pre, None, False, row0=e0)
         lo, hi = r0 - e0, r1 - e0
         flow_hr = pred[:, :2, lo:hi]
         self.last_max_flow_y = (flow_hr[:, 1].abs().max() * 20.0 * (HH / H)).detach()
@@ -545,15 +603,15 @@ class LunaTokis(nn.Module):
         if self.band is not None:
             return self._forward_band(c, times, B, N, H, HH, WW, flow_blob, synth_blob, pre, stages)
         # source directions two at a time (the kernels take a direction pair); further pairs add into the accumulator
-        preds, acc = [], None
+        preds, acc, frames = [], None, None
+        synth_l0 = self._synth_l0(c, target_t)
         for d0 in range(0, self.D, 2):
             sl = slice(d0 * B, (d0 + 2) * B)
             pred = ops.siren_flow(flow_blob, c["flow_l0"][sl], iy, ix, rel_y, rel_x, times, N, HH, WW, pre=pre)   # [2BN,3,HH,WW]
-            acc = ops.splat_motif(c["imnet_out"][sl], pred, c["feat01"][sl], iy, ix, self.alpha, HH / H, B, N, HH, WW,
-                                  acc=acc, accumulate=d0 > 0)
+            acc, frames = self._splat_synth(c, c["imnet_out"][sl], pred, sl, iy, ix, times, B, N, H, HH, WW, synth_blob, synth_l0, pre,
+                                            acc, d0 > 0, finish=d0 + 2 >= self.D)
             preds.append(pred)
         pred = preds[0] if len(preds) == 1 else torch.cat(preds, 0)              # [D*B*N,3,HH,WW]
-        frames = ops.siren_synth(synth_blob, acc, self._synth_l0(c, target_t), iy, ix, times, B, N, HH, WW, pre=pre)
         if stages is not None:
             stages.update(c)
             stages.update(pred=pred, acc=acc)

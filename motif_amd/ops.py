@@ -308,7 +308,7 @@ def siren_pack(linears):
     return blob
 
 
-SIREN_IMNET, SIREN_FLOW, SIREN_SYNTH = 0, 1, 2
+SIREN_IMNET, SIREN_FLOW, SIREN_SYNTH, SIREN_SYNTH_PRE = 0, 1, 2, 3
 _siren_mma = int(os.environ.get("MOTIF_SIREN_MMA", str(MMA_BF16X3 if _default_mma != MMA_FP32 else MMA_FP32)))
 
 
@@ -344,7 +344,8 @@ def siren_pack_split(kind, linears):
     n = len(linears)
     ws = [_c(w.detach()) for w, _ in linears]
     bs = [_c(b.detach()) for _, b in linears]
-    want = {SIREN_IMNET: [66, 64, 64, 256, 64], SIREN_FLOW: [67, 64, 64, 256, 3], SIREN_SYNTH: [198, 64, 64, 64, 256, 3]}[kind]
+    want = {SIREN_IMNET: [66, 64, 64, 256, 64], SIREN_FLOW: [67, 64, 64, 256, 3], SIREN_SYNTH: [198, 64, 64, 64, 256, 3],
+            SIREN_SYNTH_PRE: [198, 64, 64, 64, 256, 3]}[kind]
     if [ws[0].shape[1]] + [w.shape[0] for w in ws] != want:
         raise RuntimeError("siren_pack_split: layer sizes do not match kind %d" % kind)
     wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
@@ -386,6 +387,17 @@ def siren_synth(blob, acc, residual_lr, iy, ix, times, B, N, HH, WW, pre=False):
     frames = torch.empty(N, B, 3, HH, WW, dtype=torch.float32, device=acc.device)
     check(lib.motif_siren_synth_fwd(_p(blob), _p(acc), _p(residual_lr), _p(iy), _p(ix), _p(_c(times)), _p(frames),
                                     B, N, h, w, HH, WW, int(pre), _stream()), "motif_siren_synth_fwd")
+    return frames
+
+
+def siren_synth_pre(blob, acc67, residual_l0, iy, ix, times, B, N, HH, WW):
+    """synth_net on the pre-contracted accumulator of splat_motif_pre (blob: siren_pack_split(SIREN_SYNTH_PRE, ...))."""
+    lib = _lib.load()
+    residual_l0 = _c(residual_l0)
+    _, _, h, w = residual_l0.shape
+    frames = torch.empty(N, B, 3, HH, WW, dtype=torch.float32, device=acc67.device)
+    check(lib.motif_siren_synth_pre_fwd(_p(blob), _p(acc67), _p(residual_l0), _p(iy), _p(ix), _p(_c(times)), _p(frames),
+                                        B, N, h, w, HH, WW, _stream()), "motif_siren_synth_pre_fwd")
     return frames
 
 
@@ -432,6 +444,21 @@ def splat_motif(imnet_out, pred, feat_lr, iy, ix, alpha, flow_scale, B, N, HH, W
     # no zero fill: the owner-computes kernel writes every accumulator cell (max plane starts at 1)
     check(lib.motif_splat_motif_acc_fwd(_p(_c(imnet_out)), _p(_c(pred)), _p(feat_lr), _p(iy), _p(ix), _p(alpha.detach()), float(flow_scale), _p(acc),
                                         B, N, h, w, HH, WW, int(row0), int(bool(accumulate)), _stream()), "motif_splat_motif_acc_fwd")
+    return acc
+
+
+def splat_motif_pre(u_hr, pred, g_lr, ab, iy, ix, alpha, flow_scale, B, N, HH, WW, acc=None, row0=0, accumulate=False):
+    """Pre-contracted fused soft-splat (motif_splat_motif_pre_fwd): acc [B*N,67,HH,WW] = 64 first-layer pre-activation
+    sums | norm | max | count."""
+    lib = _lib.load()
+    g_lr = _c(g_lr)
+    _, _, h, w = g_lr.shape
+    if acc is None:
+        if accumulate:
+            raise RuntimeError("splat_motif_pre(accumulate=True) needs the accumulator of the first call")
+        acc = torch.empty(B * N, 67, HH, WW, dtype=torch.float32, device=pred.device)
+    check(lib.motif_splat_motif_pre_fwd(_p(_c(u_hr)), _p(_c(pred)), _p(g_lr), _p(_c(ab)), _p(iy), _p(ix), _p(alpha.detach()), float(flow_scale),
+                                        _p(acc), B, N, h, w, HH, WW, int(row0), int(bool(accumulate)), _stream()), "motif_splat_motif_pre_fwd")
     return acc
 
 

@@ -572,6 +572,86 @@ def test_splat_motif_keeps_dynamic_range_of_low_reliability_sources():
     close(out[hit_only_tiny.expand_as(out)], out_ref[hit_only_tiny.expand_as(out)], 3e-5, 3e-5, "normalised output, unreliable-only cells")
 
 
+def test_precontracted_splat_and_synth_equal_the_literal_path():
+    """motif_splat_motif_pre_fwd + motif_siren_synth_pre_fwd (synth_net's first layer contracted into the splat sources:
+    Ours.py:811-814 and 839-856 are linear) against the literal composition on the CPU: kernel-text splat of the 130
+    planes -> normalise -> the oracle Siren.  Includes unreliable-only cells, far sources and empty cells; hit count and
+    max planes exact, frames within 2e-5 + 1e-4 rel, two runs bit-identical."""
+    from oracle import native
+    from oracle.motif_ref import Siren as RefSiren
+    from motif_amd import ops
+    from motif_amd.models.modules.SIREN import Siren
+    from motif_amd.utils.synth_weights import fill_state_dict
+    B, N, H, W, s = 1, 2, 12, 20, 4
+    HH, WW = H * s, W * s
+    Q = HH * WW
+    iy, ix, _, _ = _tables(H, W, HH, WW)
+    iyc, ixc = iy.cpu().long(), ix.cpu().long()
+    gather = lambda t: t[:, :, iyc][:, :, :, ixc]
+
+    class Holder(torch.nn.Module):
+        def __init__(self, ref):
+            super().__init__()
+            self.synth_net = RefSiren(198, [64, 64, 64, 256], 3) if ref else Siren(198, [64, 64, 64, 256], 3, 3, True)
+
+    ref, mine = fill_state_dict(Holder(True)), Holder(False)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev())
+    imnet_out = rnd(2 * B, 64, HH, WW, seed=1)
+    feat_lr = rnd(2 * B, 64, H, W, seed=2)
+    res = rnd(B, 64, H, W, seed=7, scale=0.3)
+    pred = rnd(2 * B * N, 3, HH, WW, seed=3, scale=0.05)
+    p2 = torch.rand(2 * B * N, HH, WW, generator=torch.Generator().manual_seed(4)) * 0.2
+    p2[:, 10:20, 20:50] = 2.0                                   # cells reached by unreliable sources only
+    pred[:, 2] = p2
+    pred[:, :2, 24:40, 6:50] = 0.0
+    pred[:, 1, 24:40, 6:50] = 0.11                              # a block that moves 8.8 px down: leaves empty cells behind
+    pred[0, 0, 6, 10], pred[0, 1, 6, 10] = 0.3, 0.2             # one far source
+    alpha = torch.tensor([-20.0])
+    times = torch.tensor([[0.25, 0.75]])
+    flow = pred[:, :2] * 20.0 * (HH / H)
+    ez = (F.relu(pred[:, 2:3]) * alpha).exp()
+    rep = lambda t: t.repeat(1, N, 1, 1).reshape(2 * B * N, -1, HH, WW)
+    feat_all = torch.cat([rep(imnet_out), pred[:, :2], rep(gather(feat_lr))], 1)
+    ssum = native.splat(torch.cat([feat_all * ez, ez], 1), flow, "sum").reshape(2, B * N, 131, HH, WW).sum(0)
+    smax = native.splat(ez, flow, "max").reshape(2, B * N, 1, HH, WW).max(0)[0]
+    scnt = native.splat(torch.ones_like(ez), flow, "count").reshape(2, B * N, 1, HH, WW).sum(0)
+    assert int((scnt == 0).sum()) > 50
+    wz = ssum[:, 130:131].clone()
+    wz[wz == 0] = 1.0
+    cnt_ = scnt.clone()
+    cnt_[cnt_ == 0] = 1.0
+    wz_ = wz.clone()
+    wz_[wz_ == 1.0] = 0.0
+    allin = torch.cat((ssum[:, :130] / wz, smax, scnt / 16.0, wz_ / cnt_, gather(res).repeat(1, N, 1, 1).reshape(B * N, 64, HH, WW),
+                       times.reshape(B * N, 1, 1, 1).repeat(1, 1, HH, WW)), 1)
+    with torch.no_grad():
+        r = ref.synth_net(allin.reshape(B * N, 198, Q).permute(0, 2, 1)).permute(0, 2, 1).reshape(B, N, 3, HH, WW).permute(1, 0, 2, 3, 4).clamp(0, 1)
+    # the device side: W0 split as LunaTokis._pre_plan does it
+    w0 = mine.synth_net.net[0].linear.weight.detach()
+    u_hr = torch.einsum("ck,bkhw->bchw", w0[:, :64].double().cpu(), imnet_out.double()).float()       # stands for the composed imnet head
+    g_lr = ops.conv2d(ops.ConvPlan(w0[:, 66:130].contiguous().view(64, 64, 1, 1), None), feat_lr.to(dev()))
+    ab = torch.stack([w0[:, 64], w0[:, 65]]).contiguous()
+    args = (u_hr.to(dev()), pred.to(dev()), g_lr, ab, iy, ix, alpha.to(dev()), HH / H, B, N, HH, WW)
+    acc = ops.splat_motif_pre(*args)
+    assert acc.shape == (B * N, 67, HH, WW)
+    assert torch.equal(acc, ops.splat_motif_pre(*args)), "run-to-run bit identity"
+    assert torch.equal(acc[:, 66:67].cpu(), scnt), "count plane must be exact"
+    close(acc[:, 65:66], smax, 0, 3e-5, "max plane")
+    relz = ((acc[:, 64:65].cpu() - ssum[:, 130:131]).abs() / ssum[:, 130:131].abs().clamp_min(1e-37)).max()
+    assert float(relz) < 3e-5 and torch.equal(acc[:, 64:65].cpu() == 0, ssum[:, 130:131] == 0)
+    pre_ref = torch.einsum("ck,bkhw->bchw", w0[:, :130].double().cpu(), (ssum[:, :130] / wz).double()).float()
+    close(acc[:, :64].cpu() / wz, pre_ref, 3e-5, 3e-5, "contracted first-layer sums")
+    l0 = ops.conv2d(mine.synth_net.l0_plan(133, 197), res.to(dev()))
+    blob = ops.siren_pack_split(ops.SIREN_SYNTH_PRE, mine.synth_net.linears())
+    o = ops.siren_synth_pre(blob, acc, l0, iy, ix, times.to(dev()), B, N, HH, WW)
+    close(o, r, 2e-5, 1e-4, "synth on the pre-contracted accumulator")
+    # accumulate form: the same two directions added twice == sums doubled, count doubled, max unchanged
+    acc2 = ops.splat_motif_pre(*args, acc=acc.clone(), accumulate=True)
+    assert torch.equal(acc2[:, 66], 2 * acc[:, 66]) and torch.equal(acc2[:, 65], acc[:, 65])
+    close(acc2[:, :65], 2 * acc[:, :65], 1e-30, 1e-6, "accumulate")
+
+
 def test_dcn_fused_multi_vs_kernel_text(engine):
     """Fused DCN (deformable im2col in LDS + MFMA, multi-problem) == the kernel-text restatement, including
     offsets that leave the image, the (-1, 0) border band, and odd image sizes.  engine = bf16x3 runs
