@@ -1,5 +1,6 @@
 // Correlation kernels of the flow extractors (gfx950).
 #include "common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------ RAFT windowed bilinear lookup
 // One wave per query pixel: the 64 lanes are the (2r+2)^2 = 8x8 integer neighbourhood of floor(coords)
@@ -133,10 +134,124 @@ extern "C" int motif_raft_corr_lookup(const float* fmap1, const float* fmap2, co
 }
 
 // ------------------------------------------------------------------ PWC-Net 9x9 cost volume
-// One thread per (displacement, pixel); lanes run along x so f1 and the shifted f2 reads are both
-// coalesced, the 81 displacements of a pixel tile reuse f1/f2 lines through L1/L2.
-__global__ void corr81_kernel(const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ out,
-                              int C, int H, int W, int act) {
+// Two kernels (correlation.py:44-112 runs one 32-thread block per PIXEL with a serial reduce):
+//  * corr81_tiled_kernel, maps of >= 64x96 pixels: LDS-tiled and register-blocked.  A block owns 8 rows x 32 columns of
+//    output pixels.  Channels go by in chunks of 8: the chunk's f2 window (tile + 4 px halo = 16 x 40, zero outside the
+//    image = the reference's zero padding, correlation.py:17-42) is staged in LDS with coalesced row loads.  A thread owns
+//    4 horizontally adjacent pixels and 3 of the 9 vertical displacements (wave g = rows dy 3g..3g+2): per (channel, dy)
+//    it reads the 12 window values its 4 pixels x 9 horizontal displacements need as three aligned ds_read_b128 and does
+//    36 FMAs into 108 register accumulators -- 1 LDS instruction per 12 FMAs; f1 is read from HBM once (as float4s), f2
+//    1.56x (halo) instead of 81 times each through L1/L2.
+//  * corr81_small_kernel, the coarse pyramid levels (a few hundred pixels, up to 196 channels): one thread per
+//    (displacement, pixel) -- there the 81-fold parallelism matters more than the reuse, everything is L2 resident.
+// Channel order of the sum: ascending in both.
+#define C81_TH 8
+#define C81_TW 32
+#define C81_WS (C81_TW + 8)
+#define C81_WH (C81_TH + 8)
+#define C81_CK 8
+#define C81_NT 192
+
+__global__ __launch_bounds__(C81_NT) void corr81_tiled_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                              float* __restrict__ out, int C, int H, int W, int act) {
+    __shared__ __attribute__((aligned(16))) float win[C81_CK][C81_WH * C81_WS];
+    const int tid = threadIdx.x, g = tid >> 6, q = tid & 63, qy = q >> 3, qx = q & 7;
+    const int x0 = blockIdx.x * C81_TW, y0 = blockIdx.y * C81_TH, b = blockIdx.z;
+    const int x = x0 + 4 * qx, y = y0 + qy;                                   // first of this thread's 4 pixels
+    const long HW = (long)H * W;
+    const bool row_ok = y < H;
+    const bool vec = (W & 3) == 0;                                             // block-uniform: float4 global access
+    const float* f1b = f1 + (long)b * C * HW;
+    const float* f2b = f2 + (long)b * C * HW;
+    float acc[3][9][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int d = 0; d < 9; ++d)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][d][j] = 0.f;
+    // software pipeline: the f1 values and the f2 window of chunk c0 + 8 are requested (into registers) before chunk c0 is
+    // multiplied, so HBM / L2 latency hides behind the FMAs even with one block per CU
+    constexpr int NST = (C81_CK * C81_WH * C81_WS + C81_NT - 1) / C81_NT;
+    float st[NST], an[C81_CK][4];
+    auto request = [&](int c0) {
+#pragma unroll
+        for (int c = 0; c < C81_CK; ++c) {
+            const bool cok = row_ok && c0 + c < C;
+            const float* p = f1b + (long)(cok ? c0 + c : 0) * HW + (long)(row_ok ? y : 0) * W;
+            if (vec && cok && x + 3 < W) {
+                const f32x4 v = *(const f32x4*)(p + x);
+                an[c][0] = v[0]; an[c][1] = v[1]; an[c][2] = v[2]; an[c][3] = v[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) an[c][j] = (cok && x + j < W) ? p[x + j] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int e = tid + C81_NT * k;
+            const int c = e / (C81_WH * C81_WS), r = e - c * (C81_WH * C81_WS);
+            const int wy = r / C81_WS, wx = r - wy * C81_WS;
+            const int gy = y0 - 4 + wy, gx = x0 - 4 + wx;
+            const bool okv = e < C81_CK * C81_WH * C81_WS && c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            st[k] = okv ? f2b[(long)(c0 + c) * HW + (long)gy * W + gx] : 0.f;
+        }
+    };
+    request(0);
+    for (int c0 = 0; c0 < C; c0 += C81_CK) {
+        float a[C81_CK][4];
+        __syncthreads();                                   // previous chunk's window fully consumed
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int e = tid + C81_NT * k;
+            if (e < C81_CK * C81_WH * C81_WS) (&win[0][0])[e] = st[k];
+        }
+#pragma unroll
+        for (int c = 0; c < C81_CK; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[c][j] = an[c][j];
+        __syncthreads();
+        if (c0 + C81_CK < C) request(c0 + C81_CK);
+        const float* wp = &win[0][(qy + 3 * g) * C81_WS + 4 * qx];
+#pragma unroll
+        for (int c = 0; c < C81_CK; ++c)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float w[12];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const f32x4 v = *(const f32x4*)(wp + c * (C81_WH * C81_WS) + i * C81_WS + 4 * k);
+                    w[4 * k] = v[0]; w[4 * k + 1] = v[1]; w[4 * k + 2] = v[2]; w[4 * k + 3] = v[3];
+                }
+#pragma unroll
+                for (int d = 0; d < 9; ++d)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][d][j] = fmaf(a[c][j], w[j + d], acc[i][d][j]);
+            }
+    }
+    if (!row_ok || x >= W) return;
+    const float inv = (float)C;
+    float* ob = out + (long)b * 81 * HW + (long)y * W + x;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int d = 0; d < 9; ++d) {
+            float* op = ob + (long)((3 * g + i) * 9 + d) * HW;
+            if (vec && x + 3 < W) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = act_apply(acc[i][d][j] / inv, act);
+                *(f32x4*)op = v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (x + j < W) op[j] = act_apply(acc[i][d][j] / inv, act);
+            }
+        }
+}
+
+__global__ void corr81_small_kernel(const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ out,
+                                    int C, int H, int W, int act) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     const int b = blockIdx.z / 81, d = blockIdx.z % 81;
     if (x >= W) return;
@@ -155,8 +270,15 @@ __global__ void corr81_kernel(const float* __restrict__ f1, const float* __restr
 extern "C" int motif_corr81_fwd(const float* first, const float* second, float* out, int B, int C, int H, int W,
                                 int act, void* stream) {
     if (!first || !second || !out || B < 1 || C < 1) return MOTIF_EINVAL;
-    dim3 grid(cdiv(W, 64), H, B * 81);
-    corr81_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(first, second, out, C, H, W, act);
+    const char* force = getenv("MOTIF_CORR81");              // "tiled" / "small": tests and tools/pwc_bench.py
+    const bool tiled = force ? force[0] == 't' : (long)H * W >= 64L * 96;
+    if (tiled) {
+        dim3 grid(cdiv(W, C81_TW), cdiv(H, C81_TH), B);
+        corr81_tiled_kernel<<<grid, C81_NT, 0, (hipStream_t)stream>>>(first, second, out, C, H, W, act);
+    } else {
+        dim3 grid(cdiv(W, 64), H, B * 81);
+        corr81_small_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(first, second, out, C, H, W, act);
+    }
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

@@ -278,8 +278,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 
     float pre[DF_PAIRS][DF_CH][4];
     constexpr int NWR = (WCH / 4 + NT - 1) / NT;
-    f32x4 wreg[NWR];
-    auto issue = [&](int c0) {                           // corner values of channels c0..c0+3 for my pairs; weight rows
+    static_assert((WCH / 4) % 64 == 0, "a chunk's weights are whole 1 KiB wave pieces");
+    // The chunk's weights go global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16, the
+    // packed chunk is contiguous, so the copy is linear): no staging registers and no ds_write pass.  The staging
+    // registers were what pushed the bf16x3 form past 256 VGPRs into scratch (3 / 11 spilled VGPRs for 8 / 4 waves).
+    auto issue = [&](int c0, int buf) {                  // corner values of channels c0..c0+3 for my pairs; weight rows
 #pragma unroll
         for (int j = 0; j < DF_PAIRS; ++j) {
 #pragma unroll
@@ -291,10 +294,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
             }
         }
         const f32x4* src = (const f32x4*)(SPLIT ? wbase + (long)(c0 / DF_CH) * WCH : wbase + (long)c0 * 9 * WN);   // fp32: rows c0*9
+        f32x4* w4 = (f32x4*)(wl0 + buf * WCH);
 #pragma unroll
         for (int j = 0; j < NWR; ++j) {
-            const int i = tid + NT * j;
-            if (i < WCH / 4) wreg[j] = src[i];
+            const int i = tid + NT * j;                   // wave-uniform condition: WCH/4 is a multiple of 64
+            if (i < WCH / 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i),
+                                                 (__attribute__((address_space(3))) void*)(w4 + (i - lane)), 16, 0, 0);
         }
     };
     auto commit = [&](int buf) {
@@ -310,18 +316,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
                 }
             }
         }
-        f32x4* w4 = (f32x4*)(wl0 + buf * WCH);
-#pragma unroll
-        for (int j = 0; j < NWR; ++j) {
-            const int i = tid + NT * j;
-            if (i < WCH / 4) w4[i] = wreg[j];
-        }
     };
 
     const int nchunks = a.C / DF_CH;
     geometry(0);
-    issue(0);
+    issue(0, 0);
     commit(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
         const bool more = ch + 1 < nchunks;
         if (more) {
             if (cnext % cpg == 0) geometry(cnext / cpg);      // next chunk starts a new deformable group
-            issue(cnext);
+            issue(cnext, cur ^ 1);                            // buffer cur^1 was last read before the previous barrier
         }
         if constexpr (SPLIT) {
             const float* colp = col0 + cur * DF_ROWS * NPX + wave * 32 + l31;
@@ -377,6 +378,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         }
         if (more) commit(cur ^ 1);
+        // LDS-DMA is ordered for other waves' ds_reads only by the issuing wave's vmcnt followed by a barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
     }

@@ -398,10 +398,16 @@ def test_raft_lookup_vs_alt_corr_restatement_and_corrblock():
     close(blk(coords.to(dev())), ref4, 2e-5, 1e-5, "4-level lookup")
 
 
-def test_corr81():
+@pytest.mark.parametrize("kernel", ["small", "tiled"])
+@pytest.mark.parametrize("shape", [(2, 33, 12, 20), (1, 19, 37, 70), (1, 8, 64, 96)])
+def test_corr81(kernel, shape, monkeypatch):
+    """Both cost-volume kernels (per-displacement threads for the coarse levels, LDS-tiled + register-blocked for the large
+    ones) against the kernel-text restatement: ragged tiles, W % 4 != 0 (scalar edge path), C not a multiple of the chunk."""
     from oracle import native
     from motif_amd import ops
-    a, b = rnd(2, 33, 12, 20, seed=1), rnd(2, 33, 12, 20, seed=2)
+    monkeypatch.setenv("MOTIF_CORR81", kernel)
+    n, c, h, w = shape
+    a, b = rnd(n, c, h, w, seed=1), rnd(n, c, h, w, seed=2)
     close(ops.corr81(a.to(dev()), b.to(dev())), native.corr81(a, b), 2e-6, 1e-5, "corr81")
     close(ops.corr81(a.to(dev()), b.to(dev()), ops.ACT_LRELU), F.leaky_relu(native.corr81(a, b), 0.1), 2e-6, 1e-5)
 

@@ -22,7 +22,7 @@ for (h, w) in ((180, 320),):
     torch.cuda.synchronize()
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
     bad = 0
-    for it in range(200):
+    for it in range(int(os.environ.get("ITERS", "200"))):
         if not __import__("os").environ.get("SERIAL"):
             with torch.cuda.stream(sb):
                 which = __import__("os").environ.get("SIDE", "gru,tr,c7").split(",")
@@ -33,4 +33,4 @@ for (h, w) in ((180, 320),):
             outs = [ops.dcn_v2_multi([d.dplan() for d in dcns], xs, oms, 8, ops.ACT_LRELU) for _ in range(4)]
         torch.cuda.synchronize()
         bad += sum(int(not torch.equal(o, ref)) for o in outs)
-    print("dcn P=2 %dx%d: %d / 800 mismatching outputs under concurrency" % (h, w, bad))
+    print("dcn P=2 %dx%d: %d mismatching outputs under concurrency" % (h, w, bad))
