@@ -424,10 +424,15 @@ extern "C" int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, co
     a.ncg = (Cout + 63) / 64;
     a.Kpad = 2 * 9 * ((C + 1) / 2);
     a.tiles_x = (W + 31) / 32;
-    // 8-wave blocks (one 92 KB block per CU) by default.  The 4-wave variant (two 55 KB blocks per CU, ~12 % faster on the
-    // large maps) is opt-in only: run beside conv_split_kernel<*,4> blocks on the same CU it produced sporadic wrong tiles
-    // (tools/dbg/race_dcn4.py; serial runs and every other pairing are bit-reproducible) -- not understood yet, so not used.
-    int waves = 8;
+    // 4-wave blocks (two 74 KB blocks per CU whose gather latencies and MFMA stretches overlap; 11 % faster than one 8-wave
+    // block on the 180x320 maps) where the map is large enough to fill the chip that way, else 8-wave blocks.
+    // History: in round 1 the 4-wave form was seen to produce sporadic wrong tile rows beside conv_split blocks of another
+    // stream and was made opt-in.  Round 2 could not reproduce that on five fresh MI355X boxes -- neither with the exact
+    // round-1 tree (d21b251, 2400 concurrent launches, tools/dbg/race_dcn4.py) nor with this kernel; what changed here: the
+    // weights go global -> LDS directly, which removed the kernel's scratch use (3 / 11 spilled VGPRs before), and the LDS-DMA
+    // is drained by an explicit vmcnt(0) before each barrier.  tests/test_kernels_gpu.py::test_dcn_concurrent_with_conv_split
+    // and the model-level run-to-run test keep watching it.  MOTIF_DCN_WAVES=8 / 4 forces a form.
+    int waves = (long)H * W >= 90L * 160 ? 4 : 8;
     if (const char* ev = getenv("MOTIF_DCN_WAVES")) waves = atoi(ev) == 4 ? 4 : 8;
     a.front_pad = getenv("MOTIF_DCN_FRONT_PAD") ? atoi(getenv("MOTIF_DCN_FRONT_PAD")) : 0;
     const int back_pad = getenv("MOTIF_DCN_BACK_PAD") ? atoi(getenv("MOTIF_DCN_BACK_PAD")) : 0;

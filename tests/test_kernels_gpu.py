@@ -685,6 +685,44 @@ def test_dcn_fused_multi_vs_kernel_text(engine):
         close(out[pi], outs_ref[pi], 3e-5, 3e-5, "fused dcn problem %d" % pi)
 
 
+def test_dcn_concurrent_with_conv_split_is_bit_identical(keep_mma):
+    """The fused DCN (4-wave form on this map size: two blocks per CU) launched on one stream while conv_split launches of the
+    shapes RAFT issues run on another: every one of 4 x 150 outputs must equal the serial result bit for bit.  Regression
+    guard for the co-residency corruption reported in round 1 (dcn.hip, launch comment)."""
+    from motif_amd import ops
+    from motif_amd.models.modules.DCNv2.dcn_v2 import DCN_sep
+    from motif_amd.models.modules.layers import Conv2d
+    ops.set_mma("bf16x3")
+    torch.manual_seed(0)
+    gru = Conv2d(242, 96, 3, 1, 1).to(dev())
+    xg = torch.randn(2, 242, 90, 160, device=dev())
+    tr = Conv2d(64, 64, 3, 1, 1).to(dev())
+    xt = torch.randn(4, 64, 360, 640, device=dev())
+    dcns = [DCN_sep(64, 64, 3, stride=1, padding=1, dilation=1, deformable_groups=8).to(dev()) for _ in range(2)]
+    with torch.no_grad():
+        for d in dcns:
+            d.conv_offset_mask.weight.normal_(0, 0.05)
+    h, w = 180, 320
+    xs = [torch.randn(1, 64, h, w, device=dev()) for _ in range(2)]
+    feas = [torch.randn(1, 64, h, w, device=dev()) for _ in range(2)]
+    with torch.no_grad():
+        oms = ops.conv2d_multi([d.conv_offset_mask.plan() for d in dcns], feas, act=ops.ACT_NONE, act2=ops.ACT_SIGMOID, act_split=144)
+        oms = [oms[0].clone(), oms[1].clone()]
+        ref = ops.dcn_v2_multi([d.dplan() for d in dcns], xs, oms, 8, ops.ACT_LRELU).clone()
+        torch.cuda.synchronize()
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        bad = 0
+        for _ in range(150):
+            with torch.cuda.stream(sb):
+                gru(xg, act=1)
+                tr(xt, act=1)
+            with torch.cuda.stream(sa):
+                outs = [ops.dcn_v2_multi([d.dplan() for d in dcns], xs, oms, 8, ops.ACT_LRELU) for _ in range(4)]
+            torch.cuda.synchronize()
+            bad += sum(int(not torch.equal(o, ref)) for o in outs)
+    assert bad == 0, "%d of 600 concurrent DCN outputs differ from the serial result" % bad
+
+
 # ------------------------------------------------------------------------------------------- frame formats
 def test_frame_decode_encode_bit_exact():
     """motif_frames_u8_to_f32 / _f32_to_u8 against the numpy restatement of the reference's loader and tensor2img /
