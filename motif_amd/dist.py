@@ -105,22 +105,56 @@ def gather_bands_to_rank0(local, n_rows, dst=0, align=1, row_dim=-3):
     return torch.cat([bufs[r].narrow(row_dim, 0, rows[r][1] - rows[r][0]) for r in range(w)], dim=row_dim)
 
 
-def render_clip_tiled(net, x, times, scale, iters=4, halo=64, chunk=3, max_retries=2, encode=frames_to_uint8):
+def crop_rows_for_band(band, halo, H, HH, lr_halo):
+    """LR rows [a, b) a rank reads in cropped tile mode for the HR band `band`: the rows the HR stage gathers from (band +-
+    halo HR rows) widened by `lr_halo` rows of context for the LR stage, pushed outward to multiples of 4 (the encoder's
+    /2 /4 pyramid, test.py:168-175).  Integer scale only."""
+    s = HH // H
+    if s * H != HH:
+        raise ValueError("cropped tile mode needs an integer scale")
+    a = max(0, (band[0] - halo) // s - lr_halo)
+    b = min(H, -(-(band[1] + halo) // s) + lr_halo)
+    a, b = (a // 4) * 4, min(H, -(-b // 4) * 4)
+    if (b - a) * s < 128:                                   # RAFT needs HR >= 128 rows (corr.py:65-68)
+        b = min(H, a + -(-128 // s // 4) * 4)
+        a = max(0, b - -(-128 // s // 4) * 4)
+    return a, b
+
+
+def render_clip_tiled(net, x, times, scale, iters=4, halo=64, chunk=3, max_retries=2, encode=frames_to_uint8, lr_halo=None):
     """One clip over all ranks: every rank runs the LR stage, then renders its HR row band for every timestamp chunk
     (the <= 3-timestamp chunking of VideoSR_base_model.py:189-193).  Returns on rank 0 the uint8 frames
     [T, B, HH, WW, 3] (`encode`: fp32 [...,3,rows,WW] -> uint8 [...,rows,WW,3], the encode kernel), elsewhere None.
-    The halo is doubled and the clip re-rendered if some |flow_y| + 1 exceeds it."""
+    The halo is doubled and the clip re-rendered if some |flow_y| + 1 exceeds it.
+
+    lr_halo=None (exact mode): the LR stage (RAFT: instance norm = global statistics; encoder: receptive field of ~100
+    convolutions + data-dependent deformable offsets) is REPLICATED on every rank, the result equals the untiled render bit
+    for bit -- but the LR stage is 3/4 of a 540x960 clip, so 8 GPUs buy ~1.25x.
+    lr_halo=R (cropped mode, APPROXIMATE): every rank runs the whole model on its own crop of the LR clip -- the rows its
+    HR band gathers from plus R rows of context on each side (`crop_rows_for_band`) -- so the LR stage is tiled too and the
+    clip scales; what is lost is the influence of pixels more than R rows away on the encoder / RAFT output (and RAFT's
+    instance-norm statistics are the crop's).  Parity of this mode is a PSNR against the untiled render, as SURVEY.md 7(vi)
+    sets it: tests/test_model_gpu.py::test_c5_cropped_tile_mode_psnr measures it at full c5 size."""
     rank, w = world()
-    HH = int(scale[0][0]) if isinstance(scale, list) else round(x.shape[3] * scale)
-    band = band_of(HH, rank, w, align=8)
+    H = x.shape[3]
+    HH = int(scale[0][0]) if isinstance(scale, list) else round(H * scale)
     WW = int(scale[1][0]) if isinstance(scale, list) else round(x.shape[4] * scale)
+    align = 8 if lr_halo is None else 16
+    band = band_of(HH, rank, w, align=align)
     for attempt in range(max_retries + 1):
-        net.band, net.band_halo = band, halo
+        xr, sr, br = x, scale, band
+        if lr_halo is not None and band[1] > band[0]:
+            a, b = crop_rows_for_band(band, halo, H, HH, lr_halo)
+            sc = HH // H
+            xr = x[..., a:b, :].contiguous()                 # this rank's crop; alive over the chunks (it keys the clip cache)
+            sr = [[(b - a) * sc], [WW]]
+            br = (band[0] - a * sc, band[1] - a * sc)
+        net.band, net.band_halo = br, halo
         outs, worst = [], torch.zeros((), device=x.device)
         with torch.no_grad():
             for l in range(0, len(times), chunk):
                 if band[1] > band[0]:
-                    frames, _, _ = net(x, None, times[l:l + chunk], scale, use_GT=False, iter=iters)
+                    frames, _, _ = net(xr, None, times[l:l + chunk], sr, use_GT=False, iter=iters)
                     outs.append(encode(frames))
                     worst = torch.maximum(worst, net.last_max_flow_y)
                 else:                                                           # more ranks than row units: nothing to render
@@ -132,7 +166,7 @@ def render_clip_tiled(net, x, times, scale, iters=4, halo=64, chunk=3, max_retri
             raise RuntimeError("tile mode: |flow_y| = %.1f px exceeds the halo of %d rows" % (worst, halo))
         halo *= 2
     net.band = None
-    return gather_bands_to_rank0(torch.cat(outs, 0), HH, align=8, row_dim=-3)
+    return gather_bands_to_rank0(torch.cat(outs, 0), HH, align=align, row_dim=-3)
 
 
 # ------------------------------------------------------------------------------------------ timestamps of one clip

@@ -43,6 +43,13 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _packed_ready():
+    """Packed weights are cached per parameter version and then used from whichever HIP stream runs the layer (RAFT's side
+    stream, the per-image trunk streams, clips in flight): the one-off pack kernel is waited for on the host, so no later
+    user on another stream can read a half-written blob."""
+    torch.cuda.current_stream().synchronize()
+
+
 def _planar(t):
     """True if t is [N,C,H,W] with dense C,H,W (batch stride free)."""
     n, c, h, w = t.shape
@@ -101,6 +108,7 @@ class ConvPlan:
             buf = torch.empty(size, dtype=torch.float32, device=w.device)
             wc = _c(w.detach())
             check(lib.motif_conv2d_pack(ctypes.byref(d), _p(wc), _p(buf), _stream()), "motif_conv2d_pack")
+            _packed_ready()
             self._packed, self._key = buf, key
         return self._packed
 
@@ -236,6 +244,7 @@ class DcnPlan:
             rc = lib.motif_dcn_split_pack(_p(_c(w.detach())), _p(buf), co, ci, _stream())
             if rc != n:
                 raise RuntimeError("motif_dcn_split_pack failed (%d)" % rc)
+            _packed_ready()
             self._spacked, self._skey = buf, key
         return self._spacked
 
@@ -305,6 +314,7 @@ def siren_pack(linears):
     rc = lib.motif_siren_pack(wp, bp, dm, n, _p(blob), _stream())
     if rc != total:
         raise RuntimeError("motif_siren_pack failed (%d)" % rc)
+    _packed_ready()
     return blob
 
 
@@ -357,6 +367,7 @@ def siren_pack_split(kind, linears):
     rc = lib.motif_siren_pack_split(kind, wp, bp, _p(blob), _stream())
     if rc != total:
         raise RuntimeError("motif_siren_pack_split failed (%d)" % rc)
+    _packed_ready()
     return blob
 
 

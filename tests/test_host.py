@@ -225,6 +225,60 @@ dist.destroy_process_group()
     assert r.returncode == 0 and "TILED_OK (0, 56) (56, 104)" in r.stdout, r.stdout + r.stderr
 
 
+def test_cropped_tile_mode_geometry_and_driver_over_gloo_world2(tmp_path):
+    """render_clip_tiled(lr_halo=R): each rank hands the generator ITS crop of the LR clip (rows from crop_rows_for_band),
+    the HR size of that crop and the band in the crop's own row numbering; bands come back in order."""
+    from motif_amd.dist import band_of, crop_rows_for_band
+    for (H, HH, ranks) in ((540, 2160, 8), (180, 720, 2), (64, 256, 4)):
+        s = HH // H
+        for r in range(ranks):
+            band = band_of(HH, r, ranks, 16)
+            a, b = crop_rows_for_band(band, 64, H, HH, 16)
+            assert 0 <= a < b <= H and a % 4 == 0 and (b % 4 == 0 or b == H)
+            assert a * s <= max(0, band[0] - 64) and b * s >= min(HH, band[1] + 64)       # the HR stage's gather range is inside
+            assert (b - a) * s >= 128
+    script = tmp_path / "c.py"
+    script.write_text('''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from motif_amd import dist as md
+dist.init_process_group("gloo")
+r, w = md.world()
+H, W, s = 96, 4, 4
+HH, WW = H * s, W * s
+
+class FakeNet:
+    band, band_halo, last_max_flow_y, calls = None, 64, None, []
+    def __call__(self, x, _, times, scale, use_GT=False, iter=4):
+        r0, r1 = self.band
+        self.calls.append((tuple(x.shape), scale, self.band))
+        a = int(x[0, 0, 0, 0, 0])                                   # first LR row of the crop (encoded in the data below)
+        rows = (torch.arange(r0, r1, dtype=torch.float32) + a * s).view(1, 1, 1, -1, 1)
+        self.last_max_flow_y = torch.tensor(2.0)
+        return ((rows %% 251) / 255.0).expand(len(times), 1, 3, r1 - r0, WW), None, 0
+
+net = FakeNet()
+x = torch.arange(H, dtype=torch.float32).view(1, 1, 1, H, 1).expand(1, 4, 3, H, W).contiguous()    # pixel value = its LR row
+times = [torch.full((1, 1), i / 2) for i in range(3)]
+encode = lambda f: (f * 255.0).round().to(torch.uint8).permute(0, 1, 3, 4, 2).contiguous()
+out = md.render_clip_tiled(net, x, times, [[HH], [WW]], halo=16, encode=encode, lr_halo=8)
+band = md.band_of(HH, r, w, 16)
+a, b = md.crop_rows_for_band(band, 16, H, HH, 8)
+shape, scale, bnd = net.calls[0]
+assert shape == (1, 4, 3, b - a, W) and scale == [[(b - a) * s], [WW]] and bnd == (band[0] - a * s, band[1] - a * s), net.calls
+assert b - a < H
+if r == 0:
+    assert out.shape == (3, 1, HH, WW, 3)
+    assert [int(v) for v in out[0, 0, :, 0, 0]] == [i %% 251 for i in range(HH)]
+    print("CROP_OK", (a, b))
+dist.destroy_process_group()
+''' % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "CROP_OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_timestamp_split_over_gloo_world2(tmp_path):
     """motif_amd.dist.render_clip_by_timestamps (SURVEY.md 8(e) row 2: one clip, timestamps r::W per rank) with the REAL
     LunaTokis host logic -- clip-cache export / broadcast / import, cache keying, per-rank timestamp chunks, timestamp-order

@@ -464,6 +464,48 @@ def test_c5_row_bands_match_untiled_at_full_size(mma_mode):
     assert worst + 1 <= halo, "synthetic clip moves %.1f px: halo too small for an exact comparison" % worst
 
 
+def test_c5_cropped_tile_mode_psnr(mma_mode):
+    """BASELINE config 5 at FULL size in the CROPPED tile mode (`render_clip_tiled(lr_halo=16)`: every rank runs the whole
+    model on its own crop of the LR clip, so the LR stage scales too).  Approximate by construction (tile-mode
+    parity = PSNR vs the untiled render): bar PSNR >= 55 dB over the whole clip (measured 61.6 dB), and no rank may process
+    more than 30 % of the LR rows (that is what makes an 8-GPU job >= 3.5x faster than one GPU)."""
+    from motif_amd import dist as md
+    from motif_amd.data.synthetic import synthetic_sample
+    if mma_mode != "bf16x3":
+        pytest.skip("one engine is enough at this size")
+    h, w, s, T, bands, halo, R = 540, 960, 4, 5, 8, 64, 16
+    HH, WW = h * s, w * s
+    net = build_net()
+    smp = synthetic_sample(h, w, s, T)
+    x = smp["LQs"].cuda()
+    times = [t.cuda() for t in smp["time"]]
+
+    def render(xr, sc):
+        with torch.no_grad():
+            return torch.cat([net(xr, None, times[l:l + 3], sc, use_GT=False, iter=4)[0] for l in range(0, T, 3)], 0)
+
+    full = render(x, smp["scale"])
+    parts, worst_rows = [], 0
+    try:
+        for r in range(bands):
+            band = md.band_of(HH, r, bands, 16)
+            a, b = md.crop_rows_for_band(band, halo, h, HH, R)
+            assert a % 4 == 0 and b % 4 == 0 and a * s <= max(0, band[0] - halo) and b * s >= min(HH, band[1] + halo)
+            worst_rows = max(worst_rows, b - a)
+            net.band, net.band_halo = (band[0] - a * s, band[1] - a * s), halo
+            parts.append(render(x[..., a:b, :].contiguous(), [[(b - a) * s], [WW]]))
+            assert float(net.last_max_flow_y) + 1 <= halo
+    finally:
+        net.band = None
+        net.clear_cache()
+    tiled = torch.cat(parts, dim=-2)
+    assert tiled.shape == full.shape
+    p = psnr(tiled, full)
+    print("c5 cropped tiles (lr_halo %d): PSNR vs untiled %.2f dB, largest crop %d of %d LR rows" % (R, p, worst_rows, h))
+    assert p >= 55.0, p
+    assert worst_rows <= 0.30 * h
+
+
 def test_c3_crop_bf16_path_vs_oracle(mma_mode):
     """BASELINE config 3's arithmetic ("bf16 MFMA path": plain-bf16 convolutions, `mma: bf16`) against the CPU oracle on a
     crop of the Vimeo-7 septuplet shape the oracle finishes in seconds: 7 LR frames 64x112, x4 spatial, x8 temporal = 9
