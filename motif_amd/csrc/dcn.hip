@@ -401,6 +401,298 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
         }
 }
 
+// ================================================================================================
+// Window form of the fused kernel (bf16x3 engine): the bilinear corner values come out of LDS instead of the texture path.
+// The gathers above are what bounds dcn_fused_kernel: 2 x 8-byte scattered loads per (pixel, tap, channel) -- 40 wave-level
+// gather instructions per thread and chunk against 36 MFMAs.  Deformable offsets are small where the features are aligned
+// well, so a block stages, per 4-channel chunk, the input WINDOW of its tile (tile + DW_R pixels on every side, clamped to
+// the image; 16-byte coalesced loads, 4 per thread) in LDS and samples the four corners with LDS reads; a sample whose 2x2
+// footprint leaves the window falls back to predicated global loads (same corner values, same blend expression -- the
+// result does not depend on which path a sample took).  Pipeline per chunk ch, one barrier:
+//   request window(ch+2) -> registers | sample chunk ch+1 from LDS window(ch+1), blend -> registers | MFMA(ch) |
+//   write col(ch+1), window(ch+2) to LDS | barrier
+// Order matters: vmcnt retires in order, so nothing inside the sampling or MFMA stretches may wait on a global load --
+// the window / offset requests of later chunks would be dragged into that wait.  Hence the weights travel global -> LDS by
+// LDS-DMA (no register results to wait for; drained by the vmcnt(0) in front of the barrier) and the fallback path is the
+// only place that waits.  One 8-wave block per CU: col 2 x 36 KB + window 2 x 18 KB + weights 2 x 18 KB = 147 KB.
+// ================================================================================================
+#define DW_R 8
+#ifdef MOTIF_DCN_TRACE
+__device__ long long g_dcn_trace[64 * 8];
+extern "C" int motif_debug_dcn_trace(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dcn_trace), sizeof(long long) * n); }
+#define DT(i) do { const long long now_ = __builtin_amdgcn_s_memtime(); tph[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define DT(i)
+#endif
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void dcn_win_kernel(DcnFusedArgs a) {
+    constexpr int NPX = 32 * WAVES, NT = 64 * WAVES, TH = WAVES;
+    constexpr int WWD = 32 + 2 * DW_R, WHT = TH + 2 * DW_R, WSZ = WHT * WWD;      // window of one channel
+    constexpr int NWU = DF_CH * WSZ / 4, NWL = (NWU + NT - 1) / NT;                // 16-byte units per chunk, per thread
+    constexpr int WCH = 3 * 3 * 2 * 64 * 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* col0 = smem;                                  // [2][DF_ROWS][NPX]
+    float* win0 = col0 + 2 * DF_ROWS * NPX;              // [2][DF_CH][WSZ]
+    float* wl0 = win0 + 2 * DF_CH * WSZ;                 // [2][WCH] weight fragments of a chunk
+    float* bias_s = wl0 + 2 * WCH;                       // [64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    const int cg = blockIdx.y;
+    const int pz = blockIdx.z / a.B, b = blockIdx.z - pz * a.B;
+    const int H = a.H, W = a.W;
+    const long HW = (long)H * W;
+    const float* imb = a.im[pz] + (long)b * a.im_bs[pz];
+    const float* offb = a.offset[pz] + (long)b * a.offset_bs;
+    const float* mskb = a.mask[pz] + (long)b * a.mask_bs;
+    const float* wbase = a.wp[pz] + (long)cg * (a.C / DF_CH) * WCH;
+    const int cpg = a.C / a.dg;
+    const int wy0 = ty * TH - DW_R, wx0 = tx * 32 - DW_R;
+
+    const int pxl = tid % NPX;
+    const int oy = ty * TH + (pxl >> 5), ox = tx * 32 + (pxl & 31);
+    const bool pix_ok = oy < H && ox < W;
+    const long p = (long)oy * W + ox;
+    const int tap0 = tid / NPX;
+
+    if (tid < 64) {
+        const int col = cg * 64 + tid;
+        bias_s[tid] = (a.bias[pz] && col < a.Cout) ? a.bias[pz][col] : 0.f;
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // window staging plan (chunk invariant): unit u = (channel, window row, 4-pixel group) -> global offset within a plane
+    int woff[NWL];
+#pragma unroll
+    for (int k = 0; k < NWL; ++k) {
+        const int u = tid + NT * k;
+        woff[k] = -1;
+        if (u < NWU) {
+            const int c = u / (WSZ / 4), r = u - c * (WSZ / 4);
+            const int wy = r / (WWD / 4), wu = r - wy * (WWD / 4);
+            int gy = wy0 + wy, gx = wx0 + 4 * wu;
+            gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);                         // clamped: finite image data everywhere,
+            gx = gx < 0 ? 0 : (gx > W - 4 ? W - 4 : gx);                         // invalid corners carry weight 0
+            woff[k] = c * (int)HW + gy * W + gx;
+        }
+    }
+    f32x4 wreg[NWL];
+    auto win_request = [&](int c0) {
+        const float* base = imb + (long)c0 * HW;
+#pragma unroll
+        for (int k = 0; k < NWL; ++k)
+            if (woff[k] >= 0) wreg[k] = *(const f32x4*)(base + woff[k]);
+    };
+    auto win_commit = [&](int buf) {
+        f32x4* dst = (f32x4*)(win0 + buf * DF_CH * WSZ);
+#pragma unroll
+        for (int k = 0; k < NWL; ++k)
+            if (woff[k] >= 0) dst[tid + NT * k] = wreg[k];
+    };
+
+    // geometry of the current deformable group, per (pixel, tap) pair of this thread: window offset of the top-left corner
+    // (or -1: footprint outside the window -> global path), the four corner weights (0 for corners outside the image,
+    // dcn_v2_im2col_cuda.cu:37-48), the mask, and for the global path the plane offset + validity bits
+    int glt[DF_PAIRS], go1[DF_PAIRS], gfl[DF_PAIRS];
+    float gw1[DF_PAIRS], gw2[DF_PAIRS], gw3[DF_PAIRS], gw4[DF_PAIRS], gm[DF_PAIRS];
+    float roh[DF_PAIRS], row_[DF_PAIRS], rom[DF_PAIRS];     // offsets / mask of the NEXT group, requested a group ahead
+    // Everything below is written branch-free on purpose: per-sample `if`s made the compiler emit one exec-mask region (and
+    // one LDS round trip) per sample -- 110 saveexec/branch pairs per chunk; dead pairs (tap 9, pixels outside the image,
+    // samples outside the image) simply carry zero weights and read a harmless address.
+    const long pc = pix_ok ? p : 0;
+    auto geom_request = [&](int g) {
+        const float* op = offb + (long)g * 18 * HW + pc;
+        const float* mp = mskb + (long)g * 9 * HW + pc;
+#pragma unroll
+        for (int j = 0; j < DF_PAIRS; ++j) {
+            const int tap = tap0 + 2 * j < 9 ? tap0 + 2 * j : 8;
+            roh[j] = op[(long)(2 * tap) * HW];
+            row_[j] = op[(long)(2 * tap + 1) * HW];
+            rom[j] = mp[(long)tap * HW];
+        }
+    };
+    auto geometry = [&]() {                              // from the requested offsets / mask
+#pragma unroll
+        for (int j = 0; j < DF_PAIRS; ++j) {
+            const int tap = tap0 + 2 * j;
+            const bool live = tap < 9 && pix_ok;
+            const float h_im = (float)(oy - 1 + tap / 3) + roh[j];
+            const float w_im = (float)(ox - 1 + tap % 3) + row_[j];
+            const bool inside = live && h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+            const float hs = inside ? h_im : 0.f, ws = inside ? w_im : 0.f;      // safe coordinates for the dead pairs
+            const int h_low = (int)floorf(hs), w_low = (int)floorf(ws);
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = hs - h_low, lw = ws - w_low, hh = 1 - lh, hw = 1 - lw;
+            const bool vt = inside && h_low >= 0, vb = inside && h_high <= H - 1, vl = w_low >= 0, vr = w_high <= W - 1;
+            gw1[j] = (vt && vl) ? hh * hw : 0.f; gw2[j] = (vt && vr) ? hh * lw : 0.f;
+            gw3[j] = (vb && vl) ? lh * hw : 0.f; gw4[j] = (vb && vr) ? lh * lw : 0.f;
+            gm[j] = live ? rom[j] : 0.f;
+            const int ry = h_low - wy0, rx = w_low - wx0;
+            const bool inwin = !inside || (ry >= 0 && ry <= WHT - 2 && rx >= 0 && rx <= WWD - 2);
+            glt[j] = inwin ? (inside ? ry * WWD + rx : 0) : -1;
+            go1[j] = h_low * W + w_low;
+            gfl[j] = (vt && vl ? 1 : 0) | (vt && vr ? 2 : 0) | (vb && vl ? 4 : 0) | (vb && vr ? 8 : 0);
+        }
+    };
+    float val[DF_PAIRS][DF_CH];
+    auto sample = [&](int c0, int buf) {                 // chunk c0's im2col values of my pairs, from window `buf`
+        const float* wb = win0 + buf * DF_CH * WSZ;
+        bool far = false;
+        // all 40 LDS read pairs of the chunk are issued back to back (scheduling fences: left alone the compiler issues
+        // them four at a time with a full LDS round trip each), then blended
+        float t[DF_PAIRS][DF_CH][4];
+#pragma unroll
+        for (int j = 0; j < DF_PAIRS; ++j) {
+            const int lt = glt[j] >= 0 ? glt[j] : 0;
+            far |= glt[j] < 0;
+#pragma unroll
+            for (int cl = 0; cl < DF_CH; ++cl) {
+                const float* q = wb + cl * WSZ + lt;
+                t[j][cl][0] = q[0]; t[j][cl][1] = q[1]; t[j][cl][2] = q[WWD]; t[j][cl][3] = q[WWD + 1];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < DF_PAIRS; ++j)
+#pragma unroll
+            for (int cl = 0; cl < DF_CH; ++cl)
+                val[j][cl] = (gw1[j] * t[j][cl][0] + gw2[j] * t[j][cl][1] + gw3[j] * t[j][cl][2] + gw4[j] * t[j][cl][3]) * gm[j];
+        if (__any(far)) {                                // some sample of this wave left the window: predicated global loads
+#pragma unroll
+            for (int j = 0; j < DF_PAIRS; ++j) {
+                if (glt[j] < 0) {
+#pragma unroll
+                    for (int cl = 0; cl < DF_CH; ++cl) {
+                        const float* ip = imb + (long)(c0 + cl) * HW + go1[j];
+                        const int fl = gfl[j];
+                        const float v1 = (fl & 1) ? ip[0] : 0.f, v2 = (fl & 2) ? ip[1] : 0.f;
+                        const float v3 = (fl & 4) ? ip[W] : 0.f, v4 = (fl & 8) ? ip[W + 1] : 0.f;
+                        val[j][cl] = (gw1[j] * v1 + gw2[j] * v2 + gw3[j] * v3 + gw4[j] * v4) * gm[j];
+                    }
+                }
+            }
+        }
+    };
+    auto col_commit = [&](int buf) {
+        float* col = col0 + buf * DF_ROWS * NPX;
+#pragma unroll
+        for (int j = 0; j < DF_PAIRS; ++j) {
+            const int tap = tap0 + 2 * j;
+            if (tap < 9) {
+#pragma unroll
+                for (int cl = 0; cl < DF_CH; ++cl) col[(((cl >> 1) * 9 + tap) * 2 + (cl & 1)) * NPX + pxl] = val[j][cl];
+            }
+        }
+    };
+    constexpr int NWR = (WCH / 4 + NT - 1) / NT;
+    static_assert((WCH / 4) % 64 == 0, "a chunk's weights are whole 1 KiB wave pieces");
+    auto w_request = [&](int chunk, int buf) {           // LDS-DMA: wave-uniform LDS base + lane * 16, linear copy
+        const f32x4* src = (const f32x4*)(wbase + (long)chunk * WCH);
+        f32x4* w4 = (f32x4*)(wl0 + buf * WCH);
+#pragma unroll
+        for (int k = 0; k < NWR; ++k) {
+            const int i = tid + NT * k;
+            if (i < WCH / 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i),
+                                                 (__attribute__((address_space(3))) void*)(w4 + (i - lane)), 16, 0, 0);
+        }
+    };
+
+#ifdef MOTIF_DCN_TRACE
+    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = __builtin_amdgcn_s_memtime();
+#endif
+    const int nchunks = a.C / DF_CH;
+    // prologue: window(0) -> LDS, then chunk 0 sampled into col(0); window(1) staged for the first loop iteration
+    win_request(0);
+    geom_request(0);
+    w_request(0, 0);
+    geometry();
+    win_commit(0);
+    if (a.dg > 1) geom_request(1);
+    if (nchunks > 1) win_request(DF_CH);
+    __syncthreads();
+    sample(0, 0);
+    col_commit(0);
+    if (nchunks > 1) win_commit(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    DT(0);
+    int cur = 0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const bool more = ch + 1 < nchunks, more2 = ch + 2 < nchunks;
+        if (more) {
+            const int cnext = (ch + 1) * DF_CH;
+            const bool newg = cnext % cpg == 0;               // next chunk starts a new deformable group: its offsets / mask
+            if (newg) geometry();                             // were requested a whole group ago
+            DT(5);
+            sample(cnext, (ch + 1) & 1);
+            DT(6);
+            if (newg && cnext / cpg + 1 < a.dg) geom_request(cnext / cpg + 1);
+            w_request(ch + 1, cur ^ 1);                       // weight buffer cur^1 was last read before the previous barrier
+        }
+        if (more2) win_request((ch + 2) * DF_CH);             // all requests AFTER the sampling: see the note on vmcnt order
+        DT(1);
+        {
+            const float* colp = col0 + cur * DF_ROWS * NPX + wave * 32 + l31;
+            const dcn_u32x4* wfr = (const dcn_u32x4*)(wl0 + cur * WCH) + lane;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = 16 * ks + 8 * half + e;
+                    v[e] = (ks < 2 || r < DF_ROWS) ? colp[(r < DF_ROWS ? r : 0) * NPX] : 0.f;
+                    if (ks == 2 && r >= DF_ROWS) v[e] = 0.f;
+                }
+                dcn_u32x4 x[3];
+                dcn_split8(v, x);
+                dcn_u32x4 w[2][3];
+#pragma unroll
+                for (int part = 0; part < 3; ++part)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) w[t][part] = wfr[((ks * 3 + part) * 2 + t) * 64];
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dcn_bf16x8, w[t][DCN_PW[k]]),
+                                                                          __builtin_bit_cast(dcn_bf16x8, x[DCN_PX[k]]), acc[t], 0, 0, 0);
+            }
+        }
+        DT(2);
+        if (more) col_commit(cur ^ 1);
+        if (more2) win_commit(ch & 1);                        // window(ch+2) replaces window(ch), last read in the previous iteration
+        DT(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA weights landed before anyone passes the barrier
+        __syncthreads();
+        DT(4);
+        cur ^= 1;
+    }
+#ifdef MOTIF_DCN_TRACE
+    if (lane == 0 && wave == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 64)
+        for (int i = 0; i < 8; ++i) g_dcn_trace[blockIdx.x * 8 + i] = tph[i];
+#endif
+
+    const int eox = tx * 32 + l31, eoy = ty * TH + wave;
+    if (eox >= W || eoy >= H) return;
+    float* op = a.out[pz] + ((long)b * a.Cout + (long)cg * 64) * HW + (long)eoy * W + eox;
+    const int climit = a.Cout - cg * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int col = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = acc[i][r] + bias_s[col];
+            if (a.act == MOTIF_ACT_LRELU) v = v > 0.f ? v : 0.1f * v;
+            else if (a.act == MOTIF_ACT_RELU) v = v > 0.f ? v : 0.f;
+            if (col < climit) op[(long)col * HW] = v;
+        }
+}
+
 extern "C" int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, const long* input_bs, const float* const* offset,
                                             const float* const* mask, const float* const* packed3x3, const float* const* bias,
                                             float* const* out, int B, int C, int H, int W, int Cout, int deformable_groups,
@@ -432,7 +724,12 @@ extern "C" int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, co
     // weights go global -> LDS directly, which removed the kernel's scratch use (3 / 11 spilled VGPRs before), and the LDS-DMA
     // is drained by an explicit vmcnt(0) before each barrier.  tests/test_kernels_gpu.py::test_dcn_concurrent_with_conv_split
     // and the model-level run-to-run test keep watching it.  MOTIF_DCN_WAVES=8 / 4 forces a form.
-    int waves = (long)H * W >= 90L * 160 ? 4 : 8;
+    // window form (dcn_win_kernel): bf16x3 engine, rows of whole 16-byte units, 32-bit offsets over 4 planes; one 8-wave block
+    // per CU (147 KB of LDS)
+    const bool win_ok = mma == 6 && (W & 3) == 0 && W >= 4 && (long)DF_CH * HW < (1L << 30) && !getenv("MOTIF_DCN_NOWIN") &&
+                        (((unsigned long long)a.im[0] | (unsigned long long)a.im[1] | (unsigned long long)a.im[2] | (unsigned long long)a.im[3]) & 15) == 0 &&
+                        ((a.im_bs[0] | a.im_bs[1] | a.im_bs[2] | a.im_bs[3]) & 3) == 0;
+    int waves = (!win_ok && (long)H * W >= 90L * 160) ? 4 : 8;
     if (const char* ev = getenv("MOTIF_DCN_WAVES")) waves = atoi(ev) == 4 ? 4 : 8;
     a.front_pad = getenv("MOTIF_DCN_FRONT_PAD") ? atoi(getenv("MOTIF_DCN_FRONT_PAD")) : 0;
     const int back_pad = getenv("MOTIF_DCN_BACK_PAD") ? atoi(getenv("MOTIF_DCN_BACK_PAD")) : 0;
@@ -440,6 +737,20 @@ extern "C" int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, co
     const size_t lds = (size_t)(2 * DF_ROWS * 32 * waves + 2 * wch + 64 + a.front_pad + back_pad) * 4;
     dim3 grid(a.tiles_x * ((H + waves - 1) / waves), a.ncg, P * B);
     hipError_t e = hipSuccess;
+    if (win_ok) {
+        const size_t wlds = (size_t)(2 * DF_ROWS * 32 * waves + 2 * DF_CH * (waves + 2 * DW_R) * (32 + 2 * DW_R) + 2 * 3 * 3 * 2 * 64 * 4 + 64) * 4;
+        if (waves == 8) {
+            e = hipFuncSetAttribute((const void*)dcn_win_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
+            if (e != hipSuccess) return (int)e;
+            dcn_win_kernel<8><<<grid, 512, wlds, (hipStream_t)stream>>>(a);
+        } else {
+            e = hipFuncSetAttribute((const void*)dcn_win_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
+            if (e != hipSuccess) return (int)e;
+            dcn_win_kernel<4><<<grid, 256, wlds, (hipStream_t)stream>>>(a);
+        }
+        MOTIF_LAUNCH_CHECK();
+        return MOTIF_OK;
+    }
 #define MOTIF_LAUNCH_DCN(WV, SP)                                                                                          \
     do {                                                                                                                  \
         e = hipFuncSetAttribute((const void*)dcn_fused_kernel<WV, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
