@@ -21,14 +21,18 @@ def alt_cuda_corr_forward(fmap1, fmap2, coords, r):
 
 
 class AlternateCorrBlock:
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, index1=None, index2=None):
+        """index1 / index2 (LongTensors): the maps of pair i are fmap1[index1[i]] and fmap2[index2[i]] -- the channels-last
+        copies and the avg-pool pyramid are built once per distinct map and gathered per pair afterwards."""
         self.num_levels = num_levels
         self.radius = radius
         self.dim = fmap1.shape[1]
-        self.f1 = ops.nchw_to_nhwc(fmap1)
+        pick1 = (lambda t: t.index_select(0, index1)) if index1 is not None else (lambda t: t)
+        pick2 = (lambda t: t.index_select(0, index2)) if index2 is not None else (lambda t: t)
+        self.f1 = pick1(ops.nchw_to_nhwc(fmap1))
         self.f2 = []
         for i in range(self.num_levels):
-            self.f2.append(ops.nchw_to_nhwc(fmap2))
+            self.f2.append(pick2(ops.nchw_to_nhwc(fmap2)))
             if i + 1 < self.num_levels:
                 fmap2 = ops.avg_pool2(fmap2)
 

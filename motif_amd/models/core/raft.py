@@ -40,6 +40,32 @@ class RAFT(nn.Module):
         fmap1, fmap2 = self.fnet([image1, image2])
         corr_fn = AlternateCorrBlock(fmap1.contiguous(), fmap2.contiguous(), radius=self.args.corr_radius)
         cnet = self.cnet(image1, act=ops.ACT_TANH, act2=ops.ACT_RELU, act_split=self.hidden_dim)
+        return self._iterate(corr_fn, cnet, image1.shape, image1.device, iters, flow_init, test_mode, last_only)
+
+    def forward_pairs(self, frames, src, dst, iters=12, last_only=False):
+        """The same computation for the image pairs (frames[src[i]], frames[dst[i]]), frames [F,3,H,W] in [0,255]: the feature
+        and context encoders run ONCE per distinct frame instead of once per pair member -- `Ours.py:544` feeds the pairs
+        (a,b) and (b,a), so half of fnet's work there (and 5/6 of it for the 4-frame generators' 12 / 16 pairs) is a repeat.
+        Bit-identical to forward(frames[src], frames[dst]): nothing in either encoder crosses the batch dimension (the norm is
+        an instance norm), the pairing happens on the 1/8-resolution feature maps."""
+        x = (2 * (frames / 255.0) - 1.0).contiguous()
+        dev = frames.device
+        si = torch.as_tensor(src, device=dev, dtype=torch.long)
+        di = torch.as_tensor(dst, device=dev, dtype=torch.long)
+        fmap = self.fnet(x)                                                    # [F,128,h/8,w/8]
+        usrc = sorted(set(int(v) for v in src))                                # context net: distinct source frames only
+        cn = self.cnet(x[usrc] if len(usrc) < x.shape[0] else x, act=ops.ACT_TANH, act2=ops.ACT_RELU, act_split=self.hidden_dim)
+        pos = {f: i for i, f in enumerate(usrc)}
+        ci = torch.as_tensor([pos[int(v)] for v in src], device=dev, dtype=torch.long)
+        corr_fn = AlternateCorrBlock(fmap, fmap, radius=self.args.corr_radius, index1=si, index2=di)
+        shape = (len(src),) + tuple(frames.shape[1:])
+        return self._iterate(corr_fn, cn.index_select(0, ci), shape, dev, iters, None, False, last_only)
+
+    def _iterate(self, corr_fn, cnet, shape, device, iters, flow_init, test_mode, last_only):
+        class _Dev:                                       # (shape, device) of image1 as the update loop needs them
+            pass
+        image1 = _Dev()
+        image1.shape, image1.device = shape, device
         b, _, h, w = image1.shape
         h8, w8 = h // 8, w // 8
         net = cnet[:, :self.hidden_dim].contiguous()

@@ -378,11 +378,13 @@ class LunaTokis(nn.Module):
         """RAFT on the listed (source, target) frame pairs of the HR frames `hr` [B,n,3,HH,WW]; flow k of `n_flows` is
         pair (src, dst) = pairs[k] or None for a flow the reference multiplies by zero (Ours.py:552-553, Ours_4.py:509-510,
         Ours_44.py:513-516) -- those pairs are not run unless skip_zero_pairs is off.  -> LR flows [n_flows*B,2,H,W]."""
-        B, HH = hr.shape[0], hr.shape[3]
+        B, n, HH, WW = hr.shape[0], hr.shape[1], hr.shape[3], hr.shape[4]
         live = [(k, sd) for k, sd in enumerate(pairs) if sd[2] or not self.skip_zero_pairs]
-        i1 = torch.cat([hr[:, s] for _, (s, d, _) in live], 0) * 255.0
-        i2 = torch.cat([hr[:, d] for _, (s, d, _) in live], 0) * 255.0
-        f = self.flow_predictor(i1, i2, iters=iters, last_only=True)[-1]
+        # pair-major, then batch -- the order torch.cat([fr_s ...], 0) gives in the reference; RAFT's encoders run once per
+        # distinct frame (RAFT.forward_pairs), the pairing happens on the feature maps
+        src = [b * n + s for _, (s, d, _) in live for b in range(B)]
+        dst = [b * n + d for _, (s, d, _) in live for b in range(B)]
+        f = self.flow_predictor.forward_pairs(hr.reshape(B * n, 3, HH, WW) * 255.0, src, dst, iters=iters, last_only=True)[-1]
         f = ops.resize_bilinear(f, (H, W), False, H / HH)
         flow = torch.zeros(n_flows * B, 2, H, W, dtype=torch.float32, device=hr.device)
         for i, (k, (s, d, nz)) in enumerate(live):

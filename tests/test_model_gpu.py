@@ -158,6 +158,21 @@ def test_shell_ours44_one_timestamp_per_call_matches_reference():
     assert psnr(fake, ref) >= 60.0
 
 
+def test_raft_forward_pairs_is_bit_identical_to_forward(net):
+    """RAFT.forward_pairs (encoders once per distinct frame, pairing on the feature maps) == RAFT.forward on the expanded
+    pair batch (`Ours.py:544`, `Ours_44.py:505-506`), bit for bit."""
+    torch.manual_seed(0)
+    frames = torch.rand(3, 3, 128, 160, device="cuda") * 255.0
+    src, dst = [0, 1, 0, 2, 1], [1, 0, 2, 0, 1]
+    raft = net.flow_predictor
+    with torch.no_grad():
+        a = raft(frames[src], frames[dst], iters=3)
+        b = raft.forward_pairs(frames, src, dst, iters=3)
+    assert len(a) == len(b) == 3
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 def test_synth_input_planes_match_reference(net):
     """Post-splat normalisation + decoder input (Ours.py:811-844) through the splat of the predicted flow."""
     from motif_amd import ops
