@@ -5,9 +5,10 @@
 
 Reproduces what the reference's driver does around the model: zero-pad LQ frames to a multiple of 4
 (test.py:168-175), `scale` handling (176-182), `feed_data` -> `test()`, crop `fake_H[..., :H, :W]`,
-Y-channel PSNR per frame (212-238) and SSIM (245-249), log line.  Dataset readers are out of scope
-(SURVEY.md §2.1 row 14): clips come from `motif_amd.data.synthetic`; weights from `path.pretrain_model_G`
-when given, else the seeded key-hashed generator.  With `--launcher pytorch` clips are sharded over the
+Y-channel PSNR per frame (212-238) and SSIM (245-249), log line.  Clips come from `motif_amd.data.synthetic`, or with
+`--frames GT_ROOT [--lq LQ_ROOT]` from PNG folders through `motif_amd.data.folder_dataset` (the sample-dict contract of
+`data/Adobe_test_3.py`, pixels decoded on the GPU); weights from `path.pretrain_model_G` when given, else the seeded
+key-hashed generator.  With `--launcher pytorch` clips are sharded over the
 ranks (one process per GPU) and the per-frame PSNR vectors are gathered to rank 0.
 """
 import argparse
@@ -27,6 +28,9 @@ def main():
     ap.add_argument("--lr", type=int, nargs=2, default=[180, 320])
     ap.add_argument("--times", type=int, default=7)
     ap.add_argument("--ssim", action="store_true")
+    ap.add_argument("--frames", type=str, default=None, help="folder of HR PNG frame folders (<root>/<video>/<NNN>.png)")
+    ap.add_argument("--lq", type=str, default=None, help="folder of the LR frames (same layout); default: --frames")
+    ap.add_argument("--dataset-mode", choices=["mid", "arbitrary"], default="mid")
     args = ap.parse_args()
 
     from . import dist as mdist
@@ -54,9 +58,18 @@ def main():
         fill_state_dict(model.netG)
     scale = opt["scale"]
     psnrs = []
+    dataset = None
+    if args.frames:
+        from .data.folder_dataset import FolderClipDataset, collate_u8, decode_batch
+        dataset = FolderClipDataset({"dataroot_GT": args.frames, "dataroot_LQ": args.lq, "mode": args.dataset_mode})
+        args.clips = min(args.clips, len(dataset)) if args.clips else len(dataset)
     mine = mdist.shard_indices(args.clips)
     for clip in mine:
-        data = synthetic_sample(args.lr[0], args.lr[1], scale, args.times, seed=clip)
+        if dataset is not None:
+            data = decode_batch(collate_u8([dataset[clip]]), "cuda")
+            args.times = len(data["time"])
+        else:
+            data = synthetic_sample(args.lr[0], args.lr[1], scale, args.times, seed=clip)
         imgs_in = data["LQs"]
         b, n, c, h, w = imgs_in.size()
         h_n, w_n = int(4 * np.ceil(h / 4)), int(4 * np.ceil(w / 4))

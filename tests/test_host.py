@@ -379,6 +379,45 @@ def test_four_frame_generators_keys_and_define_g():
         networks.define_G(option.default_opt(which_model_G="TMNet"))
 
 
+def _write_video(root, name, n, h, w, seed):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.join(root, name), exist_ok=True)
+    frames = []
+    for i in range(n):
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        Image.fromarray(a).save(os.path.join(root, name, "%03d.png" % i))
+        frames.append(a)
+    return frames
+
+
+def test_folder_dataset_windows_times_and_u8_frames(tmp_path):
+    """FolderClipDataset = the clip windowing / GT selection / time stamps of Adobe_test_3.py:92-107,158-166 and
+    Adobe_arbitrary_test.py:161-168 on a PNG folder; frames come back as uint8 (decoded on the device later)."""
+    from motif_amd.data.folder_dataset import FolderClipDataset, collate_u8
+    gt_root, lq_root = str(tmp_path / "gt"), str(tmp_path / "lq")
+    gts = _write_video(gt_root, "walk", 9, 16, 24, 1)
+    lqs = _write_video(lq_root, "walk", 9, 4, 6, 2)
+    ds = FolderClipDataset({"dataroot_GT": gt_root, "dataroot_LQ": lq_root, "ref_num": 4, "interval": 1, "mode": "mid"})
+    assert len(ds) == 2 and ds.file_list[0] == ["walk/000.png", "walk/002.png", "walk/004.png", "walk/006.png"]
+    assert ds.gt_list[0] == ["walk/002.png", "walk/003.png", "walk/004.png"] and ds.file_list[1][0] == "walk/002.png"
+    s = ds[0]
+    assert s["LQs_u8"].shape == (4, 4, 6, 3) and s["LQs_u8"].dtype == torch.uint8 and s["GT_u8"].shape == (5, 16, 24, 3)
+    assert np.array_equal(s["LQs_u8"][1].numpy(), lqs[2]) and np.array_equal(s["GT_u8"][2].numpy(), gts[3])
+    assert np.array_equal(s["GT_u8"][0].numpy(), gts[2]) and np.array_equal(s["GT_u8"][4].numpy(), gts[4])
+    assert [float(t) for t in s["time"]] == [0.0, 0.5, 1.0]
+    ds2 = FolderClipDataset({"dataroot_GT": gt_root, "dataroot_LQ": lq_root, "ref_num": 4, "interval": 3, "mode": "arbitrary"})
+    assert len(ds2) == 0                                      # 9 frames are too few for interval 3 (needs 13)
+    gts = _write_video(gt_root, "city", 14, 16, 24, 3)
+    _write_video(lq_root, "city", 14, 4, 6, 4)
+    ds2 = FolderClipDataset({"dataroot_GT": gt_root, "dataroot_LQ": lq_root, "ref_num": 4, "interval": 3, "mode": "arbitrary", "videos": ["city"]})
+    assert len(ds2) == 1 and ds2.gt_list[0] == ["city/%03d.png" % i for i in range(4, 9)]
+    s = ds2[0]
+    assert s["GT_u8"].shape[0] == 7 and [round(float(t), 4) for t in s["time"]] == [0.0, 0.25, 0.5, 0.75, 1.0]
+    b = collate_u8([s, s])
+    assert b["LQs_u8"].shape == (2, 4, 4, 6, 3) and len(b["time"]) == 5 and b["time"][1].shape == (2, 1)
+
+
 def test_arithmetic_mode_option_plumbing():
     """network_G.mma / ops.set_mma select the contraction engines; default is the bf16x3 split."""
     from motif_amd import ops, option

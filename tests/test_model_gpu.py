@@ -557,3 +557,33 @@ def test_c3_crop_bf16_path_vs_oracle(mma_mode):
     print("c3 crop vs oracle: " + ", ".join("%s %.1f dB (dY %.4f)" % (k, v[0], v[1]) for k, v in res.items()))
     assert res["bf16"][0] >= 55.0 and res["bf16x3"][0] >= 60.0 and res["fp32"][0] >= 60.0, res
     assert max(v[1] for v in res.values()) < 0.05, res
+
+
+def test_folder_dataset_decodes_on_device_and_feeds_the_shell(tmp_path):
+    """a PNG folder through FolderClipDataset -> collate_u8 -> decode_batch (motif_frames_u8_to_f32) gives
+    exactly the tensors the reference's loader arithmetic gives (`astype(float32) / 255`, HWC -> CHW, Adobe_test_3.py:171-195), and
+    the dict drives VideoSRBaseModel.feed_data / test()."""
+    from PIL import Image
+    from motif_amd.data.folder_dataset import FolderClipDataset, collate_u8, decode_batch
+    from motif_amd.data.synthetic import smooth_video
+    from motif_amd.models import create_model
+    from motif_amd.option import default_opt
+    from motif_amd.utils.synth_weights import fill_state_dict
+    gt_root, lq_root = str(tmp_path / "gt"), str(tmp_path / "lq")
+    hr = (smooth_video(7, 128, 128, seed=3)[0] * 255.0).round().byte().permute(0, 2, 3, 1).numpy()       # [7,128,128,3]
+    lr = (smooth_video(7, 32, 32, seed=3)[0] * 255.0).round().byte().permute(0, 2, 3, 1).numpy()
+    for root, arr in ((gt_root, hr), (lq_root, lr)):
+        os.makedirs(os.path.join(root, "v"), exist_ok=True)
+        for i in range(7):
+            Image.fromarray(arr[i]).save(os.path.join(root, "v", "%03d.png" % i))
+    ds = FolderClipDataset({"dataroot_GT": gt_root, "dataroot_LQ": lq_root, "ref_num": 4, "interval": 1, "mode": "mid"})
+    batch = collate_u8([ds[0]])
+    data = decode_batch(batch, "cuda", scale=4)
+    ref_lq = torch.from_numpy(np.ascontiguousarray(np.transpose(lr[[0, 2, 4, 6]].astype(np.float32) / 255.0, (0, 3, 1, 2))))
+    assert torch.equal(data["LQs"][0].cpu(), ref_lq)
+    assert data["GT"].shape == (1, 5, 3, 128, 128) and data["scale"] == [[128], [128]]
+    model = create_model(default_opt(scale=4, gpu_ids=[0]))
+    fill_state_dict(model.netG)
+    model.feed_data(data)
+    model.test()
+    assert model.fake_H.shape == (3, 1, 3, 128, 128) and torch.isfinite(model.fake_H).all()
