@@ -238,7 +238,8 @@ int motif_reliability_pairs_fwd(const float* frames, long frame_stride, long bat
 /* InstanceNorm2d (eps 1e-5, no affine) + optional relu, optional residual: out = relu?(res + relu?(norm(x)))
  * mode 0: norm; 1: relu(norm); 2: relu(res + relu(norm))   (models/core/extractor.py:60-116,246-248) */
 int motif_instance_norm(const float* x, const float* res, float* out, int NC, int HW, int mode, void* stream);
-/* same, with a caller-owned fp64 workspace of NC*(2+64) doubles: large planes are split over many workgroups */
+/* same, with a caller-owned fp64 workspace of NC*(2+128) doubles: large planes are split over many workgroups, both moments
+ * in one pass over the tensor (fp64 sum and sum of squares) */
 int motif_instance_norm_ws(const float* x, const float* res, float* out, double* workspace, int NC, int HW, int mode, void* stream);
 int motif_avg_pool2(const float* in, float* out, int NC, int H, int W, void* stream);   /* F.avg_pool2d(x,2,2) */
 int motif_nchw_to_nhwc(const float* in, float* out, int N, int C, int HW, void* stream);

@@ -337,6 +337,45 @@ extern "C" int motif_instance_norm(const float* x, const float* res, float* out,
     return MOTIF_OK;
 }
 
+// One pass over the plane for both moments: sum and sum of squares accumulated in fp64 (x*x is exact in fp64, so
+// M2 = sum(x^2) - sum(x)^2 / n loses nothing an fp32 two-pass would keep) -- one read of the tensor less than
+// mean-pass + variance-pass.
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < nw; ++i) t += sh[i];
+    return t;
+}
+
+__global__ __launch_bounds__(256) void in_moments_kernel(const float* __restrict__ x, double* __restrict__ part, int HW, int S) {
+    __shared__ double sh[8];
+    const int plane = blockIdx.y, sb = blockIdx.x;
+    const long base = (long)plane * HW;
+    const int per = (HW + S - 1) / S, i0 = sb * per, i1 = min(HW, i0 + per);
+    double s = 0.0, q = 0.0;
+    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const double v = (double)x[base + i];
+        s += v;
+        q = fma(v, v, q);
+    }
+    const double ts = block_sum_d(s, sh), tq = block_sum_d(q, sh);
+    if (threadIdx.x == 0) { part[((long)plane * S + sb) * 2] = ts; part[((long)plane * S + sb) * 2 + 1] = tq; }
+}
+
+__global__ void in_moments_reduce_kernel(const double* __restrict__ part, double* __restrict__ stats, int NC, int S, int HW) {
+    const int plane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (plane >= NC) return;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < S; ++i) { s += part[((long)plane * S + i) * 2]; q += part[((long)plane * S + i) * 2 + 1]; }
+    const double m2 = q - s * s / (double)HW;
+    stats[plane * 2] = s;                      // in_apply_kernel: mean = stats[0] / HW, var = stats[1] / HW
+    stats[plane * 2 + 1] = m2 > 0.0 ? m2 : 0.0;
+}
+
 extern "C" int motif_instance_norm_ws(const float* x, const float* res, float* out, double* workspace, int NC, int HW, int mode, void* stream) {
     if (!x || !out || NC < 1 || HW < 1 || (mode == 2 && !res)) return MOTIF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -345,11 +384,9 @@ extern "C" int motif_instance_norm_ws(const float* x, const float* res, float* o
     if (!workspace || S < 2) return motif_instance_norm(x, res, out, NC, HW, mode, stream);
     if (S > 64) S = 64;
     double* stats = workspace;               // [NC][2]
-    double* part = workspace + 2L * NC;      // [NC][S]
-    for (int pass = 0; pass < 2; ++pass) {
-        in_partial_kernel<<<dim3(S, NC), 256, 0, s>>>(x, stats, part, HW, S, pass);
-        in_reduce_kernel<<<cdiv(NC, 64), 64, 0, s>>>(part, stats, NC, S, pass);
-    }
+    double* part = workspace + 2L * NC;      // [NC][S][2]
+    in_moments_kernel<<<dim3(S, NC), 256, 0, s>>>(x, part, HW, S);
+    in_moments_reduce_kernel<<<cdiv(NC, 64), 64, 0, s>>>(part, stats, NC, S, HW);
     in_apply_kernel<<<dim3(S, NC), 256, 0, s>>>(x, res, stats, out, HW, mode);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;

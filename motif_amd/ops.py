@@ -546,7 +546,7 @@ def instance_norm(x, mode=0, res=None):
     x = _c(x)
     n, c, h, w = x.shape
     out = torch.empty_like(x)
-    ws = workspace((n * c * 66) * 2, x.device, "instnorm")          # fp64 scratch, viewed as raw bytes by the library
+    ws = workspace((n * c * 130) * 2, x.device, "instnorm")         # fp64 scratch (NC*(2+128) doubles), raw bytes to the library
     check(lib.motif_instance_norm_ws(_p(x), _p(_c(res)) if res is not None else None, _p(out), ctypes.c_void_p(ws.data_ptr()),
                                      n * c, h * w, mode, _stream()), "motif_instance_norm_ws")
     return out
