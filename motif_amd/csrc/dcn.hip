@@ -515,6 +515,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     };
     auto geometry = [&]() {                              // from the requested offsets / mask
+        // pin the first use of the requested values HERE: left free, the compiler sinks part of this arithmetic into the
+        // previous iteration, right behind the requests, and parks a vmcnt(0) there (2.8 k cycles per chunk in the timeline)
+#pragma unroll
+        for (int j = 0; j < DF_PAIRS; ++j) asm volatile("" : "+v"(roh[j]), "+v"(row_[j]), "+v"(rom[j]));
 #pragma unroll
         for (int j = 0; j < DF_PAIRS; ++j) {
             const int tap = tap0 + 2 * j;
@@ -632,9 +636,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
             sample(cnext, (ch + 1) & 1);
             DT(6);
             if (newg && cnext / cpg + 1 < a.dg) geom_request(cnext / cpg + 1);
-            w_request(ch + 1, cur ^ 1);                       // weight buffer cur^1 was last read before the previous barrier
         }
         if (more2) win_request((ch + 2) * DF_CH);             // all requests AFTER the sampling: see the note on vmcnt order
+        if (more) w_request(ch + 1, cur ^ 1);                 // LDS-DMA last (hipcc drains vmcnt at the next ordinary load behind a
+                                                              // pending LDS-DMA); weight buffer cur^1 was last read before the previous barrier
         DT(1);
         {
             const float* colp = col0 + cur * DF_ROWS * NPX + wave * 32 + l31;
