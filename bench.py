@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=2,
                     help="clips in flight per GPU, each on its own HIP stream and model instance (default 2: the next clip's launches fill the "
                          "tails of the current one's, +6 %% throughput; 1 = strictly one clip at a time)")
+    ap.add_argument("--batch", type=int, default=1, help="clips per step (one forward over a batch of B independent clips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--launcher-selftest", action="store_true",
@@ -310,7 +311,7 @@ def main():
     # two distinct clips per rank, resident in HBM before the timed region
     clips = []
     for i in range(2):
-        s = synthetic_sample(h, w, a.scale, a.times, seed=100 * rank + i)
+        s = synthetic_sample(h, w, a.scale, a.times, seed=100 * rank + i, batch=a.batch)
         s = {"LQs": s["LQs"].cuda(), "GT": s["GT"][:, :1].cuda(), "time": [t.cuda() for t in s["time"]], "scale": s["scale"]}
         clips.append(s)
 
@@ -346,7 +347,7 @@ def main():
         return dt
 
     dt = timed(a.warmup, a.steps)
-    px = a.times * 1 * HH * WW
+    px = a.times * a.batch * HH * WW
     line = {
         "metric": "HR pixels/sec", "value": world * a.steps * px / dt, "unit": "px/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True,
@@ -354,8 +355,8 @@ def main():
         "config": {"arithmetic": ("fp32-equivalent on the bf16 matrix cores: every fp32 operand = 3 exact bf16 parts, 6 products, fp32 "
                                   "accumulate (3x3 convolutions, fused DCN and the three MLPs); everything else fp32" if a.mma == "bf16x3"
                                   else "fp32 MFMA (v_mfma_f32_32x32x2_f32) and fp32 VALU"),
-                   "workload": "c2: 4-frame %dx%d LR clip -> %dx%d (x%d spatial), x%dt = %d timestamps, B=1 clip per step per GPU, "
-                               "RAFT-small iters=4, seeded key-hashed weights" % (h, w, HH, WW, a.scale, a.times - 1, a.times),
+                   "workload": "c2: 4-frame %dx%d LR clip -> %dx%d (x%d spatial), x%dt = %d timestamps, B=%d clip(s) per step per GPU, "
+                               "RAFT-small iters=4, seeded key-hashed weights" % (h, w, HH, WW, a.scale, a.times - 1, a.times, a.batch),
                    "parallelism": "clips sharded per GPU (dp%d), uint8 frame gather to rank 0" % world,
                    "clips_in_flight_per_gpu": a.streams},
     }
