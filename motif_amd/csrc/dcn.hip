@@ -706,6 +706,7 @@ extern "C" int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, co
     if (mma != 0 && mma != 6) return MOTIF_EINVAL;
     if (deformable_groups < 1 || C % deformable_groups || (C / deformable_groups) % DF_CH || (long)H * W >= (1L << 30)) return MOTIF_ELIMIT;
     if (act != MOTIF_ACT_NONE && act != MOTIF_ACT_LRELU && act != MOTIF_ACT_RELU) return MOTIF_ELIMIT;
+    if ((long)H * W < 2) return MOTIF_ELIMIT;        // the corner-pair loads of the non-window form need two elements per plane
     const long HW = (long)H * W;
     DcnFusedArgs a;
     for (int i = 0; i < 4; ++i) {

@@ -587,3 +587,36 @@ def test_folder_dataset_decodes_on_device_and_feeds_the_shell(tmp_path):
     model.feed_data(data)
     model.test()
     assert model.fake_H.shape == (3, 1, 3, 128, 128) and torch.isfinite(model.fake_H).all()
+
+
+def test_two_clips_in_flight_equal_the_serial_renders():
+    """bench.py's default: two clips in flight on two HIP streams / model instances (plus each model's RAFT side stream).  Each
+    concurrent render must equal the same clip rendered alone, bit for bit in the t-independent stages and to fp32-atomics noise
+    (far-source fallback only) in the frames -- no kernel may depend on what runs beside it (cf. dcn.hip's launch comment)."""
+    from motif_amd.data.synthetic import synthetic_sample
+    from motif_amd.models import create_model
+    from motif_amd.option import default_opt
+    from motif_amd.utils.synth_weights import fill_state_dict
+    models, streams, clips = [], [torch.cuda.Stream(), torch.cuda.Stream()], []
+    for i in range(2):
+        m = create_model(default_opt(scale=4, gpu_ids=[0]))
+        fill_state_dict(m.netG)
+        models.append(m)
+        s = synthetic_sample(180, 320, 4, 7, seed=50 + i)
+        clips.append({"LQs": s["LQs"].cuda(), "GT": s["GT"][:, :1].cuda(), "time": [t.cuda() for t in s["time"]], "scale": s["scale"]})
+    serial = []
+    for m, c in zip(models, clips):
+        m.feed_data(c)
+        m.test()
+        serial.append((m.fake_H.clone(), m.netG._cache["feat"].clone(), m.netG._cache["flow"].clone()))
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for m, c, st in zip(models, clips, streams):
+            with torch.cuda.stream(st):
+                m.feed_data(c)
+                m.test()
+        torch.cuda.synchronize()
+        for m, (out, feat, flow) in zip(models, serial):
+            assert torch.equal(m.netG._cache["feat"], feat), "encoder output changed under concurrency (rep %d)" % rep
+            assert torch.equal(m.netG._cache["flow"], flow), "RAFT flow changed under concurrency (rep %d)" % rep
+            assert float((m.fake_H - out).abs().max()) <= 1e-6
