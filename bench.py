@@ -369,8 +369,11 @@ def main():
                    "clips_in_flight_per_gpu": a.streams},
     }
     if world > 1:
-        line["collective"] = {"backend": dist.get_backend(), "library": "RCCL (torch.distributed 'nccl' on ROCm)",
-                              "version": ".".join(str(v) for v in torch.cuda.nccl.version())}
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:                       # informational only
+            ver = "unknown (%s)" % type(e).__name__
+        line["collective"] = {"backend": dist.get_backend(), "library": "RCCL (torch.distributed 'nccl' on ROCm)", "version": ver}
     if a.mma == "bf16x3" and not a.no_fp32_leg:
         # the same job on the fp32 MFMA (all ranks, same barriers), reported next to the headline value
         from motif_amd import ops

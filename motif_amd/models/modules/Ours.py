@@ -366,6 +366,19 @@ class LunaTokis(nn.Module):
         self._weights_epoch = 0
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._bump_weights_epoch())
 
+    def load_raft_checkpoint(self, path):
+        """What `Ours.py:423-430` does at construction with its hard-coded file: load `torch.load(path)['model']`, strip the
+        'flow_predictor.' prefix from every key -- the loop deletes every key it visits after re-inserting it under the stripped
+        name, so a key WITHOUT the prefix is deleted too -- and load strictly into `flow_predictor`.
+        The reference's path is not in the repository (`.MISSING_LARGE_BLOBS`); here it is optional and explicit."""
+        ckpt = torch.load(path, map_location="cpu")["model"]
+        for key in list(ckpt.keys()):
+            tmp = key.replace("flow_predictor.", "")
+            ckpt[tmp] = ckpt[key]
+            del ckpt[key]
+        self.flow_predictor.load_state_dict(ckpt, strict=True)
+        self._bump_weights_epoch()
+
     # ----------------------------------------------------------------------------- t-independent stage
     def _flow_encoder(self, x):
         fp = self.flow_process

@@ -418,6 +418,25 @@ def test_folder_dataset_windows_times_and_u8_frames(tmp_path):
     assert b["LQs_u8"].shape == (2, 4, 4, 6, 3) and len(b["time"]) == 5 and b["time"][1].shape == (2, 1)
 
 
+def test_raft_checkpoint_ingestion_follows_the_reference_rename_loop(tmp_path):
+    """`LunaTokis.load_raft_checkpoint` = Ours.py:423-430: {'model': {'flow_predictor.<key>': tensor}} loads strictly; a file whose
+    keys lack the prefix ends up EMPTY after the reference's rename-and-delete loop and therefore fails the strict load."""
+    from motif_amd.models.modules.Ours import LunaTokis
+    from motif_amd.utils.synth_weights import synth_tensor
+    net = LunaTokis()
+    sd = net.flow_predictor.state_dict()
+    good = {"model": {"flow_predictor." + k: synth_tensor("flow_predictor." + k, v) for k, v in sd.items()}}
+    torch.save(good, tmp_path / "raft.pth")
+    epoch = net._weights_epoch
+    net.load_raft_checkpoint(str(tmp_path / "raft.pth"))
+    assert net._weights_epoch > epoch
+    k0 = next(iter(sd))
+    assert torch.equal(net.flow_predictor.state_dict()[k0], good["model"]["flow_predictor." + k0])
+    torch.save({"model": dict(sd)}, tmp_path / "bare.pth")
+    with pytest.raises(RuntimeError):
+        net.load_raft_checkpoint(str(tmp_path / "bare.pth"))
+
+
 def test_arithmetic_mode_option_plumbing():
     """network_G.mma / ops.set_mma select the contraction engines; default is the bf16x3 split."""
     from motif_amd import ops, option
