@@ -464,33 +464,46 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    // window staging plan (chunk invariant): unit u = (channel, window row, 4-pixel group) -> global offset within a plane
-    int woff[NWL];
+    // window staging plan (chunk invariant).  LDS layout of a window: [pixel][4 channels] -- the four channels of a corner are ONE
+    // ds_read_b128 (4 reads per sample instead of 8 two-dword reads; sampling is LDS-pipeline bound).  A staging thread owns one
+    // (window row, 4-pixel group): it loads that group from the chunk's four planes (16-byte coalesced), transposes 4x4 in
+    // registers and stores four pixel quads.  Requests are UNCONDITIONAL (surplus threads re-read unit 0 and skip only the LDS
+    // store): a predicated load sits in its own exec-mask region, and at such a region's entry hipcc parks a conservative
+    // vmcnt(0) -- which waits for the offset / mask requests issued a moment earlier (2.8 k cycles per chunk in the first timeline).
+    constexpr int NWG = WSZ / 4, NWS = (NWG + NT - 1) / NT;      // 4-pixel groups of a window, per thread
+    int woff[NWS], wdst[NWS];
+    bool wlive[NWS];
 #pragma unroll
-    for (int k = 0; k < NWL; ++k) {
+    for (int k = 0; k < NWS; ++k) {
         const int u = tid + NT * k;
-        woff[k] = -1;
-        if (u < NWU) {
-            const int c = u / (WSZ / 4), r = u - c * (WSZ / 4);
-            const int wy = r / (WWD / 4), wu = r - wy * (WWD / 4);
-            int gy = wy0 + wy, gx = wx0 + 4 * wu;
-            gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);                         // clamped: finite image data everywhere,
-            gx = gx < 0 ? 0 : (gx > W - 4 ? W - 4 : gx);                         // invalid corners carry weight 0
-            woff[k] = c * (int)HW + gy * W + gx;
-        }
+        wlive[k] = u < NWG;
+        const int uc = wlive[k] ? u : 0;
+        const int wy = uc / (WWD / 4), wu = uc - wy * (WWD / 4);
+        int gy = wy0 + wy, gx = wx0 + 4 * wu;
+        gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);                             // clamped: finite image data everywhere,
+        gx = gx < 0 ? 0 : (gx > W - 4 ? W - 4 : gx);                             // invalid corners carry weight 0
+        woff[k] = gy * W + gx;
+        wdst[k] = (wy * WWD + 4 * wu) * DF_CH;                                   // float index of the group's first pixel quad
     }
-    f32x4 wreg[NWL];
+    f32x4 wreg[NWS][DF_CH];
     auto win_request = [&](int c0) {
         const float* base = imb + (long)c0 * HW;
 #pragma unroll
-        for (int k = 0; k < NWL; ++k)
-            if (woff[k] >= 0) wreg[k] = *(const f32x4*)(base + woff[k]);
+        for (int k = 0; k < NWS; ++k)
+#pragma unroll
+            for (int cl = 0; cl < DF_CH; ++cl) wreg[k][cl] = *(const f32x4*)(base + (long)cl * HW + woff[k]);
     };
     auto win_commit = [&](int buf) {
-        f32x4* dst = (f32x4*)(win0 + buf * DF_CH * WSZ);
+        float* dst = win0 + buf * DF_CH * WSZ;
 #pragma unroll
-        for (int k = 0; k < NWL; ++k)
-            if (woff[k] >= 0) dst[tid + NT * k] = wreg[k];
+        for (int k = 0; k < NWS; ++k)
+            if (wlive[k]) {
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    const f32x4 q = {wreg[k][0][px], wreg[k][1][px], wreg[k][2][px], wreg[k][3][px]};
+                    *(f32x4*)(dst + wdst[k] + 4 * px) = q;
+                }
+            }
     };
 
     // geometry of the current deformable group, per (pixel, tap) pair of this thread: window offset of the top-left corner
@@ -547,23 +560,33 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
         bool far = false;
         // all 40 LDS read pairs of the chunk are issued back to back (scheduling fences: left alone the compiler issues
         // them four at a time with a full LDS round trip each), then blended
-        float t[DF_PAIRS][DF_CH][4];
+        // [pair][corner] x 4 channels, in two batches (3 + 2 pairs) so that a batch's 12 / 8 reads are in flight together
+        // without pushing the kernel past 256 VGPRs
 #pragma unroll
-        for (int j = 0; j < DF_PAIRS; ++j) {
-            const int lt = glt[j] >= 0 ? glt[j] : 0;
-            far |= glt[j] < 0;
+        for (int j0 = 0; j0 < DF_PAIRS; j0 += 3) {
+            f32x4 t[3][4];
 #pragma unroll
-            for (int cl = 0; cl < DF_CH; ++cl) {
-                const float* q = wb + cl * WSZ + lt;
-                t[j][cl][0] = q[0]; t[j][cl][1] = q[1]; t[j][cl][2] = q[WWD]; t[j][cl][3] = q[WWD + 1];
+            for (int jj = 0; jj < 3; ++jj) {
+                const int j = j0 + jj;
+                if (j < DF_PAIRS) {
+                    const int lt = glt[j] >= 0 ? glt[j] : 0;
+                    far |= glt[j] < 0;
+                    const f32x4* q = (const f32x4*)wb + lt;
+                    t[jj][0] = q[0]; t[jj][1] = q[1]; t[jj][2] = q[WWD]; t[jj][3] = q[WWD + 1];
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                const int j = j0 + jj;
+                if (j < DF_PAIRS) {
+#pragma unroll
+                    for (int cl = 0; cl < DF_CH; ++cl)
+                        val[j][cl] = (gw1[j] * t[jj][0][cl] + gw2[j] * t[jj][1][cl] + gw3[j] * t[jj][2][cl] + gw4[j] * t[jj][3][cl]) * gm[j];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < DF_PAIRS; ++j)
-#pragma unroll
-            for (int cl = 0; cl < DF_CH; ++cl)
-                val[j][cl] = (gw1[j] * t[j][cl][0] + gw2[j] * t[j][cl][1] + gw3[j] * t[j][cl][2] + gw4[j] * t[j][cl][3]) * gm[j];
         if (__any(far)) {                                // some sample of this wave left the window: predicated global loads
 #pragma unroll
             for (int j = 0; j < DF_PAIRS; ++j) {
@@ -594,14 +617,17 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
     constexpr int NWR = (WCH / 4 + NT - 1) / NT;
     static_assert((WCH / 4) % 64 == 0, "a chunk's weights are whole 1 KiB wave pieces");
     auto w_request = [&](int chunk, int buf) {           // LDS-DMA: wave-uniform LDS base + lane * 16, linear copy
+        // the chunk = 18 pieces of 1 KiB; every wave copies NWR pieces unconditionally -- where there are more wave slots than
+        // pieces, the surplus slots copy one of the last pieces again (same bytes to the same place) instead of branching
+        constexpr int NPC = WCH / 4 / 64;
         const f32x4* src = (const f32x4*)(wbase + (long)chunk * WCH);
         f32x4* w4 = (f32x4*)(wl0 + buf * WCH);
 #pragma unroll
         for (int k = 0; k < NWR; ++k) {
-            const int i = tid + NT * k;
-            if (i < WCH / 4)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i),
-                                                 (__attribute__((address_space(3))) void*)(w4 + (i - lane)), 16, 0, 0);
+            int piece = wave + WAVES * k;
+            if (piece >= NPC) piece = NPC - 1 - (wave & 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(w4 + piece * 64), 16, 0, 0);
         }
     };
 
@@ -628,16 +654,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
     int cur = 0;
     for (int ch = 0; ch < nchunks; ++ch) {
         const bool more = ch + 1 < nchunks, more2 = ch + 2 < nchunks;
-        if (more) {
-            const int cnext = (ch + 1) * DF_CH;
-            const bool newg = cnext % cpg == 0;               // next chunk starts a new deformable group: its offsets / mask
-            if (newg) geometry();                             // were requested a whole group ago
-            DT(5);
-            sample(cnext, (ch + 1) & 1);
-            DT(6);
-            if (newg && cnext / cpg + 1 < a.dg) geom_request(cnext / cpg + 1);
-        }
-        if (more2) win_request((ch + 2) * DF_CH);             // all requests AFTER the sampling: see the note on vmcnt order
+        const int cnext = (ch + 1) * DF_CH;
+        const bool newg = more && cnext % cpg == 0;           // next chunk starts a new deformable group: its offsets / mask
+        if (newg) geometry();                                 // were requested a whole group ago (and drained at the last barrier)
+        DT(5);
+        if (more2) win_request((ch + 2) * DF_CH);             // window two chunks ahead: sampling + MFMA stretch cover its latency
+        if (more) sample(cnext, (ch + 1) & 1);                // LDS only (plus the rare fallback)
+        DT(6);
+        if (newg && cnext / cpg + 1 < a.dg) geom_request(cnext / cpg + 1);
         if (more) w_request(ch + 1, cur ^ 1);                 // LDS-DMA last (hipcc drains vmcnt at the next ordinary load behind a
                                                               // pending LDS-DMA); weight buffer cur^1 was last read before the previous barrier
         DT(1);
