@@ -52,20 +52,32 @@ __global__ __launch_bounds__(256) void raft_lookup_kernel(LookupArgs a) {
         if (C == 128) {
             const f32x4* f1 = (const f32x4*)(a.fmap1 + ((long)b * HW1 + q) * 128) + sub * 2;
             const f32x4 u0 = f1[0], u1 = f1[1];
-#pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int nb = it * 4 + grp;                            // neighbour handled by this 16-lane row
-                const int h2 = (int)fy - 3 + (nb >> 3), w2 = (int)fx - 3 + (nb & 7);
-                float part = 0.f;
-                if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
-                    const f32x4* f2 = (const f32x4*)(fmap2 + (((long)b * H2 + h2) * W2 + w2) * 128) + sub * 2;
-                    const f32x4 v0 = f2[0], v1 = f2[1];
-                    float s0 = u0[0] * v0[0], s1 = u0[1] * v0[1], s2 = u0[2] * v0[2], s3 = u0[3] * v0[3];
-                    s0 = fmaf(u1[0], v1[0], s0); s1 = fmaf(u1[1], v1[1], s1); s2 = fmaf(u1[2], v1[2], s2); s3 = fmaf(u1[3], v1[3], s3);
-                    part = (s0 + s1) + (s2 + s3);
+            // the 16 neighbour rows of this 16-lane group in two batches of 8: UNCONDITIONAL loads from the clamped position
+            // (out-of-range neighbours are zeroed afterwards), all of a batch in flight together -- predicated loads put each
+            // one in its own exec-mask region with a full memory round trip per neighbour
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                f32x4 v0[8], v1[8];
+                bool okn[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int nb = (hb * 8 + i) * 4 + grp;                  // neighbour handled by this 16-lane row
+                    const int h2 = (int)fy - 3 + (nb >> 3), w2 = (int)fx - 3 + (nb & 7);
+                    okn[i] = h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2;
+                    const int hc = h2 < 0 ? 0 : (h2 > H2 - 1 ? H2 - 1 : h2), wc = w2 < 0 ? 0 : (w2 > W2 - 1 ? W2 - 1 : w2);
+                    const f32x4* f2 = (const f32x4*)(fmap2 + (((long)b * H2 + hc) * W2 + wc) * 128) + sub * 2;
+                    v0[i] = f2[0]; v1[i] = f2[1];
                 }
-                part = row16_sum(part);
-                if (sub == 15) dots[wave][nb] = part;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int nb = (hb * 8 + i) * 4 + grp;
+                    float s0 = u0[0] * v0[i][0], s1 = u0[1] * v0[i][1], s2 = u0[2] * v0[i][2], s3 = u0[3] * v0[i][3];
+                    s0 = fmaf(u1[0], v1[i][0], s0); s1 = fmaf(u1[1], v1[i][1], s1); s2 = fmaf(u1[2], v1[i][2], s2); s3 = fmaf(u1[3], v1[i][3], s3);
+                    float part = okn[i] ? (s0 + s1) + (s2 + s3) : 0.f;
+                    part = row16_sum(part);
+                    if (sub == 15) dots[wave][nb] = part;
+                }
             }
             s = dots[wave][lane];                                       // same wave wrote it: LDS ops of a wave are ordered
         } else {
