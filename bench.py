@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="clips per step (one forward over a batch of B independent clips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend: nccl = RCCL over xGMI (the product); gloo = plumbing runs where there are fewer GPUs "
+                         "than ranks (ranks then share GPUs, the uint8 gather is staged through the host)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU/gloo plumbing test of the --gpus launcher: N ranks, barrier, gather, one JSON line; no GPU work")
     return ap.parse_args()
@@ -287,10 +290,17 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU route")
+    ndev = torch.cuda.device_count()
+    if local >= ndev and a.backend == "nccl":
+        raise SystemExit("rank %d: only %d GPU(s) visible; RCCL needs one GPU per rank (use --backend gloo for a plumbing run)" % (rank, ndev))
+    local = local % ndev
     torch.cuda.set_device(local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend="gloo")
     from motif_amd import dist as mdist
     from motif_amd.data.synthetic import synthetic_sample
     from motif_amd.models import create_model
@@ -341,7 +351,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            t = torch.tensor([dt], device="cuda" if a.backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -373,7 +383,8 @@ def main():
             ver = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception as e:                       # informational only
             ver = "unknown (%s)" % type(e).__name__
-        line["collective"] = {"backend": dist.get_backend(), "library": "RCCL (torch.distributed 'nccl' on ROCm)", "version": ver}
+        line["collective"] = {"backend": dist.get_backend(), "version": ver,
+                              "library": "RCCL (torch.distributed 'nccl' on ROCm)" if a.backend == "nccl" else "gloo (plumbing run, host-staged gather)"}
     if a.mma == "bf16x3" and not a.no_fp32_leg:
         # the same job on the fp32 MFMA (all ranks, same barriers), reported next to the headline value
         from motif_amd import ops

@@ -44,11 +44,18 @@ def frames_to_uint8(frames, round_half_even=True, swap_rb=False):
     return u8.view(lead + (h, w, 3))
 
 
+def _wire(t):
+    """The gloo backend (CPU tests; `bench.py --backend gloo` plumbing runs) gathers host tensors only: stage device tensors
+    through the host there.  RCCL ("nccl") takes the device tensors as they are."""
+    return t.cpu() if (t.is_cuda and dist.get_backend() == "gloo") else t
+
+
 def gather_to_rank0(local, n_items, dst=0):
     """local: tensor [n_local, ...] holding this rank's items in shard order.  Returns on rank `dst` the
     tensor [n_items, ...] in global clip order, elsewhere None.  Ranks may hold unequal counts."""
     if not is_dist():
         return local
+    local = _wire(local)
     rank, w = world()
     per = (n_items + w - 1) // w
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -81,7 +88,12 @@ def band_of(n_rows, rank=None, world_size=None, align=1):
 def allreduce_max(value):
     """MAX over ranks of a scalar tensor (identity without a process group)."""
     if is_dist():
-        dist.all_reduce(value, op=dist.ReduceOp.MAX)
+        if value.is_cuda and dist.get_backend() == "gloo":
+            host = value.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX)
+            value.copy_(host)
+        else:
+            dist.all_reduce(value, op=dist.ReduceOp.MAX)
     return value
 
 
@@ -90,6 +102,7 @@ def gather_bands_to_rank0(local, n_rows, dst=0, align=1, row_dim=-3):
     order ([..., n_rows, W, 3]), else None."""
     if not is_dist():
         return local
+    local = _wire(local)
     rank, w = world()
     rows = [band_of(n_rows, r, w, align) for r in range(w)]
     mx = max(b - a for a, b in rows)
