@@ -1,0 +1,63 @@
+"""Two-rank runs of the multi-GPU drivers with the REAL kernels (both ranks share the test box's one GPU; collectives over gloo
+with host-staged gathers -- RCCL needs one GPU per rank): the frames rank 0 receives must equal a single-process render.
+The N-GPU RCCL job itself is the driver's SCALE run."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from motif_amd import dist as md
+from motif_amd.data.synthetic import synthetic_sample
+from motif_amd.models.modules.Ours import LunaTokis
+from motif_amd.utils.synth_weights import fill_state_dict
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+r, w = md.world()
+net = fill_state_dict(LunaTokis()).cuda().eval()
+s = synthetic_sample(64, 96, 4, 5, seed=11)
+x = s["LQs"].cuda(); times = [t.cuda() for t in s["time"]]; scale = s["scale"]
+HH, WW = 256, 384
+
+def serial():
+    net.band = None; net.clear_cache(); outs = []
+    with torch.no_grad():
+        for l in range(0, 5, 3):
+            outs.append(net(x, None, times[l:l + 3], scale, use_GT=False, iter=4)[0])
+    return md.frames_to_uint8(torch.cat(outs, 0)).cpu()              # [T,B,HH,WW,3]
+
+ref = serial()
+net.clear_cache()
+for share in ("replicate", "broadcast"):
+    out = md.render_clip_by_timestamps(net, x, times, scale, share=share)
+    if r == 0:
+        assert out.shape == ref.shape and torch.equal(out.cpu(), ref), "timestamp split (%%s) differs from the serial render" %% share
+    net.clear_cache()
+out = md.render_clip_tiled(net, x, times, scale, halo=32)
+if r == 0:
+    assert torch.equal(out.cpu(), ref), "exact row-band mode differs from the serial render"
+net.clear_cache()
+out = md.render_clip_tiled(net, x, times, scale, halo=32, lr_halo=16)
+if r == 0:
+    mse = float(((out.cpu().double() - ref.double()) ** 2).mean()) / 255.0 ** 2
+    psnr = 99.0 if mse == 0 else 10 * np.log10(1.0 / mse)
+    assert psnr >= 45.0, psnr
+    print("DIST_GPU_OK cropped-mode PSNR %%.1f dB" %% psnr)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_drivers_with_real_kernels(tmp_path):
+    script = tmp_path / "d.py"
+    script.write_text(SCRIPT % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29571", str(script)], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
