@@ -112,17 +112,22 @@ class PCD_Align(nn.Module):
 
 def easy_pcd_multi(mods, f1s, f2s):
     """Easy_PCD.forward (`Ours.py:188-210`) for P <= 2 modules at once -> stacked [P,N,C,H,W]."""
-    b = f1s[0].shape[0]
-    l1 = [torch.stack([f1, f2], dim=1).flatten(0, 1) for f1, f2 in zip(f1s, f2s)]     # (b, n) order, Ours.py:192-194
-    l2 = convm([m.fea_L2_conv1 for m in mods], l1, act=LRELU)
-    l2 = convm([m.fea_L2_conv2 for m in mods], list(l2), act=LRELU)
-    l3 = convm([m.fea_L3_conv1 for m in mods], list(l2), act=LRELU)
-    l3 = convm([m.fea_L3_conv2 for m in mods], list(l3), act=LRELU)
-    pick = lambda t, i: t.view(b, 2, *t.shape[1:])[:, i]                              # batch-strided planar views
+    # Ours.py:192-194 stacks (f1, f2) into one batch for the two pyramid convolutions; here the two features of a module are
+    # two PROBLEMS of the multi-problem launch with the same weights -- no stacked copy, and the level tensors come back
+    # already separated for the alignment
+    n = len(mods)
+    if 2 * n > 4:
+        raise ValueError("easy_pcd_multi takes at most two modules (4 problems per launch)")
+    twice = lambda name: [getattr(m, name) for m in mods for _ in (0, 1)]
+    l1 = [f for f1, f2 in zip(f1s, f2s) for f in (f1, f2)]                             # problem 2*pi + {0: f1, 1: f2}
+    l2 = convm(twice("fea_L2_conv1"), l1, act=LRELU)
+    l2 = convm(twice("fea_L2_conv2"), list(l2), act=LRELU)
+    l3 = convm(twice("fea_L3_conv1"), list(l2), act=LRELU)
+    l3 = convm(twice("fea_L3_conv2"), list(l3), act=LRELU)
     problems = []
     for pi, m in enumerate(mods):
-        fa = [pick(l1[pi], 0), pick(l2[pi], 0), pick(l3[pi], 0)]
-        fb = [pick(l1[pi], 1), pick(l2[pi], 1), pick(l3[pi], 1)]
+        fa = [l1[2 * pi], l2[2 * pi], l3[2 * pi]]
+        fb = [l1[2 * pi + 1], l2[2 * pi + 1], l3[2 * pi + 1]]
         problems += [(m.pcd_align, "1", fa, fb), (m.pcd_align, "2", fb, fa)]
     y = pcd_align_multi(problems)
     return convm([m.fusion for m in mods], [y[2 * i] for i in range(len(mods))], [y[2 * i + 1] for i in range(len(mods))])
