@@ -620,3 +620,29 @@ def test_two_clips_in_flight_equal_the_serial_renders():
             assert torch.equal(m.netG._cache["feat"], feat), "encoder output changed under concurrency (rep %d)" % rep
             assert torch.equal(m.netG._cache["flow"], flow), "RAFT flow changed under concurrency (rep %d)" % rep
             assert float((m.fake_H - out).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("which", ["Ours_4", "Ours_44"])
+def test_four_frame_generators_full_size_properties(which, mma_mode):
+    """The 4-frame generators at BASELINE config-2 size (180x320 -> 720x1280) through the shell: shapes, range, finiteness, and
+    for Ours_44 the one-timestamp-per-call branch with the residual picked by int(t*6) (t = 5/6 -> feature 4, t = 1 -> 6)."""
+    if mma_mode != "bf16x3":
+        pytest.skip("one engine is enough at this size")
+    from motif_amd.data.synthetic import synthetic_sample
+    from motif_amd.models import create_model
+    from motif_amd.option import default_opt
+    from motif_amd.utils.synth_weights import fill_state_dict
+    model = create_model(default_opt(scale=4, gpu_ids=[0], which_model_G=which))
+    fill_state_dict(model.netG)
+    s = synthetic_sample(180, 320, 4, 7)
+    data = {"LQs": s["LQs"].cuda(), "GT": s["GT"][:, :1].cuda(), "time": [s["time"][i].cuda() for i in (0, 3, 5, 6)]}
+    if which != "Ours_44":
+        data["scale"] = s["scale"]
+    model.feed_data(data)
+    model.test()
+    out = model.fake_H
+    assert out.shape == (4, 1, 3, 720, 1280) and torch.isfinite(out).all() and float(out.min()) >= 0 and float(out.max()) <= 1
+    assert float((out[0] - out[3]).abs().max()) > 1e-3                       # t = 0 and t = 1 are different frames
+    if which == "Ours_44":
+        # residual features picked over the four calls (t = 0, 3/6, 5/6, 1): the fp32 product 5/6 * 6 truncates to 4
+        assert sorted(k[1] for k in model.netG._cache if isinstance(k, tuple) and k[0] == "synth_l0") == [0, 3, 4, 6]
