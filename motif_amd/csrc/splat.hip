@@ -10,6 +10,13 @@
 // as (SE - o) products, bounds test >=0 & <size, addend = (value*e^z) rounded, then * weight rounded.
 #include "common.h"
 
+// The reference forms its flow tensor with separately rounded torch multiplies (Ours.py:794) and its kernel then ADDS the pixel
+// index (softsplat_cp.py:27-28).  hipcc contracts a*b+c into one FMA by default, which rounds once and can move a coordinate
+// across an integer -- a different floor(), i.e. other target cells and another count plane (caught by
+// tests/test_kernels_gpu.py::test_splat_motif_rounds_the_flow_before_adding_the_pixel_index at scale ratio 3; exact products
+// at power-of-two ratios hid it).  Every FMA in this file is an explicit fmaf.
+#pragma clang fp contract(off)
+
 struct Corners {
     int x0, y0;
     float wnw, wne, wsw, wse;

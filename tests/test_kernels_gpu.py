@@ -578,6 +578,99 @@ def test_splat_motif_keeps_dynamic_range_of_low_reliability_sources():
     close(out[hit_only_tiny.expand_as(out)], out_ref[hit_only_tiny.expand_as(out)], 3e-5, 3e-5, "normalised output, unreliable-only cells")
 
 
+def _flow_values_where_fma_and_rounded_product_disagree(sr, x, n=400000, seed=0):
+    """pred values p for which floor(x + fl(fl(20 p) sr)) != floor(fma(fl(20 p), sr, x)): the reference multiplies its flow
+    tensor out first (Ours.py:794) and the kernel adds the index afterwards (softsplat_cp.py:27-28)."""
+    rng = np.random.default_rng(seed)
+    k = rng.integers(1, 6, n)
+    p = ((k + rng.uniform(-1.2e-6, 1.2e-6, n)) / (20.0 * sr)).astype(np.float32)
+    q = (p * np.float32(20.0)).astype(np.float32)
+    sep = (np.float32(x) + (q * np.float32(sr)).astype(np.float32)).astype(np.float32)
+    fused = (np.float64(x) + q.astype(np.float64) * np.float64(np.float32(sr))).astype(np.float32)
+    return np.unique(p[np.floor(sep) != np.floor(fused)])
+
+
+def test_splat_motif_rounds_the_flow_before_adding_the_pixel_index():
+    """Scale ratio 3 (not a power of two): the flow product must be rounded to fp32 BEFORE the pixel index is added, as
+    the reference's separate torch multiplies do -- a fused multiply-add moves some targets across an integer, i.e. to
+    other cells.  Sources crafted to sit on such boundaries; the count plane (one per footprint corner) must be exact."""
+    from oracle import native
+    from motif_amd import ops
+    B, N, H, W, s = 1, 1, 16, 24, 3
+    HH, WW = H * s, W * s
+    cases = [(x, v) for x in range(2, 40) for v in _flow_values_where_fma_and_rounded_product_disagree(float(s), x, n=100000)]
+    assert len(cases) >= 40, "search found too few boundary cases"
+    iy, ix, _, _ = _tables(H, W, HH, WW)
+    imnet_out = rnd(2 * B, 64, HH, WW, seed=1)
+    feat_lr = rnd(2 * B, 64, H, W, seed=2)
+    pred = rnd(2 * B * N, 3, HH, WW, seed=3, scale=0.02)
+    for i, (x, v) in enumerate(cases):
+        pred[0, 0, 2 + i % 40, x] = float(v)
+        pred[0, 1, 2 + i % 40, x] = 0.0
+    alpha = torch.tensor([-20.0])
+    flow = pred[:, :2] * 20.0 * (HH / H)
+    ez = (F.relu(pred[:, 2:3]) * alpha).exp()
+    scnt = native.splat(torch.ones_like(ez), flow, "count").reshape(2, B * N, 1, HH, WW).sum(0)
+    acc = ops.splat_motif(imnet_out.to(dev()), pred.to(dev()), feat_lr.to(dev()), iy, ix, alpha.to(dev()), HH / H, B, N, HH, WW).cpu()
+    assert torch.equal(acc[:, 132:133], scnt), "count plane differs: flow not rounded before the index add"
+
+
+def test_splat_motif_sinks_and_overfull_tiles():
+    """The owner-computes tiles against the kernel text on flows that stress their bookkeeping: a point sink (hundreds of
+    footprints on one cell), every source within 14 px of a tile landing inside it (7.7 k sources for 1 k cells), motion
+    boundaries, a far source.  Count exact, max and sums within 3e-5, two runs bit-identical."""
+    from oracle import native
+    from motif_amd import ops
+    B, N, H, W, s = 1, 1, 32, 48, 4
+    HH, WW = H * s, W * s
+    iy, ix, _, _ = _tables(H, W, HH, WW)
+    iyc, ixc = iy.cpu().long(), ix.cpu().long()
+    imnet_out = rnd(2 * B, 64, HH, WW, seed=1)
+    feat_lr = rnd(2 * B, 64, H, W, seed=2)
+    alpha = torch.tensor([-20.0])
+
+    def run(pred):
+        return ops.splat_motif(imnet_out.to(dev()), pred.to(dev()), feat_lr.to(dev()), iy, ix, alpha.to(dev()), HH / H, B, N, HH, WW).cpu()
+
+    def check(pred, reproducible):
+        flow = pred[:, :2] * 20.0 * (HH / H)
+        ez = (F.relu(pred[:, 2:3]) * alpha).exp()
+        feat_low = feat_lr[:, :, iyc][:, :, :, ixc]
+        feat_all = torch.cat([imnet_out, pred[:, :2], feat_low], 1)
+        ssum = native.splat(torch.cat([feat_all * ez, ez], 1), flow, "sum").reshape(2, B * N, 131, HH, WW).sum(0)
+        smax = native.splat(ez, flow, "max").reshape(2, B * N, 1, HH, WW).max(0)[0]
+        scnt = native.splat(torch.ones_like(ez), flow, "count").reshape(2, B * N, 1, HH, WW).sum(0)
+        acc = run(pred)
+        assert torch.equal(acc[:, 132:133], scnt), "count plane must be exact"
+        close(acc[:, 131:132], smax, 1e-6, 1e-6, "max plane")
+        scale = float(ssum.abs().max())
+        close(acc[:, :131], ssum, 3e-5 * max(1.0, scale / 50), 3e-5, "sum planes")
+        if reproducible:
+            assert torch.equal(acc, run(pred)), "owner-computes tiles must be run-to-run bit-identical"
+        return scnt
+
+    yy, xx = torch.meshgrid(torch.arange(HH, dtype=torch.float32), torch.arange(WW, dtype=torch.float32), indexing="ij")
+    k = 1.0 / (20.0 * s)                                                   # pred units per HR pixel of flow
+    # (1) point sink: a 24 x 24 block of both directions flows to (40.3, 70.6)
+    pred = rnd(2, 3, HH, WW, seed=3, scale=0.02)
+    blk = (slice(28, 52), slice(58, 82))
+    pred[:, 0][(slice(None),) + blk] = ((70.6 - xx) * k)[blk]
+    pred[:, 1][(slice(None),) + blk] = ((40.3 - yy) * k)[blk]
+    pred[:, 2] = torch.rand(2, HH, WW, generator=torch.Generator().manual_seed(4)) * 0.2
+    cnt = check(pred, reproducible=True)
+    assert float(cnt.max()) > 500, "the sink must pile hundreds of footprints on one cell"
+    # (2) everything within 14 px of the tile rows 48..63 x columns 64..127 lands inside it; a far source on top (its
+    #     global float atomics are the one order-dependent part)
+    pred = rnd(2, 3, HH, WW, seed=5, scale=0.02)
+    blk = (slice(35, 77), slice(51, 141))
+    pred[:, 0][(slice(None),) + blk] = ((xx.clamp(65.5, 125.5) - xx) * k)[blk]
+    pred[:, 1][(slice(None),) + blk] = ((yy.clamp(49.5, 61.5) - yy) * k)[blk]
+    pred[:, 2] = 0.0
+    pred[0, 0, 100, 20] = 0.5
+    cnt = check(pred, reproducible=True)
+    assert float(cnt[..., 48:64, 64:128].sum()) > 4 * 7000
+
+
 def test_precontracted_splat_and_synth_equal_the_literal_path():
     """motif_splat_motif_pre_fwd + motif_siren_synth_pre_fwd (synth_net's first layer contracted into the splat sources:
     Ours.py:811-814 and 839-856 are linear) against the literal composition on the CPU: kernel-text splat of the 130
