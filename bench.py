@@ -56,6 +56,10 @@ def parse():
                     help="clips in flight per GPU, each on its own HIP stream and model instance (default 2: the next clip's launches fill the "
                          "tails of the current one's, +6 %% throughput; 1 = strictly one clip at a time)")
     ap.add_argument("--batch", type=int, default=1, help="clips per step (one forward over a batch of B independent clips)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay one HIP graph per clip instead of launching every kernel from the host (opt['hip_graph']): measured "
+                         "32.9 vs 34.3 ms with one clip at a time, but 32.7 vs 30.4 ms with two clips in flight -- two graphs do not "
+                         "overlap the way two streams of host launches do, so the default stays host launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -177,6 +181,7 @@ def instrumented_clip(model, sample):
     net = model.netG
     overlap = getattr(net, "overlap_raft", False)
     net.overlap_raft = False          # per-kernel durations: no concurrent side stream while instrumenting
+    use_graph, model.use_graph = model.use_graph, False        # and host launches, so that the hooks see every call
     c0, c1 = ev()
     try:
         c0.record()
@@ -188,6 +193,7 @@ def instrumented_clip(model, sample):
         for name, fn in saved.items():
             setattr(ops, name, fn)
         net.overlap_raft = overlap
+        model.use_graph = use_graph
     mfma_peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
     bounds = {"conv3x3": "mfma", "conv_other": "mfma", "dcn": "mfma", "imnet": "mfma", "flow_imnet": "mfma", "synth_net": "mfma", "splat": "hbm"}
     stages = {}
@@ -308,12 +314,12 @@ def main():
     from motif_amd.utils.synth_weights import fill_state_dict
 
     h, w = a.lr
-    model = create_model(default_opt(scale=a.scale, gpu_ids=[local], mma=a.mma))
+    model = create_model(default_opt(scale=a.scale, gpu_ids=[local], mma=a.mma, hip_graph=a.graph))
     fill_state_dict(model.netG)
     # --streams S: S clips in flight per GPU, each on its own stream with its own model instance (same weights)
     models, streams = [model], [torch.cuda.current_stream()]
     for _ in range(1, a.streams):
-        m = create_model(default_opt(scale=a.scale, gpu_ids=[local], mma=a.mma))
+        m = create_model(default_opt(scale=a.scale, gpu_ids=[local], mma=a.mma, hip_graph=a.graph))
         fill_state_dict(m.netG)
         models.append(m)
         streams.append(torch.cuda.Stream())
@@ -357,10 +363,13 @@ def main():
         return dt
 
     # setup, not measurement: every model instance renders one clip so that its weights are packed (one-off pack kernels with
-    # a host wait each, ops._packed_ready) and the allocator holds its buffers before the W warm-up and K timed steps
+    # a host wait each, ops._packed_ready) and the allocator holds its buffers before the W warm-up and K timed steps; with
+    # HIP graphs a second clip per instance records its graph (VideoSR_base_model._test_graph), so the warm-up and the timed
+    # steps are all replays
     def setup():
-        for i in range(len(models)):
-            step(i)
+        for _ in range(2 if a.graph else 1):
+            for i in range(len(models)):
+                step(i)
         fence()
 
     setup()
@@ -376,7 +385,8 @@ def main():
                    "workload": "c2: 4-frame %dx%d LR clip -> %dx%d (x%d spatial), x%dt = %d timestamps, B=%d clip(s) per step per GPU, "
                                "RAFT-small iters=4, seeded key-hashed weights" % (h, w, HH, WW, a.scale, a.times - 1, a.times, a.batch),
                    "parallelism": "clips sharded per GPU (dp%d), uint8 frame gather to rank 0" % world,
-                   "clips_in_flight_per_gpu": a.streams},
+                   "clips_in_flight_per_gpu": a.streams,
+                   "launch": "one HIP graph per clip (recorded from the second clip on, inputs copied in, replayed)" if a.graph else "host launches"},
     }
     if world > 1:
         try:

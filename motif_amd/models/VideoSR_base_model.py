@@ -4,6 +4,11 @@ Reproduced for the inference path: `feed_data` keys and `scale` default (95-121)
 into <=3 timestamps with `cat` on dim 0 (169-200, leaves the net in train() mode afterwards, :198),
 `load`/`save` (224-231), the Adam + scheduler objects `test.py:272` reads the learning rate from
 (`is_train=True` at test.py:311).  Training (`optimize_parameters`) is out of scope.
+
+MI355X addition (`opt["hip_graph"]`, off unless set): a clip is ~600 dependent kernel launches on two HIP streams; the second
+`test()` of a configuration (input shape, timestamps, scale, generator, arithmetic, weights) records them into a HIP graph, later
+ones copy the inputs into the graph's static buffers and replay it -- the same kernels with the same arguments (outputs are
+bit-identical to the eager launches), dispatched by the command processor without the host in between.
 """
 import logging
 from collections import OrderedDict
@@ -12,6 +17,7 @@ import torch
 
 from . import networks
 from .base_model import BaseModel
+from .. import ops
 
 logger = logging.getLogger("base")
 
@@ -29,6 +35,9 @@ class VideoSRBaseModel(BaseModel):
         self.net_base = self.net_opt["which_model_G"]
         self.load()
         self.log_dict = OrderedDict()
+        self.use_graph = bool(opt.get("hip_graph"))
+        self._graphs = OrderedDict()                     # configuration -> "warm" | recorded graph with its static tensors
+        self._time_key = None
         if self.is_train:
             self.netG.train()
             train_opt = opt["train"]
@@ -40,6 +49,10 @@ class VideoSRBaseModel(BaseModel):
     def feed_data(self, data, need_GT=True):
         self.var_L = data["LQs"].to(self.device)
         if "time" in data.keys() and "Ours" in self.net_base:
+            # timestamp VALUES identify a recorded graph (the four-frame generators pick weights by them on the host); only
+            # host tensors are read here -- device tensors would cost a synchronisation
+            self._time_key = (tuple(tuple(float(v) for v in t_.reshape(-1).tolist()) for t_ in data["time"])
+                              if all(not t_.is_cuda for t_ in data["time"]) else None)
             self.times = [t_.to(self.device) for t_ in data["time"]]
         else:
             self.times = None
@@ -56,24 +69,84 @@ class VideoSRBaseModel(BaseModel):
         with torch.no_grad():
             if self.times is None or "Ours" not in self.net_base:
                 raise NotImplementedError("only the 'Ours' generator is on the hot path")
-            if self.net_base == "Ours_44":              # one timestamp per call (VideoSR_base_model.py:182-187)
-                self.fake_H, flow, flow_GT = self.netG(self.var_L, getattr(self, "real_H", None), self.times[:1], self.scale,
-                                                       use_GT=False, iter=4)
-                for l in range(1, len(self.times), 1):
-                    tmp, flow, flow_GT = self.netG(self.var_L, None, self.times[l:l + 1], self.scale, use_GT=False, iter=4)
-                    self.fake_H = torch.cat((self.fake_H, tmp), 0)
-            else:
-                self.fake_H, flow, flow_GT = self.netG(self.var_L, getattr(self, "real_H", None), self.times[:3], self.scale,
-                                                       use_GT=False, iter=4)
-                if len(self.times) != 3:
-                    for l in range(3, len(self.times), 3):
-                        tmp, flow, flow_GT = self.netG(self.var_L, None, self.times[l:l + 3], self.scale, use_GT=False, iter=4)
-                        self.fake_H = torch.cat((self.fake_H, tmp), 0)
-            self.flow = flow
-            self.flow_GT = flow_GT
+            if not (self.use_graph and self._test_graph()):
+                self._test_eager(self.var_L, self.times)
         self.netG.train()
         if output:
             return self.fake_H
+
+    def _test_eager(self, var_L, times):
+        if self.net_base == "Ours_44":              # one timestamp per call (VideoSR_base_model.py:182-187)
+            self.fake_H, flow, flow_GT = self.netG(var_L, getattr(self, "real_H", None), times[:1], self.scale,
+                                                   use_GT=False, iter=4)
+            for l in range(1, len(times), 1):
+                tmp, flow, flow_GT = self.netG(var_L, None, times[l:l + 1], self.scale, use_GT=False, iter=4)
+                self.fake_H = torch.cat((self.fake_H, tmp), 0)
+        else:
+            self.fake_H, flow, flow_GT = self.netG(var_L, getattr(self, "real_H", None), times[:3], self.scale,
+                                                   use_GT=False, iter=4)
+            if len(times) != 3:
+                for l in range(3, len(times), 3):
+                    tmp, flow, flow_GT = self.netG(var_L, None, times[l:l + 3], self.scale, use_GT=False, iter=4)
+                    self.fake_H = torch.cat((self.fake_H, tmp), 0)
+        self.flow = flow
+        self.flow_GT = flow_GT
+
+    # ---- HIP-graph replay of a clip
+    MAX_GRAPHS = 4
+
+    def _graph_key(self):
+        if not self.var_L.is_cuda or isinstance(self.scale, (list, tuple)) and any(torch.is_tensor(v) and v.is_cuda for r in self.scale for v in r):
+            return None
+        if self._time_key is None and self.net_base != "Ours":
+            return None                                   # timestamps only on the device: their values are unknown here
+        net = self.netG
+        scale = self.scale if not isinstance(self.scale, (list, tuple)) else tuple(tuple(int(v) for v in r) for r in self.scale)
+        return (tuple(self.var_L.shape), self.var_L.dtype, self._time_key or tuple(tuple(t.shape) for t in self.times), scale,
+                self.net_base, ops.get_conv_mma(), ops.get_siren_mma(), getattr(net, "_weights_epoch", 0),
+                sum(p._version for p in net.parameters()),      # in-place weight edits re-pack on the next eager call: never replay over them
+                getattr(net, "precontract", None), getattr(net, "overlap_raft", None), getattr(net, "band", None) is None)
+
+    def _test_graph(self):
+        """-> True when the clip was rendered by a graph replay.  First sight of a configuration: eager (it also packs weights and
+        sizes the allocator); second: record; from then on: copy inputs, replay, hand out copies of the static outputs."""
+        key = self._graph_key()
+        if key is None or getattr(self.netG, "band", None) is not None:
+            return False
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._graphs[key] = "warm"
+            while len(self._graphs) > self.MAX_GRAPHS:
+                self._graphs.popitem(last=False)
+            return False
+        if ent == "warm":
+            ent = dict(L=self.var_L.clone(), times=[t.clone() for t in self.times])
+            real_H = getattr(self, "real_H", None)
+            self.real_H = None                            # unused by the inference path; keep it out of the recording
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._test_eager(ent["L"], ent["times"])
+                ent.update(g=g, out=self.fake_H, flow=self.flow, flow_GT=self.flow_GT)
+                self._graphs[key] = ent
+            except Exception as e:                        # recording is an optimisation: fall back to the eager launches
+                logger.warning("HIP graph capture failed (%s: %s); launching eagerly", type(e).__name__, e)
+                self.use_graph = False
+                torch.cuda.synchronize()
+                return False
+            finally:
+                self.real_H = real_H
+        else:
+            self._graphs.move_to_end(key)
+            ent["L"].copy_(self.var_L, non_blocking=True)
+            for dst, src in zip(ent["times"], self.times):
+                dst.copy_(src, non_blocking=True)
+        ent["g"].replay()
+        self.fake_H = ent["out"].clone()
+        self.flow = ent["flow"].clone() if torch.is_tensor(ent["flow"]) else ent["flow"]
+        self.flow_GT = ent["flow_GT"]
+        return True
 
     def get_current_log(self):
         return self.log_dict

@@ -13,6 +13,19 @@ from .extractor import SmallEncoder
 from .update import SmallUpdateBlock
 
 
+_INDEX_CACHE = {}
+
+
+def _index_tensor(values, device):
+    """Small constant index lists live on the device once (a host-to-device copy per forward is a synchronous
+    pageable transfer -- and cannot be recorded into a HIP graph)."""
+    key = (tuple(int(v) for v in values), str(device))
+    t = _INDEX_CACHE.get(key)
+    if t is None:
+        t = _INDEX_CACHE[key] = torch.as_tensor(key[0], device=device, dtype=torch.long)
+    return t
+
+
 def coords_grid(batch, ht, wd, device):
     ys, xs = torch.meshgrid(torch.arange(ht, device=device), torch.arange(wd, device=device), indexing="ij")
     return torch.stack([xs, ys], dim=0).float()[None].repeat(batch, 1, 1, 1)
@@ -50,13 +63,12 @@ class RAFT(nn.Module):
         an instance norm), the pairing happens on the 1/8-resolution feature maps."""
         x = (2 * (frames / 255.0) - 1.0).contiguous()
         dev = frames.device
-        si = torch.as_tensor(src, device=dev, dtype=torch.long)
-        di = torch.as_tensor(dst, device=dev, dtype=torch.long)
+        si, di = _index_tensor(src, dev), _index_tensor(dst, dev)
         fmap = self.fnet(x)                                                    # [F,128,h/8,w/8]
         usrc = sorted(set(int(v) for v in src))                                # context net: distinct source frames only
         cn = self.cnet(x[usrc] if len(usrc) < x.shape[0] else x, act=ops.ACT_TANH, act2=ops.ACT_RELU, act_split=self.hidden_dim)
         pos = {f: i for i, f in enumerate(usrc)}
-        ci = torch.as_tensor([pos[int(v)] for v in src], device=dev, dtype=torch.long)
+        ci = _index_tensor([pos[int(v)] for v in src], dev)
         corr_fn = AlternateCorrBlock(fmap, fmap, radius=self.args.corr_radius, index1=si, index2=di)
         shape = (len(src),) + tuple(frames.shape[1:])
         return self._iterate(corr_fn, cn.index_select(0, ci), shape, dev, iters, None, False, last_only)

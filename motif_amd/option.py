@@ -48,7 +48,7 @@ def parse(opt_path, is_train=True):
     return opt
 
 
-def default_opt(scale=4, gpu_ids=(0,), pretrain_model_G=None, name="synthetic", mma=None, which_model_G="Ours"):
+def default_opt(scale=4, gpu_ids=(0,), pretrain_model_G=None, name="synthetic", mma=None, which_model_G="Ours", hip_graph=False):
     """The option dict `test.yml` yields (test.yml:1-83) for the `Ours` generator, setting 5."""
     return dict_to_nonedict(OrderedDict(
         name=name, use_tb_logger=False, model="VideoSR_base", distortion="sr", scale=scale,
@@ -58,4 +58,5 @@ def default_opt(scale=4, gpu_ids=(0,), pretrain_model_G=None, name="synthetic", 
         train=OrderedDict(lr_G=0.0, lr_scheme="CosineAnnealingLR_Restart", beta1=0.9, beta2=0.99, pixel_criterion="cb",
                           pixel_weight=1.0, manual_seed=0),
         logger=OrderedDict(print_freq=1),
+        hip_graph=bool(hip_graph),        # MI355X addition: record a clip's launches into a HIP graph and replay it (VideoSR_base_model.py)
     ))

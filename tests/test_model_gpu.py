@@ -646,3 +646,43 @@ def test_four_frame_generators_full_size_properties(which, mma_mode):
     if which == "Ours_44":
         # residual features picked over the four calls (t = 0, 3/6, 5/6, 1): the fp32 product 5/6 * 6 truncates to 4
         assert sorted(k[1] for k in model.netG._cache if isinstance(k, tuple) and k[0] == "synth_l0") == [0, 3, 4, 6]
+
+
+def test_hip_graph_replay_is_bit_identical_and_tracks_inputs_and_weights():
+    """opt['hip_graph']: the second clip of a configuration records the launches, later ones replay them.  Frames and flow must
+    equal the eager launches bit for bit for every clip (also a different clip through the same graph), and an in-place weight
+    edit must not be replayed over (new configuration -> eager, then a new recording)."""
+    from motif_amd import models
+    from motif_amd.option import default_opt
+    from motif_amd.data.synthetic import synthetic_sample
+    from motif_amd.utils.synth_weights import fill_state_dict
+    eager = models.create_model(default_opt(scale=4)); fill_state_dict(eager.netG)
+    graph = models.create_model(default_opt(scale=4, hip_graph=True)); fill_state_dict(graph.netG)
+    clips = [synthetic_sample(32, 48, 4, 7, seed=s) for s in (1, 2)]
+
+    def render(m, s):
+        m.feed_data(s)
+        m.test()
+        return m.fake_H.clone(), m.flow.clone()
+
+    want = [render(eager, s) for s in clips]
+    kinds = []
+    for i in (0, 0, 1, 0, 1):
+        out, flow = render(graph, clips[i])
+        ent = list(graph._graphs.values())[-1]
+        kinds.append("warm" if ent == "warm" else "graph")
+        assert torch.equal(out, want[i][0]) and torch.equal(flow, want[i][1]), "clip %d differs (%s)" % (i, kinds[-1])
+    assert kinds == ["warm", "graph", "graph", "graph", "graph"], kinds
+    held = out                                                       # handed-out frames are copies: the next replay must not touch them
+    snapshot = held.clone()
+    render(graph, clips[0])
+    assert torch.equal(held, snapshot)
+    with torch.no_grad():                                            # in-place weight edit on both models
+        for m in (eager, graph):
+            m.netG.synth_net.net[4].bias.add_(0.05)
+    want2 = render(eager, clips[0])
+    assert not torch.equal(want2[0], want[0][0])
+    n0 = len(graph._graphs)
+    out, _ = render(graph, clips[0])
+    assert torch.equal(out, want2[0]), "stale packed weights were replayed"
+    assert len(graph._graphs) == n0 + 1
