@@ -18,17 +18,45 @@ __device__ __forceinline__ float resize_sample(const float* __restrict__ p, int 
            ly * (hx * p[(long)y1 * W + x0] + lx * p[(long)y1 * W + x1]);
 }
 
-// one thread = VEC consecutive outputs of a row (16-byte stores when VEC = 4); block = 64 x 4 threads
-template <int VEC>
+// one thread = VEC consecutive outputs of a row (16-byte stores when VEC = 4); threads are dealt over the flattened
+// (row, column group) index of a plane, so no lane idles on a ragged row width; blockIdx.y = plane.
+// UP2: exactly x2 up-sampling with align_corners = False (the PCD pyramid's 8x64-plane maps: 0.65 ms per clip).  The four outputs
+// 4k..4k+3 of a row read input columns 2k-1..2k+2 only: 8 loads (clamped, issued together) instead of 16, the same
+// interpolation expression on the same values.
+template <int VEC, bool UP2>
 __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
                                                                int Ho, int Wo, float sh, float sw, int align, float mul) {
-    const int ox = (blockIdx.x * 64 + threadIdx.x) * VEC;
-    const int oy = blockIdx.y * 4 + threadIdx.y;
-    const long nc = blockIdx.z;
-    if (ox >= Wo || oy >= Ho) return;
+    const int gpr = Wo / VEC + (Wo % VEC ? 1 : 0);                    // column groups per row
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi >= Ho * gpr) return;
+    const int oy = gi / gpr, ox = (gi - oy * gpr) * VEC;
+    const long nc = blockIdx.y;
     const float* p = in + nc * (long)H * W;
     float* o = out + nc * (long)Ho * Wo + (long)oy * Wo + ox;
-    if constexpr (VEC == 4) {
+    if constexpr (UP2) {
+        float sy = sh * (oy + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+        const int y0 = (int)sy, y1 = y0 + (y0 < H - 1 ? 1 : 0);
+        const float ly = sy - y0, hy = 1.f - ly;
+        const int xb = ox / 2 - 1;
+        float r0[4], r1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int xc = min(max(xb + i, 0), W - 1);
+            r0[i] = p[(long)y0 * W + xc];
+            r1[i] = p[(long)y1 * W + xc];
+        }
+        f32x4 v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float sx = sw * (ox + u + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+            const int x0 = (int)sx;
+            const float lx = sx - x0, hx = 1.f - lx;
+            constexpr int i0[4] = {0, 1, 1, 2};                       // x0 - xb of outputs 4k..4k+3 (the left edge clamps to the same value)
+            const float a = r0[i0[u]], b = r0[i0[u] + 1], c = r1[i0[u]], d = r1[i0[u] + 1];
+            v[u] = (hy * (hx * a + lx * b) + ly * (hx * c + lx * d)) * mul;
+        }
+        *(f32x4*)o = v;
+    } else if constexpr (VEC == 4) {
         f32x4 v;
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = resize_sample(p, H, W, oy, ox + u, sh, sw, align) * mul;
@@ -41,16 +69,20 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
 extern "C" int motif_resize_bilinear(const float* in, float* out, int NC, int H, int W, int Ho, int Wo,
                                      int align_corners, float mul, void* stream) {
     if (!in || !out || NC < 1 || H < 1 || W < 1 || Ho < 1 || Wo < 1) return MOTIF_EINVAL;
+    if (NC > 65535 || (long)Ho * Wo >= (1L << 31)) return MOTIF_ELIMIT;
     float sh, sw;
     if (align_corners) { sh = Ho > 1 ? (float)(H - 1) / (Ho - 1) : 0.f; sw = Wo > 1 ? (float)(W - 1) / (Wo - 1) : 0.f; }
     else { sh = (float)H / Ho; sw = (float)W / Wo; }
-    const dim3 block(64, 4);
+    hipStream_t s = (hipStream_t)stream;
     if (Wo % 4 == 0 && ((uintptr_t)out & 15) == 0) {
-        dim3 grid(cdiv(Wo, 256), cdiv(Ho, 4), NC);
-        resize_bilinear_kernel<4><<<grid, block, 0, (hipStream_t)stream>>>(in, out, H, W, Ho, Wo, sh, sw, align_corners, mul);
+        dim3 grid(cdiv((long)Ho * (Wo / 4), 256), NC);
+        if (!align_corners && Ho == 2 * H && Wo == 2 * W && W >= 2)
+            resize_bilinear_kernel<4, true><<<grid, 256, 0, s>>>(in, out, H, W, Ho, Wo, sh, sw, align_corners, mul);
+        else
+            resize_bilinear_kernel<4, false><<<grid, 256, 0, s>>>(in, out, H, W, Ho, Wo, sh, sw, align_corners, mul);
     } else {
-        dim3 grid(cdiv(Wo, 64), cdiv(Ho, 4), NC);
-        resize_bilinear_kernel<1><<<grid, block, 0, (hipStream_t)stream>>>(in, out, H, W, Ho, Wo, sh, sw, align_corners, mul);
+        dim3 grid(cdiv((long)Ho * Wo, 256), NC);
+        resize_bilinear_kernel<1, false><<<grid, 256, 0, s>>>(in, out, H, W, Ho, Wo, sh, sw, align_corners, mul);
     }
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;

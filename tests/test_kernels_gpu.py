@@ -292,7 +292,7 @@ def test_splat_empty_flow_is_identity_count_four_corners():
 
 # ------------------------------------------------------------------------------------------- resampling
 @pytest.mark.parametrize("align", [False, True])
-@pytest.mark.parametrize("shape", [((18, 32), (72, 128)), ((72, 128), (18, 32)), ((9, 16), (18, 32)), ((16, 24), (128, 192)), ((23, 31), (47, 50))])
+@pytest.mark.parametrize("shape", [((18, 32), (72, 128)), ((72, 128), (18, 32)), ((9, 16), (18, 32)), ((45, 80), (90, 160)), ((7, 10), (14, 20)), ((16, 24), (128, 192)), ((23, 31), (47, 50))])
 def test_resize_bilinear(shape, align):
     from motif_amd import ops
     (h, w), (ho, wo) = shape
