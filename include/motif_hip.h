@@ -249,6 +249,9 @@ int motif_gru_update(const float* z, const float* q, const float* h, float* out,
 int motif_lstm_gates(const float* cc, const float* c_cur, float* h_next, float* c_next, int B, int hid, int HW, void* stream);
 /* out = a*x + b*y (y may be NULL) */
 int motif_axpby(const float* x, const float* y, float a, float b, float* out, long n, void* stream);
+/* The flow LunaTokis.forward returns (Ours.py:794 scales the prediction up, (p*20)*ratio, :858 scales it back, /20 /ratio):
+ * pred [N,3,Q] -> out [N,2,Q] = (((p*a)*b)/a)/b with the four roundings of the four torch operations. */
+int motif_flow_roundtrip(const float* pred, float* out, int N, long Q, float a, float b, void* stream);
 /* ConvTranspose2d(k=4,s=2,p=1) with few output channels (PWCNet.py:102-106) */
 int motif_deconv4x4s2(const float* in, const float* weight /*[Cin,Cout,4,4]*/, const float* bias, float* out,
                       int N, int Cin, int Cout, int H, int W, void* stream);

@@ -63,6 +63,7 @@ _SIGS = {
     "motif_gru_update": (c_int, [P, P, P, P, c_long, P]),
     "motif_lstm_gates": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "motif_axpby": (c_int, [P, P, c_float, c_float, P, c_long, P]),
+    "motif_flow_roundtrip": (c_int, [P, P, c_int, c_long, c_float, c_float, P]),
     "motif_deconv4x4s2": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
 }
 EXPORTS = tuple(_SIGS)

@@ -513,6 +513,25 @@ extern "C" int motif_axpby(const float* x, const float* y, float a, float b, flo
     return MOTIF_OK;
 }
 
+// The flow the generator returns (Ours.py:794, 858): the predicted flow is scaled up for the splat, flow = (p * 20) * ratio, and
+// scaled back for the caller, (flow / 20) / ratio -- four separately rounded torch operations there, one pass here with the same four
+// roundings (IEEE division; no contraction possible between a multiply and a divide).  pred [N,3,Q] -> out [N,2,Q].
+__global__ void flow_roundtrip_kernel(const float* __restrict__ pred, float* __restrict__ out, long Q, float a, float b) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = blockIdx.y;
+    if (i >= 2 * Q) return;
+    const float f = (pred[n * 3 * Q + i] * a) * b;
+    out[n * 2 * Q + i] = (f / a) / b;
+}
+
+extern "C" int motif_flow_roundtrip(const float* pred, float* out, int N, long Q, float a, float b, void* stream) {
+    if (!pred || !out || N < 1 || Q < 1) return MOTIF_EINVAL;
+    if (N > 65535) return MOTIF_ELIMIT;
+    flow_roundtrip_kernel<<<dim3(cdiv(2 * Q, 256), N), 256, 0, (hipStream_t)stream>>>(pred, out, Q, a, b);
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}
+
 // ------------------------------------------------------------------ ConvTranspose2d(k=4, s=2, p=1), small Cout
 __global__ void deconv4x4s2_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
                                    float* __restrict__ out, int Cin, int Cout, int H, int W) {

@@ -635,5 +635,4 @@ class LunaTokis(nn.Module):
         if stages is not None:
             stages.update(c)
             stages.update(pred=pred, acc=acc)
-        flow_hr = pred[:, :2] * 20.0 * (HH / H)
-        return frames, flow_hr / 20.0 / (HH / H), 0
+        return frames, ops.flow_roundtrip(pred, 20.0, HH / H), 0         # (pred[:, :2] * 20 * (HH/H)) / 20 / (HH/H), Ours.py:794, 858

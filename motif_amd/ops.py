@@ -623,6 +623,16 @@ def axpby(x, y=None, a=1.0, b=1.0):
     return out
 
 
+def flow_roundtrip(pred, a, b):
+    """pred [N,3,HH,WW] -> [N,2,HH,WW] = ((pred[:, :2] * a) * b / a) / b, the reference's scale-up / scale-back of the flow in one pass."""
+    lib = _lib.load()
+    pred = _c(pred)
+    n, _, hh, ww = pred.shape
+    out = torch.empty(n, 2, hh, ww, dtype=torch.float32, device=pred.device)
+    check(lib.motif_flow_roundtrip(_p(pred), _p(out), n, hh * ww, float(a), float(b), _stream()), "motif_flow_roundtrip")
+    return out
+
+
 def deconv4x4s2(x, weight, bias):
     lib = _lib.load()
     x = _c(x)

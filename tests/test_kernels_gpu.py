@@ -367,6 +367,10 @@ def test_pool_transpose_gates_axpby():
     close(h2, hn, 2e-6)
     close(c2, cn, 2e-6)
     close(ops.axpby(x.to(dev()), (x * 2).to(dev()), 1.0, -1.0), -x, 0)
+    pred = rnd(3, 3, 24, 40, seed=9, scale=0.3)
+    for ratio in (4.0, 3.0, 2.5):
+        want = pred[:, :2] * 20.0 * ratio / 20.0 / ratio
+        assert torch.equal(ops.flow_roundtrip(pred.to(dev()), 20.0, ratio).cpu(), want), "flow round trip must keep the four roundings"
 
 
 def test_deconv4x4s2():
