@@ -686,3 +686,23 @@ def test_hip_graph_replay_is_bit_identical_and_tracks_inputs_and_weights():
     out, _ = render(graph, clips[0])
     assert torch.equal(out, want2[0]), "stale packed weights were replayed"
     assert len(graph._graphs) == n0 + 1
+
+
+@pytest.mark.parametrize("cfg", [(36, 52, 4, 3, 1, 4), (48, 64, 3, 2, 2, 4), (40, 32, 4, 3, 1, 2), (64, 72, 2, 1, 1, 3)],
+                         ids=["lr36x52_s4_t3", "lr48x64_s3_t2_b2", "lr40x32_s4_t3_2frames", "lr64x72_s2_t1_3frames"])
+def test_generator_matches_oracle_on_odd_shapes(cfg, mma_mode):
+    """The whole generator against the CPU oracle on shapes none of the goldens or BASELINE configs have: LR sizes that are
+    multiples of 4 but not of the tile sizes (36x52, 40x32: ragged conv / splat / SIREN tiles, HR not a multiple of 64), scale
+    ratio 3, batch 2, 2 and 3 input frames, a single timestamp.  PSNR >= 60 dB, flow L-inf <= 2e-3."""
+    from oracle.motif_ref import MotifRef
+    from motif_amd.data.synthetic import synthetic_sample
+    from motif_amd.utils.synth_weights import fill_state_dict
+    h, w, scale, T, B, nfr = cfg
+    net = build_net()
+    s = synthetic_sample(h, w, scale, T, n_frames=nfr, batch=B, seed=11 + h)
+    with torch.no_grad():
+        out, flow, _ = net(s["LQs"].cuda(), None, [t.cuda() for t in s["time"]], s["scale"], use_GT=False, iter=4)
+        ref, rflow, _ = fill_state_dict(MotifRef().eval())(s["LQs"], None, s["time"], s["scale"], use_GT=False, iter=4)
+    assert out.shape == ref.shape == (T, B, 3, h * scale, w * scale)
+    assert psnr(out.cpu(), ref) >= 60.0, psnr(out.cpu(), ref)
+    assert float((flow.cpu() - rflow).abs().max()) < 2e-3
