@@ -241,6 +241,12 @@ int motif_instance_norm(const float* x, const float* res, float* out, int NC, in
 /* same, with a caller-owned fp64 workspace of NC*(2+128) doubles: large planes are split over many workgroups, both moments
  * in one pass over the tensor (fp64 sum and sum of squares) */
 int motif_instance_norm_ws(const float* x, const float* res, float* out, double* workspace, int NC, int HW, int mode, void* stream);
+/* InstanceNorm whose statistics span several processes (one clip tiled over GPUs, SURVEY.md 8(e) row 3: "all_reduce of per-channel
+ * sum x, sum x^2 for each of the 21 InstanceNorm layers of fnet", extractor.py:85-90,206-207): moments over the rows [row_lo,row_hi) a rank
+ * owns -> sums [NC][3] doubles (sum, sum of squares, element count); the caller all-reduces them (SUM); apply normalises the whole
+ * plane with them (mode as motif_instance_norm). */
+int motif_instance_norm_moments(const float* x, double* sums, int NC, int H, int W, int row_lo, int row_hi, void* stream);
+int motif_instance_norm_apply(const float* x, const float* res, const double* sums, float* out, int NC, int HW, int mode, void* stream);
 int motif_avg_pool2(const float* in, float* out, int NC, int H, int W, void* stream);   /* F.avg_pool2d(x,2,2) */
 int motif_nchw_to_nhwc(const float* in, float* out, int N, int C, int HW, void* stream);
 /* ConvGRU update (update.py:24-31): h' = (1-z)*h + z*q */

@@ -58,6 +58,8 @@ _SIGS = {
     "motif_reliability_fwd": (c_int, [P, P, c_long, P, P, P, P, c_int, c_int, c_int, P]),
     "motif_instance_norm": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "motif_instance_norm_ws": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "motif_instance_norm_moments": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "motif_instance_norm_apply": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "motif_avg_pool2": (c_int, [P, P, c_int, c_int, c_int, P]),
     "motif_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, P]),
     "motif_gru_update": (c_int, [P, P, P, P, c_long, P]),

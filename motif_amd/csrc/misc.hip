@@ -424,6 +424,59 @@ extern "C" int motif_instance_norm_ws(const float* x, const float* res, float* o
     return MOTIF_OK;
 }
 
+// InstanceNorm with statistics that span several processes (one clip tiled over GPUs in row bands): each rank
+// sums x and x^2 in fp64 over the rows it OWNS (its band, not the halo around it), the [NC][3] doubles (sum, sum of squares, count) are
+// all-reduced by the caller (RCCL), and every rank normalises its whole crop with the global mean / variance.
+__global__ __launch_bounds__(256) void in_moments_rows_kernel(const float* __restrict__ x, double* __restrict__ sums, int H, int W,
+                                                              int row_lo, int row_hi) {
+    __shared__ double sh[8];
+    const int plane = blockIdx.x;
+    const float* p = x + (long)plane * H * W + (long)row_lo * W;
+    const long n = (long)(row_hi - row_lo) * W;
+    double s = 0.0, q = 0.0;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) {
+        const double v = (double)p[i];
+        s += v;
+        q = fma(v, v, q);
+    }
+    const double ts = block_sum_d(s, sh), tq = block_sum_d(q, sh);
+    if (threadIdx.x == 0) { sums[plane * 3] = ts; sums[plane * 3 + 1] = tq; sums[plane * 3 + 2] = (double)n; }
+}
+
+__global__ __launch_bounds__(256) void in_apply_sums_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                           const double* __restrict__ sums, float* __restrict__ out, int HW, int mode) {
+    const int plane = blockIdx.y;
+    const long base = (long)plane * HW;
+    const double n = sums[plane * 3 + 2], sx = sums[plane * 3];
+    double m2 = sums[plane * 3 + 1] - sx * sx / n;
+    m2 = m2 > 0.0 ? m2 : 0.0;
+    const float mean = (float)(sx / n);
+    const float var = (float)(m2 / n);
+    const float inv = 1.0f / sqrtf(var + 1e-5f);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+        float v = (x[base + i] - mean) * inv;
+        if (mode >= 1) v = v > 0.f ? v : 0.f;
+        if (mode == 2) { v += res[base + i]; v = v > 0.f ? v : 0.f; }
+        out[base + i] = v;
+    }
+}
+
+extern "C" int motif_instance_norm_moments(const float* x, double* sums, int NC, int H, int W, int row_lo, int row_hi, void* stream) {
+    if (!x || !sums || NC < 1 || H < 1 || W < 1 || row_lo < 0 || row_hi > H || row_lo >= row_hi) return MOTIF_EINVAL;
+    in_moments_rows_kernel<<<NC, 256, 0, (hipStream_t)stream>>>(x, sums, H, W, row_lo, row_hi);
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}
+
+extern "C" int motif_instance_norm_apply(const float* x, const float* res, const double* sums, float* out, int NC, int HW, int mode, void* stream) {
+    if (!x || !sums || !out || NC < 1 || HW < 1 || (mode == 2 && !res)) return MOTIF_EINVAL;
+    if (NC > 65535) return MOTIF_ELIMIT;
+    int gx = HW / 2048; gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    in_apply_sums_kernel<<<dim3(gx, NC), 256, 0, (hipStream_t)stream>>>(x, res, sums, out, HW, mode);
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}
+
 // ------------------------------------------------------------------ small streaming kernels
 __global__ void avg_pool2_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int Ho, int Wo) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;

@@ -97,6 +97,18 @@ def allreduce_max(value):
     return value
 
 
+def allreduce_sum_(value):
+    """SUM over ranks, in place (identity without a process group); gloo takes host tensors only."""
+    if is_dist():
+        if value.is_cuda and dist.get_backend() == "gloo":
+            host = value.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            value.copy_(host)
+        else:
+            dist.all_reduce(value, op=dist.ReduceOp.SUM)
+    return value
+
+
 def gather_bands_to_rank0(local, n_rows, dst=0, align=1, row_dim=-3):
     """local [..., rows_of_this_rank, W, 3] (row axis = `row_dim`) -> on rank `dst` the concatenation over ranks in band
     order ([..., n_rows, W, 3]), else None."""
@@ -134,7 +146,8 @@ def crop_rows_for_band(band, halo, H, HH, lr_halo):
     return a, b
 
 
-def render_clip_tiled(net, x, times, scale, iters=4, halo=64, chunk=3, max_retries=2, encode=frames_to_uint8, lr_halo=None):
+def render_clip_tiled(net, x, times, scale, iters=4, halo=64, chunk=3, max_retries=2, encode=frames_to_uint8, lr_halo=None,
+                      sync_norm=False, reduce_sum=None):
     """One clip over all ranks: every rank runs the LR stage, then renders its HR row band for every timestamp chunk
     (the <= 3-timestamp chunking of VideoSR_base_model.py:189-193).  Returns on rank 0 the uint8 frames
     [T, B, HH, WW, 3] (`encode`: fp32 [...,3,rows,WW] -> uint8 [...,rows,WW,3], the encode kernel), elsewhere None.
@@ -147,7 +160,10 @@ def render_clip_tiled(net, x, times, scale, iters=4, halo=64, chunk=3, max_retri
     HR band gathers from plus R rows of context on each side (`crop_rows_for_band`) -- so the LR stage is tiled too and the
     clip scales; what is lost is the influence of pixels more than R rows away on the encoder / RAFT output (and RAFT's
     instance-norm statistics are the crop's).  Parity of this mode is a PSNR against the untiled render, as SURVEY.md 7(vi)
-    sets it: tests/test_model_gpu.py::test_c5_cropped_tile_mode_psnr measures it at full c5 size."""
+    sets it: tests/test_model_gpu.py::test_c5_cropped_tile_mode_psnr measures it at full c5 size.
+    sync_norm=True (cropped mode only): the 21 InstanceNorm layers of RAFT's feature encoder take their statistics over the
+    WHOLE image -- every rank sums x, x^2 over the rows of its own band, one tiny SUM all-reduce per layer (`reduce_sum`, default
+    `allreduce_sum_` = RCCL), as SURVEY.md 8(e) row 3 sketches -- which removes the statistics error and leaves the context one."""
     rank, w = world()
     H = x.shape[3]
     HH = int(scale[0][0]) if isinstance(scale, list) else round(H * scale)
@@ -163,6 +179,12 @@ def render_clip_tiled(net, x, times, scale, iters=4, halo=64, chunk=3, max_retri
             sr = [[(b - a) * sc], [WW]]
             br = (band[0] - a * sc, band[1] - a * sc)
         net.band, net.band_halo = br, halo
+        if sync_norm:
+            if lr_halo is None:
+                raise ValueError("sync_norm applies to the cropped mode (lr_halo=R); the exact mode replicates the LR stage")
+            if any(band_of(HH, r, w, align=align)[1] <= band_of(HH, r, w, align=align)[0] for r in range(w)):
+                raise RuntimeError("sync_norm needs a non-empty band on every rank (a rank without rows would not join the all-reduces)")
+            net.norm_sync = (br, reduce_sum or allreduce_sum_)
         outs, worst = [], torch.zeros((), device=x.device)
         with torch.no_grad():
             for l in range(0, len(times), chunk):
@@ -179,6 +201,7 @@ def render_clip_tiled(net, x, times, scale, iters=4, halo=64, chunk=3, max_retri
             raise RuntimeError("tile mode: |flow_y| = %.1f px exceeds the halo of %d rows" % (worst, halo))
         halo *= 2
     net.band = None
+    net.norm_sync = None
     return gather_bands_to_rank0(torch.cat(outs, 0), HH, align=align, row_dim=-3)
 
 

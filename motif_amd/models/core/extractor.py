@@ -6,8 +6,37 @@ Mirrors `/root/reference/models/core/extractor.py:60-116` (BottleneckBlock) and 
 import torch
 import torch.nn as nn
 
+import contextlib
+import threading
+
 from ... import ops
 from ..modules.layers import Conv2d
+
+_SYNC = threading.local()
+
+
+@contextlib.contextmanager
+def norm_sync(rows, total_rows, reduce_sum):
+    """While active (this thread), the encoders' InstanceNorms take their statistics over ALL ranks of a row-tiled clip
+    (SURVEY.md 8(e) row 3): this rank owns the rows [rows[0], rows[1]) of the `total_rows` rows of the encoder's input (its
+    band without the context rows around it; the bounds must stay integers at 1/2, 1/4 and 1/8 resolution), `reduce_sum(t)`
+    sums a float64 tensor over the ranks in place.  Every rank must run the same layers in the same order."""
+    _SYNC.ctx = (int(rows[0]), int(rows[1]), int(total_rows), reduce_sum)
+    try:
+        yield
+    finally:
+        _SYNC.ctx = None
+
+
+def _inorm(x, mode, res=None):
+    ctx = getattr(_SYNC, "ctx", None)
+    if ctx is None:
+        return ops.instance_norm(x, mode, res=res)
+    lo, hi, total, reduce_sum = ctx
+    h = x.shape[2]
+    if (lo * h) % total or (hi * h) % total:
+        raise RuntimeError("norm_sync: rows (%d, %d) of %d do not map to whole rows of a %d-row map" % (lo, hi, total, h))
+    return ops.instance_norm_synced(x, (lo * h // total, hi * h // total), reduce_sum, mode, res=res)
 
 
 class BottleneckBlock(nn.Module):
@@ -26,11 +55,11 @@ class BottleneckBlock(nn.Module):
 
     def forward(self, x):
         if self.norm_fn == "instance":
-            y = ops.instance_norm(self.conv1(x), 1)
-            y = ops.instance_norm(self.conv2(y), 1)
+            y = _inorm(self.conv1(x), 1)
+            y = _inorm(self.conv2(y), 1)
             if self.downsample is not None:
-                x = ops.instance_norm(self.downsample[0](x), 0)
-            return ops.instance_norm(self.conv3(y), 2, res=x)          # relu(x + relu(norm(conv3)))
+                x = _inorm(self.downsample[0](x), 0)
+            return _inorm(self.conv3(y), 2, res=x)          # relu(x + relu(norm(conv3)))
         y = self.conv1(x, act=ops.ACT_RELU)
         y = self.conv2(y, act=ops.ACT_RELU)
         if self.downsample is not None:
@@ -60,7 +89,7 @@ class SmallEncoder(nn.Module):
             batch_dim = x[0].shape[0]
             x = torch.cat(x, dim=0)
         if self.norm_fn == "instance":
-            x = ops.instance_norm(self.conv1(x), 1)
+            x = _inorm(self.conv1(x), 1)
         else:
             x = self.conv1(x, act=ops.ACT_RELU)
         for layer in (self.layer1, self.layer2, self.layer3):

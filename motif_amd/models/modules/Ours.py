@@ -14,12 +14,14 @@ What is restructured relative to the reference schedule (results unchanged, SURV
     channel concat are never materialised: they are fused into the MLP / splat / conv kernels.
 """
 import argparse
+import contextlib
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
+from ..core import extractor
 from ..core.raft import RAFT
 from ..softsplat_cp import Softsplat
 from ..softsplat_count_cp import Softsplat_Count
@@ -402,7 +404,10 @@ class LunaTokis(nn.Module):
         # distinct frame (RAFT.forward_pairs), the pairing happens on the feature maps
         src = [b * n + s for _, (s, d, _) in live for b in range(B)]
         dst = [b * n + d for _, (s, d, _) in live for b in range(B)]
-        f = self.flow_predictor.forward_pairs(hr.reshape(B * n, 3, HH, WW) * 255.0, src, dst, iters=iters, last_only=True)[-1]
+        # a row-tiled clip may ask for RAFT's instance-norm statistics over all ranks (motif_amd.dist.render_clip_tiled(sync_norm=True))
+        ns = getattr(self, "norm_sync", None)
+        with (extractor.norm_sync(ns[0], HH, ns[1]) if ns is not None else contextlib.nullcontext()):
+            f = self.flow_predictor.forward_pairs(hr.reshape(B * n, 3, HH, WW) * 255.0, src, dst, iters=iters, last_only=True)[-1]
         f = ops.resize_bilinear(f, (H, W), False, H / HH)
         flow = torch.zeros(n_flows * B, 2, H, W, dtype=torch.float32, device=hr.device)
         for i, (k, (s, d, nz)) in enumerate(live):
@@ -529,7 +534,7 @@ class LunaTokis(nn.Module):
         so the address cannot be recycled), the output size, the RAFT iteration count, band / untiled mode, the
         arithmetic engines and the weights epoch."""
         return (x.data_ptr(), x._version, tuple(x.shape), HH, WW, iters, self.band is None,
-                ops.get_conv_mma(), ops.get_siren_mma(), self._weights_epoch, self.precontract)
+                ops.get_conv_mma(), ops.get_siren_mma(), self._weights_epoch, self.precontract, getattr(self, "norm_sync", None) is not None)
 
     # ---- t-independent stage as a transferable object (motif_amd.dist.render_clip_by_timestamps, share="broadcast")
     def clip_cache_names(self):

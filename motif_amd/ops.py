@@ -552,6 +552,23 @@ def instance_norm(x, mode=0, res=None):
     return out
 
 
+def instance_norm_synced(x, rows, reduce_sum, mode=0, res=None):
+    """InstanceNorm with statistics over several processes: moments over this rank's own rows `rows` = (lo, hi) of every plane,
+    `reduce_sum(t)` all-reduces the [N*C,3] float64 tensor in place (sum, sum of squares, count), then the whole plane is
+    normalised with the global mean / variance."""
+    lib = _lib.load()
+    x = _c(x)
+    n, c, h, w = x.shape
+    sums = torch.empty(n * c, 3, dtype=torch.float64, device=x.device)
+    check(lib.motif_instance_norm_moments(_p(x), ctypes.c_void_p(sums.data_ptr()), n * c, h, w, int(rows[0]), int(rows[1]), _stream()),
+          "motif_instance_norm_moments")
+    reduce_sum(sums)
+    out = torch.empty_like(x)
+    check(lib.motif_instance_norm_apply(_p(x), _p(_c(res)) if res is not None else None, ctypes.c_void_p(sums.data_ptr()), _p(out),
+                                        n * c, h * w, mode, _stream()), "motif_instance_norm_apply")
+    return out
+
+
 def avg_pool2(x):
     lib = _lib.load()
     x = _c(x)

@@ -49,6 +49,19 @@ if r == 0:
     psnr = 99.0 if mse == 0 else 10 * np.log10(1.0 / mse)
     assert psnr >= 45.0, psnr
     print("DIST_GPU_OK cropped-mode PSNR %%.1f dB" %% psnr)
+    plain = psnr
+# cropped mode with RAFT's instance-norm statistics all-reduced over the two ranks: must equal the same two virtual ranks run as
+# threads of one process (tools/c5_crop_eval.ThreadWorld; a two-term sum is order independent), and must not be worse than without
+net.clear_cache()
+out = md.render_clip_tiled(net, x, times, scale, halo=32, lr_halo=16, sync_norm=True)
+if r == 0:
+    from tools.c5_crop_eval import render_cropped_synced
+    emu = md.frames_to_uint8(render_cropped_synced(net, x, times, 4, 2, 32, 16)).cpu()
+    assert torch.equal(out.cpu(), emu), "two-rank sync_norm run differs from its single-process emulation"
+    mse = float(((out.cpu().double() - ref.double()) ** 2).mean()) / 255.0 ** 2
+    psnr = 99.0 if mse == 0 else 10 * np.log10(1.0 / mse)
+    assert psnr >= plain - 0.2, (psnr, plain)
+    print("DIST_GPU_OK sync_norm PSNR %%.1f dB" %% psnr)
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -60,4 +73,4 @@ def test_two_rank_drivers_with_real_kernels(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29571", str(script)], capture_output=True, text=True, env=env, timeout=900)
-    assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.returncode == 0 and "DIST_GPU_OK cropped-mode" in r.stdout and "DIST_GPU_OK sync_norm" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

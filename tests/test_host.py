@@ -310,6 +310,7 @@ def siren_synth_pre(blob, acc, synth_l0, iy, ix, times, B, N, HH, WW):
     t = times.reshape(B, N).permute(1, 0).reshape(N, B, 1, 1, 1)
     return (t * 0.4 + acc.mean() + synth_l0.mean()).expand(N, B, 3, HH, WW).contiguous()
 ops.siren_flow, ops.splat_motif_pre, ops.siren_synth_pre = siren_flow, splat_motif_pre, siren_synth_pre
+ops.flow_roundtrip = lambda pred, a, b: pred[:, :2] * a * b / a / b
 
 net = Ours.LunaTokis().eval()
 net._pre_plan = lambda: dict(ab=None, synth_blob=None)          # packed weights of the pre-contracted form (device objects)

@@ -301,6 +301,37 @@ def test_resize_bilinear(shape, align):
     close(ops.resize_bilinear(x.to(dev()), (ho, wo), align, 0.25), ref, 2e-6, 0, "resize")
 
 
+def test_instance_norm_with_statistics_over_row_bands():
+    """motif_instance_norm_moments / _apply (statistics of a row-tiled clip all-reduced over ranks): moments over two disjoint row
+    ranges, summed, then applied to the whole plane == F.instance_norm of the plane, for every epilogue mode; a halo row outside the
+    owned range must not enter the statistics."""
+    from motif_amd import ops
+    x = rnd(2, 5, 40, 24, seed=1, scale=2.0) + 0.7
+    res = rnd(2, 5, 40, 24, seed=2)
+    ref = F.instance_norm(x, eps=1e-5)
+    xd, rd = x.to(dev()), res.to(dev())
+    parts = []
+
+    def collect(t):
+        parts.append(t.clone())
+        return t
+    ops.instance_norm_synced(xd, (0, 16), collect, 0)
+    ops.instance_norm_synced(xd, (16, 40), collect, 0)
+    total = parts[0] + parts[1]
+    assert float(total[0, 2]) == 40 * 24
+
+    def use_total(t):
+        t.copy_(total)
+        return t
+    close(ops.instance_norm_synced(xd, (0, 16), use_total, 0), ref, 2e-5, 1e-5, "mode 0")
+    close(ops.instance_norm_synced(xd, (16, 40), use_total, 1), F.relu(ref), 2e-5, 1e-5, "mode 1")
+    close(ops.instance_norm_synced(xd, (3, 9), use_total, 2, res=rd), F.relu(F.relu(ref) + res), 2e-5, 1e-5, "mode 2")
+    close(ops.instance_norm(xd, 0), ref, 2e-5, 1e-5, "single-process kernel")
+    sub = F.instance_norm(x[:, :, 8:24], eps=1e-5)                     # statistics of rows 8..23 only, applied to those rows
+    got = ops.instance_norm_synced(xd, (8, 24), lambda t: t, 0)[:, :, 8:24]
+    close(got, sub, 2e-5, 1e-5, "own rows only")
+
+
 def test_backwarp_and_reliability_maps():
     from oracle.motif_ref import MotifRef, back_warp
     from motif_amd import ops

@@ -519,6 +519,11 @@ def test_c5_cropped_tile_mode_psnr(mma_mode):
     print("c5 cropped tiles (lr_halo %d): PSNR vs untiled %.2f dB, largest crop %d of %d LR rows" % (R, p, worst_rows, h))
     assert p >= 55.0, p
     assert worst_rows <= 0.30 * h
+    # the same eight crops with RAFT's instance-norm statistics all-reduced over the ranks (sync_norm; the ranks are threads here)
+    from tools.c5_crop_eval import render_cropped_synced
+    ps = psnr(render_cropped_synced(net, x, times, s, bands, halo, R), full)
+    print("c5 cropped tiles with sync_norm: PSNR vs untiled %.2f dB" % ps)
+    assert ps >= p - 0.05, (ps, p)
 
 
 def test_c3_crop_bf16_path_vs_oracle(mma_mode):

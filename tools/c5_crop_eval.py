@@ -11,6 +11,82 @@ from motif_amd.models.modules.Ours import LunaTokis
 from motif_amd.utils.synth_weights import fill_state_dict
 
 
+class ThreadWorld:
+    """W virtual ranks of a row-tiled clip on ONE GPU, for the modes that need a collective inside the forward (sync_norm): one
+    thread per rank, only one of them runs at a time (`run` lock: the kernels of all threads go to the same stream in a defined
+    order and the shared workspaces are never used concurrently), and they meet in `reduce_sum`, which plays the SUM all-reduce."""
+
+    def __init__(self, n):
+        import threading
+        self.n, self.run, self.barrier, self.buf, self.errors = n, threading.Lock(), threading.Barrier(n), None, []
+
+    def reduce_sum(self, t):
+        if self.buf is None:
+            self.buf = t.clone()
+        else:
+            self.buf.add_(t)
+        self.run.release()
+        self.barrier.wait()                       # every rank has added its part
+        self.run.acquire()
+        t.copy_(self.buf)
+        self.run.release()
+        if self.barrier.wait() == 0:              # every rank has read the sum
+            self.buf = None
+        self.barrier.wait()
+        self.run.acquire()
+        return t
+
+    def map(self, fn):
+        """fn(rank) on every virtual rank -> list of results in rank order."""
+        import threading
+        out = [None] * self.n
+
+        def body(r):
+            self.run.acquire()
+            try:
+                out[r] = fn(r)
+            except BaseException as e:            # a dead rank must not leave the others in the barrier
+                self.errors.append(e)
+                self.barrier.abort()
+            finally:
+                if self.run.locked():
+                    try:
+                        self.run.release()
+                    except RuntimeError:
+                        pass
+        ts = [threading.Thread(target=body, args=(r,)) for r in range(self.n)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        if self.errors:
+            raise self.errors[0]
+        return out
+
+
+def rank_view(net):
+    """A LunaTokis that shares the parameters of `net` but has its own band / cache / norm_sync state."""
+    import copy
+    v = copy.copy(net)
+    v._cache, v._cache_key, v.band, v.norm_sync = None, None, None, None
+    return v
+
+
+def render_cropped_synced(net, x, times, s, bands, halo, R, chunk=3):
+    """The 8 ranks of render_clip_tiled(lr_halo=R, sync_norm=True) as threads on one GPU -> the HR frames [T,B,3,HH,WW]."""
+    h, HH, WW = x.shape[3], x.shape[3] * s, x.shape[4] * s
+    world = ThreadWorld(bands)
+
+    def one(r):
+        band = md.band_of(HH, r, bands, 16)
+        a, b = md.crop_rows_for_band(band, halo, h, HH, R)
+        v = rank_view(net)
+        v.band, v.band_halo = (band[0] - a * s, band[1] - a * s), halo
+        v.norm_sync = (v.band, world.reduce_sum)
+        xr = x[..., a:b, :].contiguous()
+        with torch.no_grad():
+            return torch.cat([v(xr, None, times[l:l + chunk], [[(b - a) * s], [WW]], use_GT=False, iter=4)[0] for l in range(0, len(times), chunk)], 0)
+    return torch.cat(world.map(one), dim=-2)
+
+
 def main():
     h, w, s, T, bands, halo = 540, 960, 4, 5, 8, 64
     HH, WW = h * s, w * s
@@ -46,6 +122,10 @@ def main():
         psnr = 99.0 if mse == 0 else 10 * np.log10(1.0 / mse)
         print("lr_halo %3d: PSNR(cropped tiles, untiled) = %.2f dB, Linf %.2e; per-rank ms %s -> 8-GPU clip %.1f ms = %.2fx" % (
             R, psnr, float((tiled - full).abs().max()), " ".join("%.0f" % (t * 1e3) for t in ts), max(ts) * 1e3, t_full / max(ts)))
+        synced = render_cropped_synced(net, x, times, s, bands, halo, R)
+        mse = float(((synced.double() - full.double()) ** 2).mean())
+        print("             with sync_norm (RAFT instance-norm statistics all-reduced over the ranks): PSNR %.2f dB, Linf %.2e" % (
+            99.0 if mse == 0 else 10 * np.log10(1.0 / mse), float((synced - full).abs().max())))
 
 
 if __name__ == "__main__":
