@@ -32,19 +32,6 @@ __device__ __forceinline__ float act_c(float v) {
     else return v;
 }
 
-// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in linear-id order;
-// this maps blockIdx.x so that the blocks landing on one XCD get a CONTIGUOUS run of tile ids: vertically adjacent
-// tiles then share their halo rows in that XCD's L2 (measured on the recon-trunk launch: FETCH_SIZE 73 -> 27 MB).
-// A bijection of [0, gridDim.x) for every grid size (tests: tools/ + CPU check in the commit that introduced it).
-__device__ __forceinline__ int xcd_tile_id() {
-    const int gx = gridDim.x;
-    const int off = (int)(((long)(blockIdx.z * gridDim.y + blockIdx.y) * gx) & 7);
-    const int xcd = (blockIdx.x + off) & 7, first = (xcd - off) & 7;
-    int base = 0;
-    for (int c = 0; c < xcd; ++c) { const int f = (c - off) & 7; base += f < gx ? (gx - f + 7) >> 3 : 0; }
-    return base + ((blockIdx.x - first) >> 3);
-}
-
 // The activation / residual mode is block-uniform: dispatch ONCE to a specialised body `run(actf, res_tag)`;
 // actf(v, residual, cout) -> stored value, res_tag = std::true_type when a residual tensor is read.
 template <bool SPECIALISE = true, class RUN>
