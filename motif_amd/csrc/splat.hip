@@ -217,6 +217,7 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
     unsigned* tcnt = tmaxb + OT_TP;                                  // [OT_TP] hit count
     int* texp = (int*)(tcnt + OT_TP);                                // [OT_TP] per-cell scale exponent E
     unsigned* list = (unsigned*)(texp + OT_TP);                      // [cap]
+    unsigned* segbase = list + cap;                                  // [192] hits per 64-source segment, then their prefix sums
     __shared__ unsigned count;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bn = blockIdx.z, b = bn / a.N, n = bn % a.N;
@@ -231,25 +232,49 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
     const int rx0 = max(tx0 - a.R, 0), rx1 = min(tx0 + OT_W - 1 + a.R, a.WW - 1);
     const int RH = ry1 - ry0 + 1, RW = rx1 - rx0 + 1;
     const int xiters = (RW + 63) >> 6;
-    for (int d = 0; d < 2; ++d) {
-        const int img = (d * a.B + b) * a.N + n;
-        for (int row = wave; row < RH; row += OT_THREADS / 64) {
-            for (int it = 0; it < xiters; ++it) {
-                const int xc = it * 64 + lane;
-                bool hit = false;
-                if (xc < RW) {
-                    const SrcGeom g = src_geom(a, img, rx0 + xc, ry0 + row, false);
-                    hit = g.near_ && g.x0 >= tx0 - 1 && g.x0 <= tx0 + OT_W - 1 && g.y0 >= ty0 - 1 && g.y0 <= ty0 + OT_H - 1;
-                }
-                const unsigned long long m = __ballot(hit);
-                if (m) {
-                    unsigned base = 0;
-                    if (lane == 0) base = atomicAdd(&count, (unsigned)__popcll(m));
-                    base = __shfl(base, 0);
-                    if (hit) list[base + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned)d << 16) | ((unsigned)row << 8) | (unsigned)xc;
-                }
-            }
-        }
+    // The list is written in SCAN ORDER (direction, row, column), not in the order the waves happen to finish: ballot counts per
+    // 64-source segment, one prefix sum, then every hit goes to its rank.  Consecutive entries are then consecutive sources of
+    // one row -- whose targets are consecutive accumulator cells for any smooth flow -- so the 64 lanes of an LDS-atomic instruction
+    // in pass 2 hit 64 consecutive 8-byte cells (bank-conflict free) instead of pieces of several rows (rocprofv3: 56 % of the LDS
+    // cycles of this kernel were bank conflicts with the append-as-you-go list).  Slot j = (row step, direction, segment) is a
+    // compile-time loop with unconditional, clamped loads.
+    constexpr int NWV = OT_THREADS / 64, RSTEPS = (OT_H + 32 + NWV - 1) / NWV, XIT = (OT_W + 32 + 63) / 64, NJ = RSTEPS * 2 * XIT;
+    static_assert(NJ <= 32 && 2 * (OT_H + 32) * XIT <= 192, "hit bits / segment scan sizes");
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned hitbits = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int r = j / (2 * XIT), d = (j / XIT) & 1, it = j % XIT;
+        const int row = wave + NWV * r, xc = it * 64 + lane;
+        const bool valid = row < RH && xc < RW;
+        const SrcGeom g = src_geom(a, (d * a.B + b) * a.N + n, rx0 + min(xc, RW - 1), ry0 + min(row, RH - 1), false);
+        const bool hit = valid && g.near_ && g.x0 >= tx0 - 1 && g.x0 <= tx0 + OT_W - 1 && g.y0 >= ty0 - 1 && g.y0 <= ty0 + OT_H - 1;
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0 && row < RH && it < xiters) segbase[(d * RH + row) * xiters + it] = (unsigned)__popcll(m);
+        if (hit) hitbits |= 1u << j;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int nseg = 2 * RH * xiters;
+        unsigned v[3], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const int sid = lane * 3 + i; v[i] = sid < nseg ? segbase[sid] : 0u; sum += v[i]; }
+        unsigned incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        unsigned run = incl - sum;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const int sid = lane * 3 + i; if (sid < nseg) segbase[sid] = run; run += v[i]; }
+        if (lane == 63) count = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int r = j / (2 * XIT), d = (j / XIT) & 1, it = j % XIT;
+        const int row = wave + NWV * r;
+        const bool hit = (hitbits >> j) & 1u;
+        const unsigned long long m = __ballot(hit);
+        if (hit) list[segbase[(d * RH + row) * xiters + it] + (unsigned)__popcll(m & lt)] = ((unsigned)d << 16) | ((unsigned)row << 8) | (unsigned)(it * 64 + lane);
     }
     __syncthreads();
     const int cnt = (int)count;
@@ -395,7 +420,7 @@ __global__ __launch_bounds__(256) void splat_far_kernel(MotifSplatArgs a, int ti
 template <bool PRE>
 static int launch_motif_splat(MotifSplatArgs a, void* stream) {
     const int cap = 2 * (OT_H + 2 * a.R) * (OT_W + 2 * a.R);
-    const size_t lds = (size_t)OT_CC * OT_TP * 8 + (size_t)3 * OT_TP * 4 + (size_t)cap * 4;
+    const size_t lds = (size_t)OT_CC * OT_TP * 8 + (size_t)3 * OT_TP * 4 + (size_t)cap * 4 + 192 * 4;
     hipError_t e = hipFuncSetAttribute((const void*)splat_owner_kernel<PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     dim3 grid((a.WW + OT_W - 1) / OT_W, (a.HH + OT_H - 1) / OT_H, a.B * a.N);
