@@ -112,7 +112,7 @@ extern "C" int motif_splat_fwd(const float* src, const float* flow, const float*
 // Forward splatting is a scatter, but the predicted HR flow is locally bounded, so it can be turned
 // inside out: a workgroup OWNS a 16x64 tile of the accumulator, scans the source pixels of BOTH
 // directions within +-R of the tile, keeps those whose 2x2 footprint touches the tile (compacted into an
-// LDS list with a wave-aggregated append), accumulates 8 accumulator planes at a time in LDS (the padded
+// LDS list in scan order: ballot counts per 64-source segment + one prefix sum), accumulates 8 accumulator planes at a time in LDS (the padded
 // 18x66 tile absorbs footprint cells that spill over the border, so the inner loop has no bounds tests),
 // and writes each finished plane tile with plain coalesced stores.
 // LDS accumulation is 32.32 FIXED POINT with ds_add_u64, on a PER-CELL binary scale: measured on MI355X
