@@ -43,7 +43,9 @@ __global__ __launch_bounds__(256) void raft_lookup_kernel(LookupArgs a) {
     const int gy = lane >> 3, gx = lane & 7;
     const int sub = lane & 15, grp = lane >> 4;
     for (int i = 0; i < 16; ++i) {
-        const int ql = wave * 16 + i;
+        // the four waves work on four ADJACENT pixels at a time: their 8x8 windows overlap, so the lines one wave pulls into the L1 serve
+        // the others (16 pixels apart they shared nothing and each window is the size of the L1)
+        const int ql = i * 4 + wave;
         const long q = q0 + ql;
         if (q >= HW1) break;                                    // wave-uniform
         const float x = a.coords[((long)b * 2) * HW1 + q] * cs;
