@@ -436,7 +436,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
     float* wl0 = win0 + 2 * DF_CH * WSZ;                 // [2][WCH] weight fragments of a chunk
     float* bias_s = wl0 + 2 * WCH;                       // [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    const int tile_id = xcd_tile_id();                   // an XCD gets a contiguous run of tiles: neighbouring windows overlap 4.5x
+    const int tx = tile_id % a.tiles_x, ty = tile_id / a.tiles_x;
     const int cg = blockIdx.y;
     const int pz = blockIdx.z / a.B, b = blockIdx.z - pz * a.B;
     const int H = a.H, W = a.W;
