@@ -221,7 +221,10 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
     __shared__ unsigned count;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bn = blockIdx.z, b = bn / a.N, n = bn % a.N;
-    const int tx0 = blockIdx.x * OT_W, ty0 = blockIdx.y * OT_H;
+    // 1-D tile grid in XCD-aware order: an XCD gets a contiguous run of tiles (several tile rows), so the +-16-pixel scan regions
+    // of neighbouring tiles share its L2
+    const int tiles_x = (a.WW + OT_W - 1) / OT_W, tile_id = xcd_tile_id();
+    const int tx0 = (tile_id % tiles_x) * OT_W, ty0 = (tile_id / tiles_x) * OT_H;
     const long Q = (long)a.HH * a.WW, HWl = (long)a.H * a.W;
     if (tid == 0) count = 0;
     for (int i = tid; i < OT_TP; i += OT_THREADS) { tmaxb[i] = 0u; tcnt[i] = 0u; }
@@ -423,7 +426,7 @@ static int launch_motif_splat(MotifSplatArgs a, void* stream) {
     const size_t lds = (size_t)OT_CC * OT_TP * 8 + (size_t)3 * OT_TP * 4 + (size_t)cap * 4 + 192 * 4;
     hipError_t e = hipFuncSetAttribute((const void*)splat_owner_kernel<PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    dim3 grid((a.WW + OT_W - 1) / OT_W, (a.HH + OT_H - 1) / OT_H, a.B * a.N);
+    dim3 grid(((a.WW + OT_W - 1) / OT_W) * ((a.HH + OT_H - 1) / OT_H), 1, a.B * a.N);
     splat_owner_kernel<PRE><<<grid, OT_THREADS, lds, (hipStream_t)stream>>>(a, cap);
     MOTIF_LAUNCH_CHECK();
     const int tiles_x = (a.WW + 63) / 64, tiles_y = (a.HH + 3) / 4;
