@@ -36,6 +36,16 @@ extern "C" {
 int motif_abi_version(void);                 /* bumps when any signature below changes */
 int motif_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
+/* Tuning / test switches (no reference counterpart; the reference has no kernel-selection knobs).  The library reads the
+ * environment ONCE, at its first call (MOTIF_<NAME> in upper case, e.g. MOTIF_CONV_ENGINE=1), never per launch; after that
+ * the values change only through motif_set_option.  Every option defaults to 0 = "let the library choose"; none of them
+ * changes a result beyond kernel-selection rounding.  Names: conv_dbg, conv_ck, conv_nospec, conv_engine (1 = the round-2
+ * two-block kernel instead of the ping-pong kernel), pp_rp (rows per wave 2 / 3), lds_pad, corr81 (1 tiled / 2 small),
+ * dcn_nowin, dcn_waves (4 / 8), dcn_front_pad, dcn_back_pad, siren_stagger.  Returns MOTIF_EINVAL for an unknown name.
+ * Not thread-safe against concurrent launches -- a test / tuning aid, not part of the data path. */
+int motif_set_option(const char* name, int value);
+int motif_get_option(const char* name, int* value);
+
 /* ------------------------------------------------------------------------------------------------
  * A1-A3  fused soft-splat forward.
  * Replaces the three cupy launches of kernel_Softsplat_updateOutput:

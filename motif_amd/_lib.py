@@ -25,6 +25,8 @@ P = c_void_p
 _SIGS = {
     "motif_abi_version": (c_int, []),
     "motif_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
+    "motif_set_option": (c_int, [c_char_p, c_int]),
+    "motif_get_option": (c_int, [c_char_p, POINTER(c_int)]),
     "motif_splat_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "motif_splat_motif_fwd": (c_int, [P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_splat_motif_acc_fwd": (c_int, [P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

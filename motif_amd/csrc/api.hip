@@ -2,7 +2,7 @@
 #include "common.h"
 #include <string.h>
 
-extern "C" int motif_abi_version(void) { return 2; }   // 2: MotifConvDesc.mma, motif_siren_pack_split + pre=2, splat row0
+extern "C" int motif_abi_version(void) { return 3; }   // 3: motif_set_option / motif_get_option (2: MotifConvDesc.mma, motif_siren_pack_split + pre=2, splat row0)
 
 extern "C" int motif_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len) {
     int dev = 0;
@@ -14,5 +14,52 @@ extern "C" int motif_device_info(int* cu_count, int* lds_bytes, char* arch, int 
     if (cu_count) *cu_count = p.multiProcessorCount;
     if (lds_bytes) *lds_bytes = (int)p.maxSharedMemoryPerMultiProcessor;
     if (arch && arch_len > 0) { strncpy(arch, p.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+    return MOTIF_OK;
+}
+
+// ---- tuning / test switches: environment read once, then motif_set_option only ---------------------------------------
+#include <stdlib.h>
+#include <ctype.h>
+namespace {
+const char* const kOptNames[MOTIF_OPT_COUNT] = {"conv_dbg", "conv_ck", "conv_nospec", "conv_engine", "pp_rp", "lds_pad", "corr81",
+                                                "dcn_nowin", "dcn_waves", "dcn_front_pad", "dcn_back_pad", "siren_stagger"};
+struct OptTable {
+    int v[MOTIF_OPT_COUNT];
+    OptTable() {
+        for (int i = 0; i < MOTIF_OPT_COUNT; ++i) {
+            char env[64] = "MOTIF_";
+            int k = 6;
+            for (const char* c = kOptNames[i]; *c && k < 62; ++c) env[k++] = (char)toupper((unsigned char)*c);
+            env[k] = 0;
+            const char* e = getenv(env);
+            v[i] = 0;
+            if (e && *e) {
+                if (i == MOTIF_OPT_CORR81) v[i] = !strcmp(e, "tiled") ? 1 : !strcmp(e, "small") ? 2 : atoi(e);
+                else v[i] = atoi(e);
+            }
+        }
+    }
+};
+OptTable& opt_table() { static OptTable t; return t; }
+int opt_index(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < MOTIF_OPT_COUNT; ++i) if (!strcmp(name, kOptNames[i])) return i;
+    return -1;
+}
+}  // namespace
+
+int motif_opt(int id) { return opt_table().v[id]; }
+
+extern "C" int motif_set_option(const char* name, int value) {
+    const int i = opt_index(name);
+    if (i < 0) return MOTIF_EINVAL;
+    opt_table().v[i] = value;
+    return MOTIF_OK;
+}
+
+extern "C" int motif_get_option(const char* name, int* value) {
+    const int i = opt_index(name);
+    if (i < 0 || !value) return MOTIF_EINVAL;
+    *value = opt_table().v[i];
     return MOTIF_OK;
 }

@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), "libmotif_hip.so")
-SOURCES = ["api.hip", "conv_igemm.hip", "conv_split.hip", "siren.hip", "siren_split.hip", "splat.hip", "misc.hip", "corr.hip", "dcn.hip"]
+SOURCES = ["api.hip", "conv_igemm.hip", "conv_split.hip", "conv_pp.hip", "siren.hip", "siren_split.hip", "splat.hip", "misc.hip", "corr.hip", "dcn.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value",
          "-Wno-pass-failed"]
 
@@ -19,7 +19,7 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
-    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "conv_common.h"), os.path.join(HERE, "siren_common.h"), os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "motif_hip.h")]
+    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "conv_common.h"), os.path.join(HERE, "conv_split_common.h"), os.path.join(HERE, "siren_common.h"), os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "motif_hip.h")]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs, jobs = [], []

@@ -270,8 +270,7 @@ bool plan_conv(const MotifConvDesc* d, ConvPlan* p) {
             if ((c & 1) == 0 && (!two || d->C0 % c == 0) && (long)c * PHW <= PATCH_MAX && (long)c * p->T * p->WN <= WCHUNK_MAX) { ck = c; break; }
     }
     if (ck == 0) return false;
-    if (const char* e = getenv("MOTIF_CONV_CK")) {            // tuning aid
-        const int f = atoi(e);
+    if (const int f = motif_opt(MOTIF_OPT_CONV_CK)) {         // tuning aid
         if (f > 0 && f <= ck && (f & 1) == 0 && (!two || d->C0 % f == 0)) ck = f;
     }
     p->CK = ck;
@@ -323,8 +322,7 @@ extern "C" int motif_conv2d_fwd_multi(const MotifConvDesc* d, int P, const float
         a.out_bs[i] = (out_bs && out_bs[j]) ? out_bs[j] : (long)d->Cout * HWo;
     }
     a.N = d->N;
-    a.dbg = 0;
-    if (const char* e = getenv("MOTIF_CONV_DBG")) a.dbg = atoi(e);
+    a.dbg = motif_opt(MOTIF_OPT_CONV_DBG);
     if (split) {
         a.C0 = d->C0; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
         a.KH = 3; a.KW = 3; a.stride = 1; a.pad = d->pad; a.dil = 1; a.pad_mode = d->pad_mode;
@@ -341,7 +339,7 @@ extern "C" int motif_conv2d_fwd_multi(const MotifConvDesc* d, int P, const float
     a.ncg = p.ncg;
     dim3 grid(a.tiles_x * tiles_y, d->groups * p.ncg, d->N * P);
     hipStream_t s = (hipStream_t)stream;
-    const bool spec = d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1 && !getenv("MOTIF_CONV_NOSPEC");
+    const bool spec = d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1 && !motif_opt(MOTIF_OPT_CONV_NOSPEC);
 #define MOTIF_LAUNCH_CONV(NCV, SPECV)                                                                                        \
     do {                                                                                                                     \
         if (p.lds > 64 * 1024)                                                                                               \

@@ -18,47 +18,9 @@
 //     walks the same 6 KB per k-step), one k-step ahead in registers;
 //   * k-step = (16-channel group, tap); lower half-wave = channels 0..7 of the group, upper = 8..15.
 // The epilogue (bias, residual, activation, planar stores) is the one of the fp32 engine: same C/D layout.
-#include "conv_common.h"
+#include "conv_split_common.h"
 #include <stdlib.h>
 #include <type_traits>
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-namespace {
-// (weight part, activation part) of each product, smallest terms first
-template <int NP> struct SplitProducts;
-template <> struct SplitProducts<1> { static constexpr int n = 1; static constexpr int w[1] = {0}; static constexpr int x[1] = {0}; };
-template <> struct SplitProducts<2> { static constexpr int n = 3; static constexpr int w[3] = {1, 0, 0}; static constexpr int x[3] = {0, 1, 0}; };
-template <> struct SplitProducts<3> {
-    static constexpr int n = 6;
-    static constexpr int w[6] = {2, 0, 1, 1, 0, 0};
-    static constexpr int x[6] = {0, 2, 1, 0, 1, 0};
-};
-
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
-    bf16x2 p = {(__bf16)a, (__bf16)b};
-    return __builtin_bit_cast(unsigned, p);
-}
-__device__ __forceinline__ float bf_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float bf_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-
-// 8 floats -> NP packed-bf16 quads (part 0 = leading bits)
-template <int NP>
-__device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[NP]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float x0 = v[2 * q], x1 = v[2 * q + 1];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const unsigned pk = pk_bf16(x0, x1);
-            out[p][q] = pk;
-            if (p + 1 < NP) { x0 -= bf_lo(pk); x1 -= bf_hi(pk); }
-        }
-    }
-}
-}  // namespace
 
 #ifdef MOTIF_TRACE
 __device__ long long g_trace[4096 * 16];
@@ -258,7 +220,6 @@ __global__ void conv_split_pack_kernel(const float* w, unsigned short* wp, int C
 }
 
 // ---- host side (called from conv_igemm.hip's entry points) -------------------------------------------------------
-static int split_parts(int mma) { return mma == 6 ? 3 : mma == 3 ? 2 : mma == 1 ? 1 : 0; }
 
 // The engine takes a layer when it is 3x3, stride 1, dilation 1 with > 32 couts and >= 16 input channels per group
 // (depends on the weight shape and hyper-parameters only, so pack and forward always agree).
@@ -286,6 +247,7 @@ int motif_conv_split_pack(const MotifConvDesc* d, const float* weight, float* pa
 }
 
 int motif_conv_split_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s) {
+    if (motif_opt(MOTIF_OPT_CONV_ENGINE) != 1 && motif_conv_pp_eligible(d, a, P)) return motif_conv_pp_launch(d, a, P, s);   // round 3: the ping-pong kernel
     const int Cin_g = (d->C0 + d->C1) / d->groups, Cout_g = d->Cout / d->groups;
     if (d->C1 > 0 && (d->groups != 1 || d->C0 % 16)) return MOTIF_ELIMIT;   // a 16-channel chunk must not straddle the sources
     if ((long)d->H * d->W * 16 >= 0x7fffffffL) return MOTIF_ELIMIT;
@@ -301,7 +263,7 @@ int motif_conv_split_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStrea
     size_t ldsb = (size_t)2 * NP * (2 * (TH + 2) * 34 + 4) * 16;
     const size_t scratch = (size_t)32 * (TH * 32 + 8) * 4;                      // epilogue transpose of one 32-cout tile
     ldsb = (ldsb > scratch ? ldsb : scratch) + 64 * 4;
-    if (const char* e = getenv("MOTIF_LDS_PAD")) ldsb = (ldsb + atoi(e) - 1) / atoi(e) * atoi(e);
+    if (const int pad = motif_opt(MOTIF_OPT_LDS_PAD); pad > 0) ldsb = (ldsb + pad - 1) / pad * pad;
     dim3 grid(a.tiles_x * tiles_y, d->groups * a.ncg, d->N * P);
 #define MOTIF_LAUNCH_SPLIT(NPV, WV)                                                                                     \
     do {                                                                                                                \

@@ -286,8 +286,8 @@ __global__ void corr81_small_kernel(const float* __restrict__ f1, const float* _
 extern "C" int motif_corr81_fwd(const float* first, const float* second, float* out, int B, int C, int H, int W,
                                 int act, void* stream) {
     if (!first || !second || !out || B < 1 || C < 1) return MOTIF_EINVAL;
-    const char* force = getenv("MOTIF_CORR81");              // "tiled" / "small": tests and tools/pwc_bench.py
-    const bool tiled = force ? force[0] == 't' : (long)H * W >= 64L * 96;
+    const int force = motif_opt(MOTIF_OPT_CORR81);           // 1 = tiled, 2 = small: tests and tools/pwc_bench.py
+    const bool tiled = force ? force == 1 : (long)H * W >= 64L * 96;
     if (tiled) {
         dim3 grid(cdiv(W, C81_TW), cdiv(H, C81_TH), B);
         corr81_tiled_kernel<<<grid, C81_NT, 0, (hipStream_t)stream>>>(first, second, out, C, H, W, act);

@@ -757,13 +757,13 @@ extern "C" int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, co
     // and the model-level run-to-run test keep watching it.  MOTIF_DCN_WAVES=8 / 4 forces a form.
     // window form (dcn_win_kernel): bf16x3 engine, rows of whole 16-byte units, 32-bit offsets over 4 planes; one 8-wave block
     // per CU (147 KB of LDS)
-    const bool win_ok = mma == 6 && (W & 3) == 0 && W >= 4 && (long)DF_CH * HW < (1L << 30) && !getenv("MOTIF_DCN_NOWIN") &&
+    const bool win_ok = mma == 6 && (W & 3) == 0 && W >= 4 && (long)DF_CH * HW < (1L << 30) && !motif_opt(MOTIF_OPT_DCN_NOWIN) &&
                         (((unsigned long long)a.im[0] | (unsigned long long)a.im[1] | (unsigned long long)a.im[2] | (unsigned long long)a.im[3]) & 15) == 0 &&
                         ((a.im_bs[0] | a.im_bs[1] | a.im_bs[2] | a.im_bs[3]) & 3) == 0;
     int waves = (!win_ok && (long)H * W >= 90L * 160) ? 4 : 8;
-    if (const char* ev = getenv("MOTIF_DCN_WAVES")) waves = atoi(ev) == 4 ? 4 : 8;
-    a.front_pad = getenv("MOTIF_DCN_FRONT_PAD") ? atoi(getenv("MOTIF_DCN_FRONT_PAD")) : 0;
-    const int back_pad = getenv("MOTIF_DCN_BACK_PAD") ? atoi(getenv("MOTIF_DCN_BACK_PAD")) : 0;
+    if (const int wv = motif_opt(MOTIF_OPT_DCN_WAVES)) waves = wv == 4 ? 4 : 8;
+    a.front_pad = motif_opt(MOTIF_OPT_DCN_FRONT_PAD);
+    const int back_pad = motif_opt(MOTIF_OPT_DCN_BACK_PAD);
     const int wch = mma == 6 ? 3 * 3 * 2 * 64 * 4 : DF_ROWS * 64;
     const size_t lds = (size_t)(2 * DF_ROWS * 32 * waves + 2 * wch + 64 + a.front_pad + back_pad) * 4;
     dim3 grid(a.tiles_x * ((H + waves - 1) / waves), a.ncg, P * B);

@@ -460,7 +460,7 @@ static int launch_siren(const SirenArgs& a_in, void* stream) {
     static_assert(L::LDS_FLOATS % 4 == 0, "blob prefix must be float4 sized");
     SirenArgs a = a_in;
     a.stagger = 2;
-    if (const char* e = getenv("MOTIF_SIREN_STAGGER")) a.stagger = atoi(e);
+    if (const int sv = motif_opt(MOTIF_OPT_SIREN_STAGGER)) a.stagger = sv < 0 ? 0 : sv;
     hipError_t e = hipFuncSetAttribute((const void*)siren_kernel<MODE, TP, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;

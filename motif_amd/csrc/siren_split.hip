@@ -740,7 +740,7 @@ static int launch_siren_split(const SirenArgs& a_in, void* stream) {
     static_assert(L::LDS_BYTES <= 160 * 1024, "resident part of the packed network must fit the 160 KB LDS");
     SirenArgs a = a_in;
     a.stagger = 4;
-    if (const char* e = getenv("MOTIF_SIREN_STAGGER")) a.stagger = atoi(e);
+    if (const int sv = motif_opt(MOTIF_OPT_SIREN_STAGGER)) a.stagger = sv < 0 ? 0 : sv;
     hipError_t e = hipFuncSetAttribute((const void*)siren_split_kernel<MODE, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;

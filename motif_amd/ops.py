@@ -77,6 +77,17 @@ def get_conv_mma():
     return _conv_mma
 
 
+def set_option(name, value):
+    """Tuning / test switch of the device library (include/motif_hip.h: motif_set_option); 0 = library default."""
+    check(_lib.load().motif_set_option(name.encode(), int(value)), "motif_set_option(%s)" % name)
+
+
+def get_option(name):
+    v = ctypes.c_int(0)
+    check(_lib.load().motif_get_option(name.encode(), ctypes.byref(v)), "motif_get_option(%s)" % name)
+    return v.value
+
+
 class ConvPlan:
     """Packed weights of one convolution layer, re-packed when the parameter (or the mma mode) changes."""
 

@@ -194,6 +194,30 @@ def test_conv_split_multi_problem_and_views(keep_mma):
     assert float(buf[:, :8].abs().max()) == 0 and float(buf[:, 72:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 64, 180, 320), (2, 64, 216, 90, 160), (5, 128, 64, 63, 100), (1, 48, 80, 19, 36)])
+def test_conv_pp_persistent_tiles(shape, keep_mma):
+    """The ping-pong kernel over MANY tiles per workgroup (persistent loop, both halves, tile-boundary epilogues, ragged last
+    tile row / column, partial cout group, channel padding) against torch on the host and against the round-2 kernel."""
+    from motif_amd import ops
+    from motif_amd.models.modules.layers import Conv2d
+    n, cin, cout, H, W = shape
+    m = Conv2d(cin, cout, 3, 1, 1)
+    with torch.no_grad():
+        m.weight.copy_(rnd(*m.weight.shape, seed=1, scale=1.0 / math.sqrt(cin * 9)))
+        m.bias.copy_(rnd(cout, seed=2, scale=0.1))
+    x, res = rnd(n, cin, H, W, seed=3), rnd(n, cout, H, W, seed=4)
+    ref = F.relu(F.conv2d(x, m.weight, m.bias, 1, 1)) + res
+    m = m.to(dev())
+    ops.set_conv_mma(ops.MMA_BF16X3)
+    try:
+        out = m(x.to(dev()), act=ops.ACT_RELU, res=res.to(dev()), res_mode=2)
+        ops.set_option("conv_engine", 1)
+        old = m(x.to(dev()), act=ops.ACT_RELU, res=res.to(dev()), res_mode=2)
+    finally:
+        ops.set_option("conv_engine", 0)
+    close(out, ref, 2e-5, 2e-5, "pp vs torch")
+    close(out, old, 2e-6, 2e-6, "pp vs two-block kernel")
+
 
 # ------------------------------------------------------------------------------------------- DCNv2
 def test_dcn_matches_kernel_text_restatement():
@@ -435,16 +459,19 @@ def test_raft_lookup_vs_alt_corr_restatement_and_corrblock():
 
 @pytest.mark.parametrize("kernel", ["small", "tiled"])
 @pytest.mark.parametrize("shape", [(2, 33, 12, 20), (1, 19, 37, 70), (1, 8, 64, 96)])
-def test_corr81(kernel, shape, monkeypatch):
+def test_corr81(kernel, shape):
     """Both cost-volume kernels (per-displacement threads for the coarse levels, LDS-tiled + register-blocked for the large
     ones) against the kernel-text restatement: ragged tiles, W % 4 != 0 (scalar edge path), C not a multiple of the chunk."""
     from oracle import native
     from motif_amd import ops
-    monkeypatch.setenv("MOTIF_CORR81", kernel)
     n, c, h, w = shape
     a, b = rnd(n, c, h, w, seed=1), rnd(n, c, h, w, seed=2)
-    close(ops.corr81(a.to(dev()), b.to(dev())), native.corr81(a, b), 2e-6, 1e-5, "corr81")
-    close(ops.corr81(a.to(dev()), b.to(dev()), ops.ACT_LRELU), F.leaky_relu(native.corr81(a, b), 0.1), 2e-6, 1e-5)
+    ops.set_option("corr81", {"tiled": 1, "small": 2}[kernel])     # the library reads no environment per launch
+    try:
+        close(ops.corr81(a.to(dev()), b.to(dev())), native.corr81(a, b), 2e-6, 1e-5, "corr81")
+        close(ops.corr81(a.to(dev()), b.to(dev()), ops.ACT_LRELU), F.leaky_relu(native.corr81(a, b), 0.1), 2e-6, 1e-5)
+    finally:
+        ops.set_option("corr81", 0)
 
 
 # ------------------------------------------------------------------------------------------- SIREN MLPs

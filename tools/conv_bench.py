@@ -17,25 +17,38 @@ SHAPES = [  # N, Cin, Cout, k, stride, H, W
     (8, 64, 216, 3, 1, 45, 80),
     (8, 64, 64, 3, 1, 90, 160),
     (2, 64, 64, 3, 1, 90, 160),
+    (8, 128, 64, 3, 1, 180, 320),
+    (8, 64, 216, 3, 1, 180, 320),
+    (2, 242, 96, 3, 1, 90, 160),
+    (2, 64, 64, 3, 1, 180, 320),
+    (2, 128, 256, 3, 1, 180, 320),
+    (8, 128, 64, 3, 1, 90, 160),
+    (8, 64, 216, 3, 1, 90, 160),
 ]
 
 def main():
     reps = int(os.environ.get("REPS", "20"))
     only = os.environ.get("ONLY")
     from motif_amd import ops
-    print("conv mma mode", ops.get_conv_mma())
+    if os.environ.get("ENGINE"):
+        ops.set_option("conv_engine", int(os.environ["ENGINE"]))      # 1 = round-2 two-block kernel, 0 = ping-pong kernel
+    if os.environ.get("RP"):
+        ops.set_option("pp_rp", int(os.environ["RP"]))
+    print("conv mma mode", ops.get_conv_mma(), "engine", ops.get_option("conv_engine"), "pp_rp", ops.get_option("pp_rp"))
     for i, (n, ci, co, k, s, h, w) in enumerate(SHAPES):
         if only is not None and int(only) != i:
             continue
         m = Conv2d(ci, co, k, s, k // 2).cuda()
         x = torch.randn(n, ci, h, w, device="cuda")
+        res = torch.randn(n, co, h // s, w // s, device="cuda") if os.environ.get("RES") else None
+        kw = dict(act=1, res=res, res_mode=1) if res is not None else dict(act=1)
         for _ in range(3):
-            y = m(x, act=1)
+            y = m(x, **kw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            y = m(x, act=1)
+            y = m(x, **kw)
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1000 / reps

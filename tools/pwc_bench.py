@@ -47,10 +47,10 @@ def main():
         out0 = torch.empty(B, 81, H, W, device="cuda")
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         t0 = timeit(lambda: lib.corr81_naive(a.data_ptr(), b.data_ptr(), out0.data_ptr(), B, C, H, W, st))
-        os.environ["MOTIF_CORR81"] = "tiled"
+        ops.set_option("corr81", 1)
         t1 = timeit(lambda: ops.corr81(a, b))
         d = float((ops.corr81(a, b) - out0).abs().max())
-        del os.environ["MOTIF_CORR81"]
+        ops.set_option("corr81", 0)
         t2 = timeit(lambda: ops.corr81(a, b))                    # the library's own choice for this size
         print("(%3d,%3d,%3d)        %8.1f   %8.1f   %7.2fx   %10.1f      %.1e   auto: %.1f us" % (
             C, H, W, t0, t1, t0 / t1, 2.0 * B * 81 * C * H * W / t1 / 1e3, d, t2))
