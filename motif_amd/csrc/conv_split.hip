@@ -247,7 +247,7 @@ int motif_conv_split_pack(const MotifConvDesc* d, const float* weight, float* pa
 }
 
 int motif_conv_split_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s) {
-    if (motif_opt(MOTIF_OPT_CONV_ENGINE) != 1 && motif_conv_pp_eligible(d, a, P)) return motif_conv_pp_launch(d, a, P, s);   // round 3: the ping-pong kernel
+    if (motif_opt(MOTIF_OPT_CONV_ENGINE) != 1 && motif_conv_split2_eligible(d, a, P)) return motif_conv_split2_launch(d, a, P, s);   // round 3: conv_split2.hip
     const int Cin_g = (d->C0 + d->C1) / d->groups, Cout_g = d->Cout / d->groups;
     if (d->C1 > 0 && (d->groups != 1 || d->C0 % 16)) return MOTIF_ELIMIT;   // a 16-channel chunk must not straddle the sources
     if ((long)d->H * d->W * 16 >= 0x7fffffffL) return MOTIF_ELIMIT;

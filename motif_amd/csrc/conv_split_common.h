@@ -43,6 +43,6 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[NP]) {
 
 static inline int split_parts(int mma) { return mma == 6 ? 3 : mma == 3 ? 2 : mma == 1 ? 1 : 0; }
 
-// ping-pong kernel (conv_pp.hip): same packed weights, same ConvArgs as conv_split.hip
-bool motif_conv_pp_eligible(const MotifConvDesc* d, const ConvArgs& a, int P);
-int motif_conv_pp_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s);
+// round-3 kernel (conv_split2.hip): same packed weights, same ConvArgs as conv_split.hip
+bool motif_conv_split2_eligible(const MotifConvDesc* d, const ConvArgs& a, int P);
+int motif_conv_split2_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s);

@@ -195,8 +195,8 @@ def test_conv_split_multi_problem_and_views(keep_mma):
 
 
 @pytest.mark.parametrize("shape", [(3, 64, 64, 180, 320), (2, 64, 216, 90, 160), (5, 128, 64, 63, 100), (1, 48, 80, 19, 36)])
-def test_conv_pp_persistent_tiles(shape, keep_mma):
-    """The ping-pong kernel over MANY tiles per workgroup (persistent loop, both halves, tile-boundary epilogues, ragged last
+def test_conv_split2_persistent_tiles(shape, keep_mma):
+    """The round-3 conv kernel over MANY tiles per workgroup (persistent loop, next tile staged under the last chunk, ragged last
     tile row / column, partial cout group, channel padding) against torch on the host and against the round-2 kernel."""
     from motif_amd import ops
     from motif_amd.models.modules.layers import Conv2d
@@ -210,13 +210,14 @@ def test_conv_pp_persistent_tiles(shape, keep_mma):
     m = m.to(dev())
     ops.set_conv_mma(ops.MMA_BF16X3)
     try:
+        ops.set_option("conv_engine", 2)                  # the round-3 kernel whatever the tile count
         out = m(x.to(dev()), act=ops.ACT_RELU, res=res.to(dev()), res_mode=2)
         ops.set_option("conv_engine", 1)
         old = m(x.to(dev()), act=ops.ACT_RELU, res=res.to(dev()), res_mode=2)
     finally:
         ops.set_option("conv_engine", 0)
-    close(out, ref, 2e-5, 2e-5, "pp vs torch")
-    close(out, old, 2e-6, 2e-6, "pp vs two-block kernel")
+    close(out, ref, 2e-5, 2e-5, "split2 vs torch")
+    close(out, old, 2e-6, 2e-6, "split2 vs two-block kernel")
 
 
 # ------------------------------------------------------------------------------------------- DCNv2

@@ -31,7 +31,7 @@ def main():
     only = os.environ.get("ONLY")
     from motif_amd import ops
     if os.environ.get("ENGINE"):
-        ops.set_option("conv_engine", int(os.environ["ENGINE"]))      # 1 = round-2 two-block kernel, 0 = ping-pong kernel
+        ops.set_option("conv_engine", int(os.environ["ENGINE"]))      # 1 = round-2 two-block kernel, 2 = round-3 kernel, 0 = by tile count
     if os.environ.get("RP"):
         ops.set_option("pp_rp", int(os.environ["RP"]))
     print("conv mma mode", ops.get_conv_mma(), "engine", ops.get_option("conv_engine"), "pp_rp", ops.get_option("pp_rp"))
