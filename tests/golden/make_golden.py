@@ -246,6 +246,95 @@ def pwc_case():
     print("pwc flow", tuple(flow.shape), float(flow.abs().mean()))
 
 
+def corr_case():
+    """Row C2: the RAFT correlation look-up pinned by the reference's OWN code.  alt_cuda_corr (third party, binary only) is what
+    Ours.py runs, but models/core/corr.py:8-56 holds the pure-torch CorrBlock of the same quantity and raft.py:44-45,104 switches
+    between them.  (i) CorrBlock on seeded feature maps with query coordinates that leave the map, sit on integers and on
+    half-pixels; (ii) the reference RAFT-small with alternate_corr=False on a seeded frame pair.  Nothing of the oracle or of
+    oracle/native_ref.c takes part in either."""
+    import argparse
+    from models.core.corr import CorrBlock
+    from models.core.raft import RAFT
+    g = torch.Generator().manual_seed(11)
+    B, C, H, W, r = 2, 128, 16, 24, 3
+    f1, f2 = torch.randn(B, C, H, W, generator=g) * 0.5, torch.randn(B, C, H, W, generator=g) * 0.5
+    base = torch.stack(torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")[::-1], 0).float()[None].repeat(B, 1, 1, 1)
+    coords = base + (torch.rand(B, 2, H, W, generator=g) - 0.5) * 10          # fractional, some windows leave the map
+    coords[0, :, :4] = base[0, :, :4]                                         # exact integers (fractional part 0)
+    coords[0, :, 4:6] = base[0, :, 4:6] + 0.5                                 # half pixels
+    coords[1, :, :2] = base[1, :, :2] - 40.0                                  # far outside: all-zero windows
+    coords[1, :, 2:4] = base[1, :, 2:4] + torch.tensor([float(W), float(H)]).view(2, 1, 1)
+    with torch.no_grad():
+        out = CorrBlock(f1, f2, num_levels=4, radius=r)(coords)
+    store = {"fmap1": f1.numpy(), "fmap2": f2.numpy(), "coords": coords.numpy(), "radius": np.array(r), "torch_version": np.array(torch.__version__)}
+    pack(store, "corr", out, limit=10_000_000)
+    np.savez_compressed(os.path.join(HERE, "corrblock_16x24.npz"), **store)
+    print("CorrBlock", tuple(out.shape), float(out.abs().mean()))
+
+    args = argparse.Namespace(small=True, mixed_precision=False, alternate_corr=False)
+    net = RAFT(args)
+    sd = net.state_dict()
+    net.load_state_dict({k: synth_tensor("flow_predictor." + k, v) for k, v in sd.items()})      # the weights every golden uses
+    net.eval()
+    frames = smooth_video(2, 128, 160, seed=12, shift=(1.7, -2.3))            # [B, 2 frames, 3, H, W] in [0,1]
+    im1, im2 = frames[:, 0] * 255.0, frames[:, 1] * 255.0
+    with torch.no_grad():
+        flow_lr, flow_up = net(im1, im2, iters=4, test_mode=True)
+    store = {"image1": im1.numpy(), "image2": im2.numpy(), "iters": np.array(4), "torch_version": np.array(torch.__version__)}
+    pack(store, "flow_lr", flow_lr, limit=10_000_000)
+    pack(store, "flow_up", flow_up, limit=10_000_000)
+    np.savez_compressed(os.path.join(HERE, "raft_corrblock_128x160.npz"), **store)
+    print("RAFT (CorrBlock path) flow_up", tuple(flow_up.shape), float(flow_up.abs().mean()))
+
+
+def host_side_case():
+    """Rows H and (f)3, reference-run data for the host-side numerics: (i) the per-frame Y-PSNR vector and its summary numbers,
+    produced by exec'ing the reference's own lines (test.py:212-238) on the shell golden's frames; (ii) the LR generator
+    data/util.py:imresize_np on seeded images (shrink x1/4, x1/2 with antialiasing, a non-divisible size, x2 up)."""
+    g = dict(np.load(os.path.join(HERE, "shell_T7_lr32_s4.npz"), allow_pickle=False))
+    GT = torch.from_numpy(g["GT"])
+    fake = torch.zeros(*[int(v) for v in g["fake_H__shape"]])
+    fake.reshape(-1)[:] = torch.from_numpy(g["fake_H"]).reshape(-1)
+    b = GT.shape[0]
+    n = GT.shape[1] - 2
+    H, W = GT.shape[3], GT.shape[4]
+    real_H = GT[:, 1:-1].reshape(b * n, 3, H, W).clone()                   # test.py:187-188
+    fake_H = fake[:, :, :, 0:H, 0:W].reshape(b * n, 3, H, W).clone()       # test.py:192-193 (model.fake_H is [T,B,3,H,W], B = 1)
+    src = open(os.path.join(REF, "test.py")).read().split("\n")
+    lo = next(i for i, l in enumerate(src) if l.strip() == "real_H *= 255.")
+    hi = next(i for i, l in enumerate(src) if l.strip().startswith("psnr_all = 10 * torch.log10"))
+    lines = [l for l in src[lo:hi + 1]]
+    body, skip = [], False
+    for l in lines:                                                          # drop the commented-out triple-quoted block and the print
+        q = l.count("\'\'\'")
+        if q % 2 == 1:
+            skip = not skip
+            continue
+        if skip or q or l.strip().startswith("print("):
+            continue
+        body.append(l)
+    import textwrap
+    ns = {"torch": torch, "real_H": real_H, "fake_H": fake_H, "b": b, "n": n, "psnrs_anchor": [], "psnrs_inter": [], "psnrs_center": [], "psnrs": []}
+    exec(compile(textwrap.dedent("\n".join(body)), os.path.join(REF, "test.py"), "exec"), ns)
+    store = {"psnr_all": np.asarray(ns["psnr_all"], dtype=np.float64), "psnr_anchor": np.array(ns["psnr_anchor"]),
+             "psnr_inter": np.array(ns["psnr_inter"]), "psnr_center": np.array(ns["psnr_center"]), "psnr": np.array(ns["psnr"])}
+    print("reference Y-PSNR lines on the shell golden:", store["psnr_all"])
+
+    sys.modules["cv2"] = sys.modules.get("cv2") or types.ModuleType("cv2")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_data_util", os.path.join(REF, "data", "util.py"))
+    du = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(du)
+    rng = np.random.RandomState(21)
+    for tag, shape, sc in (("q", (48, 64, 3), 0.25), ("h", (37, 52, 3), 0.5), ("odd", (45, 70, 3), 0.25), ("up", (12, 10, 3), 2.0)):
+        img = rng.rand(*shape).astype(np.float32)
+        store["imresize_in_" + tag] = img
+        store["imresize_scale_" + tag] = np.array(sc)
+        store["imresize_out_" + tag] = du.imresize_np(img.copy(), sc, True)
+    np.savez_compressed(os.path.join(HERE, "host_side.npz"), **store)
+    print("imresize_np fixtures", {k: v.shape for k, v in store.items() if k.startswith("imresize_out")})
+
+
 def variants():
     """the 4-frame generators, goldens + restatement check (writes its own report file)."""
     rep = {}
@@ -273,12 +362,22 @@ def main():
     reports["lr32x48_s4_n2_b2"] = run_case(net, "lr32x48_s4_n2_b2", 32, 48, 4, 2, batch=2, seed=2)
     shell_case(net)
     pwc_case()
+    corr_case()
+    host_side_case()
     variants()
     json.dump(reports, open(os.path.join(HERE, "restatement_vs_reference.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
-    if "--variants-only" in sys.argv:
+    if "--host-only" in sys.argv:
+        install_stubs()
+        host_side_case()
+    elif "--corr-only" in sys.argv:
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        build_reference()
+        corr_case()
+    elif "--variants-only" in sys.argv:
         torch.manual_seed(0)
         torch.set_num_threads(8)
         build_reference()

@@ -458,6 +458,30 @@ def test_raft_lookup_vs_alt_corr_restatement_and_corrblock():
     close(blk(coords.to(dev())), ref4, 2e-5, 1e-5, "4-level lookup")
 
 
+def test_raft_lookup_and_raft_against_reference_corrblock_fixtures():
+    """Row C2 with reference-run data only: the HIP pyramid look-up against the output of the reference's own CorrBlock
+    (models/core/corr.py:8-56; out-of-range, integer and half-pixel queries), and the HIP RAFT-small against the reference RAFT
+    run with alternate_corr=False -- fixtures from tests/golden/make_golden.py:corr_case, no oracle code involved."""
+    import argparse
+    import numpy as np
+    from motif_amd.models.core.corr import AlternateCorrBlock
+    from motif_amd.models.core.raft import RAFT
+    from motif_amd.utils.synth_weights import synth_tensor
+    gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = dict(np.load(os.path.join(gd, "corrblock_16x24.npz"), allow_pickle=False))
+    f1, f2, coords = (torch.from_numpy(g[k]).to(dev()) for k in ("fmap1", "fmap2", "coords"))
+    out = AlternateCorrBlock(f1, f2, radius=int(g["radius"]))(coords)
+    close(out, torch.from_numpy(g["corr"]), 2e-5, 1e-5, "look-up vs reference CorrBlock")
+    g = dict(np.load(os.path.join(gd, "raft_corrblock_128x160.npz"), allow_pickle=False))
+    net = RAFT(argparse.Namespace(small=True, mixed_precision=False, alternate_corr=True))
+    net.load_state_dict({k: synth_tensor("flow_predictor." + k, v) for k, v in net.state_dict().items()})
+    net = net.to(dev()).eval()
+    with torch.no_grad():
+        lr, up = net(torch.from_numpy(g["image1"]).to(dev()), torch.from_numpy(g["image2"]).to(dev()), iters=int(g["iters"]), test_mode=True)
+    close(up, torch.from_numpy(g["flow_up"]), 2e-3, 1e-3, "RAFT vs reference RAFT (CorrBlock path)")
+    close(lr, torch.from_numpy(g["flow_lr"]), 5e-4, 1e-3, "RAFT 1/8 flow")
+
+
 @pytest.mark.parametrize("kernel", ["small", "tiled"])
 @pytest.mark.parametrize("shape", [(2, 33, 12, 20), (1, 19, 37, 70), (1, 8, 64, 96)])
 def test_corr81(kernel, shape):

@@ -120,6 +120,47 @@ def test_alt_corr_restatement_equals_in_repo_corrblock():
     assert float((mine - ref).abs().max()) < 2e-5
 
 
+def _golden(name):
+    import numpy as np
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"), allow_pickle=False))
+
+
+def _raft_weights(net):
+    """The key-hashed weights every golden uses ('flow_predictor.' + key, as tests/golden/make_golden.py:corr_case)."""
+    from motif_amd.utils.synth_weights import synth_tensor
+    net.load_state_dict({k: synth_tensor("flow_predictor." + k, v) for k, v in net.state_dict().items()})
+    return net.eval()
+
+
+def test_alt_corr_restatement_against_the_references_own_corrblock_fixture():
+    """Row C2 pinned by reference-run data: tests/golden/corrblock_16x24.npz is the output of the reference's own
+    models/core/corr.py:CorrBlock (imported in the build container) for queries that leave the map, sit on integers and on
+    half pixels; the restatement of the third-party alt_cuda_corr kernel must give the same 196 channels."""
+    from oracle.motif_ref import alt_corr_lookup
+    g = _golden("corrblock_16x24")
+    f1, f2, coords = (torch.from_numpy(g[k]) for k in ("fmap1", "fmap2", "coords"))
+    pyr = [f2]
+    for _ in range(3):
+        pyr.append(F.avg_pool2d(pyr[-1], 2, stride=2))
+    mine = alt_corr_lookup(f1, pyr, coords, int(g["radius"]))
+    ref = torch.from_numpy(g["corr"])
+    assert mine.shape == ref.shape
+    assert float((mine - ref).abs().max()) < 2e-5
+    assert float(ref[1, :, :2].abs().max()) == 0.0 and float(mine[1, :, :2].abs().max()) == 0.0      # windows far outside: zeros
+
+
+def test_oracle_raft_against_the_reference_raft_with_corrblock():
+    """The oracle's RAFT-small (alt_corr path) against the reference RAFT run with alternate_corr=False (raft.py:44-45,104)."""
+    from oracle.motif_ref import RaftSmall
+    g = _golden("raft_corrblock_128x160")
+    net = _raft_weights(RaftSmall())
+    with torch.no_grad():
+        up = net(torch.from_numpy(g["image1"]), torch.from_numpy(g["image2"]), iters=int(g["iters"]))[-1]
+    ref = torch.from_numpy(g["flow_up"])
+    assert up.shape == ref.shape and float(ref.abs().mean()) > 0.5
+    assert float((up - ref).abs().max()) < 2e-3
+
+
 def test_splat_kernel_text_properties():
     from oracle import native
     n, c, h, w = 2, 3, 12, 17
