@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend: nccl = RCCL over xGMI (the product); gloo = plumbing runs where there are fewer GPUs "
                          "than ranks (ranks then share GPUs, the uint8 gather is staged through the host)")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="multi-GPU runs: rank 0 re-renders every rank's first clip and checks the gathered uint8 frames byte for byte")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU/gloo plumbing test of the --gpus launcher: N ranks, barrier, gather, one JSON line; no GPU work")
     return ap.parse_args()
@@ -249,24 +251,50 @@ def _oracle_clip(h, w, s, times, seed=0):
     return sample, torch.cat(outs, 0), flow, time.time() - t0
 
 
-def cpu_baseline_and_parity(times, model, mma):
-    """cpu_baseline: the oracle on a bounded crop of c2 (LR 48x80 -> 192x320, same 7 timestamps) and on c1, the
-    reference's own CPU-runnable configuration (LR 64x64, x2 spatial, 3 timestamps).  parity: the HIP path on the same
-    crop clip against the oracle's frames, for both arithmetic engines."""
+def _cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_and_parity(times, model, mma, lr=(180, 320), scale=4):
+    """cpu_baseline: the oracle at the metric's own shape (c2: LR 180x320 -> 720x1280), ONE of the clip's timestamps (t = 0.5: one
+    forward call of the reference schedule, ~40 s on the box's host cores -- a bounded sample of the 3-call clip), plus c1, the
+    reference's own CPU-runnable configuration (LR 64x64, x2 spatial, 3 timestamps).  parity: the HIP path against the oracle's
+    frames on a cropped c2 clip (LR 48x80, all timestamps), for both arithmetic engines."""
     import numpy as np
     import torch
+    from oracle.motif_ref import MotifRef
     from motif_amd import ops
-    h, w, s = 48, 80, 4
+    from motif_amd.data.synthetic import synthetic_sample
+    from motif_amd.utils.synth_weights import fill_state_dict
     cores = torch.get_num_threads()
+    H, W = lr
+    full = synthetic_sample(H, W, scale, times, seed=0)
+    onet = fill_state_dict(MotifRef().eval())
+    mid = times // 2
+    t0 = time.time()
+    with torch.no_grad():
+        onet(full["LQs"], None, full["time"][mid:mid + 1], full["scale"], use_GT=False, iter=4)
+    dtf = time.time() - t0
+    del onet
+    h, w, s = 48, 80, 4
     sample, ref, rflow, dt = _oracle_clip(h, w, s, times)
     _, _, _, dt1 = _oracle_clip(64, 64, 2, 3)
-    base = {"value": times * h * s * w * s / dt, "unit": "HR px/s", "cores": cores, "kind": "port",
-            "sample": "oracle/motif_ref.py (CPU restatement, bit-identical to the reference on the goldens), one c2 clip cropped to "
-                      "LR %dx%d -> %dx%d, %d timestamps in chunks of 3, %.1f s on %d torch threads" % (h, w, h * s, w * s, times, dt, cores),
+    base = {"value": H * scale * W * scale / dtf, "unit": "HR px/s", "cores": cores, "cpu": _cpu_model(), "kind": "port",
+            "sample": "oracle/motif_ref.py (CPU restatement, bit-identical to the reference on the goldens) at the c2 shape, LR %dx%d -> "
+                      "%dx%d, ONE timestamp (t = %d/%d) = one forward call of the reference schedule, which recomputes the t-independent "
+                      "stages per call: %.1f s on %d torch threads" % (H, W, H * scale, W * scale, mid, times - 1, dtf, cores),
+            "crop": {"value": times * h * s * w * s / dt, "unit": "HR px/s",
+                     "sample": "the parity clip: c2 cropped to LR %dx%d, %d timestamps in chunks of 3, %.1f s" % (h, w, times, dt)},
             "c1": {"value": 3 * 128 * 128 / dt1, "unit": "HR px/s",
                    "sample": "BASELINE configs[0]: LR 64x64 -> 128x128 (x2 spatial, x2 temporal = 3 timestamps), %.1f s" % dt1}}
     data = {"LQs": sample["LQs"].cuda(), "GT": sample["GT"][:, :1].cuda(), "time": [t.cuda() for t in sample["time"]], "scale": sample["scale"]}
-    parity = {"clip": "the cpu_baseline crop clip, all %d timestamps" % times, "tolerance": "PSNR >= 60 dB, flow L-inf <= 2e-3 (tests/test_model_gpu.py)"}
+    parity = {"clip": "c2 cropped to LR %dx%d, all %d timestamps" % (h, w, times), "tolerance": "PSNR >= 60 dB, flow L-inf <= 2e-3 (tests/test_model_gpu.py)"}
     try:
         for mode in ("bf16x3", "fp32"):
             ops.set_mma(mode)
@@ -338,10 +366,14 @@ def main():
             m.test()
             if world > 1:
                 u8 = mdist.frames_to_uint8(m.fake_H.permute(1, 0, 2, 3, 4))       # [B,T,HH,WW,3] = this rank's clip, encode kernel
-                mdist.gather_to_rank0(u8, world)
+                pending.append(mdist.gather_to_rank0(u8, world, async_op=True))   # the collective runs behind the next clip's kernels
         return m.fake_H
 
+    pending = []
+
     def fence():
+        while pending:
+            pending.pop(0).wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -395,6 +427,20 @@ def main():
             ver = "unknown (%s)" % type(e).__name__
         line["collective"] = {"backend": dist.get_backend(), "version": ver,
                               "library": "RCCL (torch.distributed 'nccl' on ROCm)" if a.backend == "nccl" else "gloo (plumbing run, host-staged gather)"}
+    if world > 1 and a.verify_gather:
+        m = models[0]
+        m.feed_data(clips[0]); m.test()
+        got = mdist.gather_to_rank0(mdist.frames_to_uint8(m.fake_H.permute(1, 0, 2, 3, 4)), world)
+        if rank == 0:
+            ok = True
+            for r in range(world):
+                sr = synthetic_sample(h, w, a.scale, a.times, seed=100 * r, batch=a.batch)
+                m.feed_data({"LQs": sr["LQs"].cuda(), "GT": sr["GT"][:, :1].cuda(), "time": [t.cuda() for t in sr["time"]], "scale": sr["scale"]})
+                m.test()
+                mine = mdist.frames_to_uint8(m.fake_H.permute(1, 0, 2, 3, 4))
+                ok = ok and bool(torch.equal(got[r * a.batch:(r + 1) * a.batch].to(mine.device), mine))
+            line["gather_verified"] = ok                 # every rank's gathered frames == rank 0's own render of that rank's clip
+        fence()
     if a.mma == "bf16x3" and not a.no_fp32_leg:
         # the same job on the fp32 MFMA (all ranks, same barriers), reported next to the headline value
         from motif_amd import ops
@@ -417,17 +463,23 @@ def main():
                     traffic, traffic_src = json.load(open(tj)).get("hbm_bytes_per_launch"), "profiles/" + name
                     break
             peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
+            clip_flop = sum(v.get("tflop", 0.0) for k, v in r["table"].items() if isinstance(v, dict)) * 1e12
             line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                                "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+                                "frac": ach / peak, "traffic": None, "traffic_from_profile": traffic, "traffic_source": traffic_src,
+                                "overall": {"tflop_executed_per_clip": clip_flop / 1e12, "achieved": clip_flop / (dt / a.steps) / 1e12,
+                                            "frac": clip_flop / (dt / a.steps) / 1e12 / peak,
+                                            "note": "dense FLOP of one clip (all conv / DCN / MLP stages as executed, t-independent part once) over "
+                                                    "the timed wall time per clip, against the same peak"},
                                 "peak_basis": ("bf16 dense MFMA 2500 TFLOP/s / 6 bf16 products per fp32 MAC" if split
                                                else "fp32 MFMA 157.3 TFLOP/s"),
-                                "kernel": "conv_split_kernel<3,4>" if split else "conv_igemm_kernel<2>", "launches_per_clip": r["launches"],
+                                "kernel": "3x3 engine: conv_split2_kernel where its 12-row tiles fill >= 0.9 of the rounds, else conv_split_kernel<3,4>" if split else "conv_igemm_kernel<2>",
+                                "launches_per_clip": r["launches"],
                                 "avg_launch_us": 1000.0 * r["ms"] / max(r["launches"], 1),
                                 "avg_launch_gflop": r["flops"] / max(r["launches"], 1) / 1e9,
                                 "all_conv_ms_per_clip": r["all_conv_ms"], "all_conv_tflop_per_clip": r["all_conv_flops"] / 1e12}
             line["stages"] = r["table"]
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(a.times, model, a.mma)
+            line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(a.times, model, a.mma, tuple(a.lr), a.scale)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -50,26 +50,50 @@ def _wire(t):
     return t.cpu() if (t.is_cuda and dist.get_backend() == "gloo") else t
 
 
-def gather_to_rank0(local, n_items, dst=0):
+class _PendingGather:
+    """Handle of an asynchronous gather: `.wait()` completes the collective and returns what `gather_to_rank0` returns.
+    Keeps the send / receive buffers alive until then."""
+
+    def __init__(self, work, finish, keep):
+        self._work, self._finish, self._keep = work, finish, keep
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        out = self._finish()
+        self._keep = None
+        return out
+
+
+def gather_to_rank0(local, n_items, dst=0, async_op=False):
     """local: tensor [n_local, ...] holding this rank's items in shard order.  Returns on rank `dst` the
-    tensor [n_items, ...] in global clip order, elsewhere None.  Ranks may hold unequal counts."""
+    tensor [n_items, ...] in global clip order, elsewhere None.  Ranks may hold unequal counts.
+    async_op=True: the collective is only enqueued (RCCL runs it on its own stream behind the work already queued on the
+    current one) and a handle is returned; `.wait()` gives the result -- bench.py waits at its fence, so a rank's next clip
+    is not held up by a blocking collective."""
     if not is_dist():
-        return local
+        return _PendingGather(None, lambda: local, None) if async_op else local
     local = _wire(local)
     rank, w = world()
     per = (n_items + w - 1) // w
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]].copy_(local)
     bufs = [torch.empty_like(pad) for _ in range(w)] if rank == dst else None
-    dist.gather(pad, bufs, dst=dst)
-    if rank != dst:
-        return None
-    out = torch.empty((n_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    for r in range(w):
-        idx = shard_indices(n_items, r, w)
-        if idx:
-            out[idx] = bufs[r][:len(idx)]
-    return out
+    work = dist.gather(pad, bufs, dst=dst, async_op=async_op)
+
+    def finish():
+        if rank != dst:
+            return None
+        out = torch.empty((n_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        for r in range(w):
+            idx = shard_indices(n_items, r, w)
+            if idx:
+                out[idx] = bufs[r][:len(idx)]
+        return out
+    if async_op:
+        return _PendingGather(work, finish, (pad, bufs))
+    return finish()
 
 
 # ------------------------------------------------------------------------------------------ row bands of one clip

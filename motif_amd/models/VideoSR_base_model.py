@@ -126,8 +126,13 @@ class VideoSRBaseModel(BaseModel):
             try:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._test_eager(ent["L"], ent["times"])
+                from motif_amd import ops as _ops
+                _ops.set_workspace_owner(id(self))         # scratch recorded into this graph belongs to this instance only
+                try:
+                    with torch.cuda.graph(g):
+                        self._test_eager(ent["L"], ent["times"])
+                finally:
+                    _ops.set_workspace_owner(None)
                 ent.update(g=g, out=self.fake_H, flow=self.flow, flow_GT=self.flow_GT)
                 self._graphs[key] = ent
             except Exception as e:                        # recording is an optimisation: fall back to the eager launches

@@ -449,7 +449,7 @@ class LunaTokis(nn.Module):
           synth_blob  synth_net packed for motif_siren_synth_pre_fwd (first layer = the 3 extra columns + t)."""
         w0 = self.synth_net.net[0].linear.weight
         wh, bh = self.imnet.net[3].weight, self.imnet.net[3].bias
-        key = tuple((t.data_ptr(), t._version) for t in [w0, wh, bh] + [t for wb in self.imnet.linears() + self.synth_net.linears() for t in wb])
+        key = (self._weights_epoch,) + tuple((t.data_ptr(), t._version) for t in [w0, wh, bh] + [t for wb in self.imnet.linears() + self.synth_net.linears() for t in wb])
         if getattr(self, "_pre_key", None) != key:
             W0 = w0.detach().double()
             whc = (W0[:, :64] @ wh.detach().double()).float().contiguous()

@@ -273,9 +273,20 @@ class DcnPlan:
 _ws = {}
 
 
+_ws_owner = None          # set by a model instance while it records a HIP graph (VideoSRBaseModel._test_graph)
+
+
+def set_workspace_owner(owner):
+    """Scratch recorded into a HIP graph is baked into it: every model instance captures on torch's ONE capture stream, so the
+    stream alone would hand two instances the same buffers and their graphs, replayed concurrently, would race on them.
+    While an instance records, its id is part of the key."""
+    global _ws_owner
+    _ws_owner = owner
+
+
 def workspace(numel, device, tag="default"):
-    """Scratch buffer per (tag, device, current stream): clips in flight on different streams never share one."""
-    key = (tag, str(device), torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
+    """Scratch buffer per (tag, device, current stream[, recording model]): clips in flight on different streams never share one."""
+    key = (tag, str(device), torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0, _ws_owner)
     buf = _ws.get(key)
     if buf is None or buf.numel() < numel:
         buf = torch.empty(numel, dtype=torch.float32, device=device)

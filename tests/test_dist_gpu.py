@@ -74,3 +74,21 @@ def test_two_rank_drivers_with_real_kernels(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29571", str(script)], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "DIST_GPU_OK cropped-mode" in r.stdout and "DIST_GPU_OK sync_norm" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_bench_two_gpus_over_rccl():
+    """The product's collective path on real hardware: `bench.py --gpus 2` (two ranks, one GPU each, backend nccl = RCCL over
+    xGMI), asynchronous uint8 gather, and rank 0's byte-for-byte check of every rank's gathered frames against its own render of
+    that rank's clip (--verify-gather).  Skipped on boxes with a single GPU (the builder's gpurun boxes have one)."""
+    import json
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL wants one GPU per rank")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-fp32-leg", "--no-roofline", "--verify-gather"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["collective"]["backend"] == "nccl" and line["collective"]["library"].startswith("RCCL")
+    assert line["gather_verified"] is True
+    assert line["value"] > 0

@@ -865,14 +865,18 @@ def test_dcn_fused_multi_vs_kernel_text(engine):
         close(out[pi], outs_ref[pi], 3e-5, 3e-5, "fused dcn problem %d" % pi)
 
 
-def test_dcn_concurrent_with_conv_split_is_bit_identical(keep_mma):
-    """The fused DCN (4-wave form on this map size: two blocks per CU) launched on one stream while conv_split launches of the
-    shapes RAFT issues run on another: every one of 4 x 150 outputs must equal the serial result bit for bit.  Regression
-    guard for the co-residency corruption reported in round 1 (dcn.hip, launch comment)."""
+@pytest.mark.parametrize("form", ["window8", "fused4_bf16x3", "fused4_fp32", "fused8_oddW"])
+def test_dcn_concurrent_with_conv_split_is_bit_identical(form, keep_mma):
+    """The fused DCN launched on one stream while the 3x3 conv kernels of the shapes RAFT / the trunk issue run on another:
+    every one of 4 x 100 outputs must equal the serial result bit for bit.  Regression guard for the co-residency corruption
+    reported in round 1 (dcn.hip, launch comment).  Each form is FORCED through the library options so that the guard really
+    runs the kernel it names: the shipped window kernel (dcn_win_kernel<8>), the 4-wave fused form the report was about
+    (dcn_fused_kernel<4,*>: two blocks per CU) in both engines, and the 8-wave fallback on a map whose width is not a multiple
+    of 4 (what a PCD level of width 162 takes)."""
     from motif_amd import ops
     from motif_amd.models.modules.DCNv2.dcn_v2 import DCN_sep
     from motif_amd.models.modules.layers import Conv2d
-    ops.set_mma("bf16x3")
+    ops.set_mma("fp32" if form == "fused4_fp32" else "bf16x3")
     torch.manual_seed(0)
     gru = Conv2d(242, 96, 3, 1, 1).to(dev())
     xg = torch.randn(2, 242, 90, 160, device=dev())
@@ -882,25 +886,32 @@ def test_dcn_concurrent_with_conv_split_is_bit_identical(keep_mma):
     with torch.no_grad():
         for d in dcns:
             d.conv_offset_mask.weight.normal_(0, 0.05)
-    h, w = 180, 320
+    h, w = (180, 322) if form == "fused8_oddW" else (180, 320)
     xs = [torch.randn(1, 64, h, w, device=dev()) for _ in range(2)]
     feas = [torch.randn(1, 64, h, w, device=dev()) for _ in range(2)]
-    with torch.no_grad():
-        oms = ops.conv2d_multi([d.conv_offset_mask.plan() for d in dcns], feas, act=ops.ACT_NONE, act2=ops.ACT_SIGMOID, act_split=144)
-        oms = [oms[0].clone(), oms[1].clone()]
-        ref = ops.dcn_v2_multi([d.dplan() for d in dcns], xs, oms, 8, ops.ACT_LRELU).clone()
-        torch.cuda.synchronize()
-        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
-        bad = 0
-        for _ in range(150):
-            with torch.cuda.stream(sb):
-                gru(xg, act=1)
-                tr(xt, act=1)
-            with torch.cuda.stream(sa):
-                outs = [ops.dcn_v2_multi([d.dplan() for d in dcns], xs, oms, 8, ops.ACT_LRELU) for _ in range(4)]
+    try:
+        if form.startswith("fused4"):
+            ops.set_option("dcn_nowin", 1)
+            ops.set_option("dcn_waves", 4)
+        with torch.no_grad():
+            oms = ops.conv2d_multi([d.conv_offset_mask.plan() for d in dcns], feas, act=ops.ACT_NONE, act2=ops.ACT_SIGMOID, act_split=144)
+            oms = [oms[0].clone(), oms[1].clone()]
+            ref = ops.dcn_v2_multi([d.dplan() for d in dcns], xs, oms, 8, ops.ACT_LRELU).clone()
             torch.cuda.synchronize()
-            bad += sum(int(not torch.equal(o, ref)) for o in outs)
-    assert bad == 0, "%d of 600 concurrent DCN outputs differ from the serial result" % bad
+            sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+            bad = 0
+            for _ in range(100):
+                with torch.cuda.stream(sb):
+                    gru(xg, act=1)
+                    tr(xt, act=1)
+                with torch.cuda.stream(sa):
+                    outs = [ops.dcn_v2_multi([d.dplan() for d in dcns], xs, oms, 8, ops.ACT_LRELU) for _ in range(4)]
+                torch.cuda.synchronize()
+                bad += sum(int(not torch.equal(o, ref)) for o in outs)
+    finally:
+        ops.set_option("dcn_nowin", 0)
+        ops.set_option("dcn_waves", 0)
+    assert bad == 0, "%d of 400 concurrent DCN outputs (%s) differ from the serial result" % (bad, form)
 
 
 # ------------------------------------------------------------------------------------------- frame formats

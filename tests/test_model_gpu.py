@@ -105,6 +105,39 @@ def test_lunatokis_matches_reference_goldens(net, case, precontract):
     assert p >= 60.0, "PSNR(build, reference) %.1f dB < 60 dB" % p
 
 
+@pytest.mark.parametrize("case", ["lr32_s4_n3", "lr32x48_s4_n2_b2"])
+def test_default_precontracted_stage_equals_the_contracted_literal_stage(net, case):
+    """Stage-level check of the DEFAULT form (67-plane accumulator): its feature planes must be W0[:, 0:130] applied to the
+    literal 133-plane accumulator -- whose normalised form is what the reference-derived `synth_in` golden pins -- and its
+    z-sum / max / count planes must be the literal ones (count and max bit for bit)."""
+    g = load(case)
+    x = torch.from_numpy(g["LQs"]).cuda()
+    times = [t.cuda() for t in torch.from_numpy(g["times"])]
+    scale = [[int(g["scale"][0])], [int(g["scale"][1])]]
+    accs = {}
+    try:
+        for pc in (False, True):
+            st = {}
+            net.clear_cache()
+            net.precontract = pc
+            with torch.no_grad():
+                net(x, None, times, scale, use_GT=False, iter=4, stages=st)
+            accs[pc] = st["acc"].double().cpu()
+    finally:
+        net.precontract = True
+        net.clear_cache()
+    a133, a67 = accs[False], accs[True]
+    assert a133.shape[1] == 133 and a67.shape[1] == 67
+    assert torch.equal(a67[:, 66], a133[:, 132]) and torch.equal(a67[:, 65], a133[:, 131])         # count, max: exact
+    zs = a133[:, 130]
+    assert float(((a67[:, 64] - zs).abs() / zs.abs().clamp_min(1e-30)).max()) < 1e-5
+    w0 = net.synth_net.net[0].linear.weight.detach().double().cpu()
+    want = torch.einsum("ck,bkhw->bchw", w0[:, :130], a133[:, :130])
+    err = (a67[:, :64] - want).abs()
+    tol = 2e-5 * torch.einsum("ck,bkhw->bchw", w0[:, :130].abs(), a133[:, :130].abs()) + 1e-30
+    assert bool((err <= tol).all()), float((err / tol).max())
+
+
 def _variant_net(which):
     from motif_amd.models import networks
     from motif_amd.option import default_opt
