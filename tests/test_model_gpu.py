@@ -122,6 +122,8 @@ def test_default_precontracted_stage_equals_the_contracted_literal_stage(net, ca
             net.precontract = pc
             with torch.no_grad():
                 net(x, None, times, scale, use_GT=False, iter=4, stages=st)
+            if pc and not net._pc():
+                pytest.skip("the pre-contracted form belongs to the bf16x3 engine (LunaTokis._pc)")
             accs[pc] = st["acc"].double().cpu()
     finally:
         net.precontract = True
