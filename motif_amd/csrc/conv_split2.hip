@@ -47,11 +47,13 @@ struct S2Order {
 // Static schedule of a chunk: slot s = tap * M + m follows MFMA m (= product * RW + row) of that tap.
 //   bpart/brow/bnext[m]: B fragment (activation part, row) requested after MFMA m, for the next tap (bnext) or for this one;
 //   widx[m]: weight fragment (part) of the tap after next requested after MFMA m;
-//   ext[s]: staging step of the NEXT chunk done after slot s: kind * 16 + index, kinds
-//           1 = global load i, 2 = mask + park load i in the landing area, 3 = read two channels of split item set it (it*4 + pair),
-//           4 = split half-step (it*8 + 2*pair + half), 5 = store part p of item set it (it*3 + p).
-template <int RW, int NLD, int NSPL>
+//   ext[s]: staging step of the NEXT chunk done after slot s: kind << 8 | index.  The wave's share of the chunk is staged in
+//           ROUNDS rounds through one landing area; per round r: 1 = global load (r*8 + i), 2 = mask + park it (r*8 + i),
+//           3 = read four channels of item set it (r*4 + it*2 + half), 4 = split half-step (r*16 + it*8 + 2*pair + half),
+//           5 = store the three parts of item set it (r*2 + it), 6 = both half-steps of a pair (as 4), 7 = all eight channels (as 3) -- MERGE.
+template <int RW, int NLD, int NSPL, int ROUNDS>
 struct S2Sched {
+    static constexpr bool MERGE = RW < 3;                      // few free slots per tap: a channel pair's two split half-steps share a slot
     static constexpr int NP = 3, M = S2Order::n * RW, S = 9 * M;
     int bpart[M], brow[M], bnext[M], widx[M], ext[S], used, nfree;
     constexpr S2Sched() : bpart(), brow(), bnext(), widx(), ext(), used(0), nfree(0) {
@@ -68,20 +70,27 @@ struct S2Sched {
         }
         int wi = 0;
         for (int m = 0; m < M && wi < NP; ++m) if (bpart[m] < 0) widx[m] = wi++;
-        // staging steps go to the slots that carry no operand request: loads in tap 0, parked two taps later, then the item sets
+        // staging steps go to the slots that carry no operand request; a round's values fly >= two taps before they are touched,
+        // the next round's loads are issued as soon as the registers are free (behind the parks of the round before)
         for (int s = 0; s < S; ++s) ext[s] = 0;
         int fr[S] = {}, nf = 0;
         for (int s = 0; s < S; ++s) { const int m = s % M; if (bpart[m] < 0 && widx[m] < 0) fr[nf++] = s; }
         const int per_tap = nf / 9;
-        int f = 0;
-        for (int i = 0; i < NLD; ++i) ext[fr[f++]] = 1 * 16 + i;
-        if (f < 2 * per_tap) f = 2 * per_tap;                  // >= two taps of flight before the values are touched
-        for (int i = 0; i < NLD; ++i) ext[fr[f++]] = 2 * 16 + i;
-        f += 1;
-        for (int it = 0; it < NSPL; ++it) {
-            for (int q = 0; q < 4; ++q) ext[fr[f++]] = 3 * 16 + it * 4 + q;
-            for (int hs = 0; hs < 8; ++hs) ext[fr[f++]] = 4 * 16 + it * 8 + hs;
-            for (int p = 0; p < NP; ++p) ext[fr[f++]] = 5 * 16 + it * 3 + p;
+        int f = 0, ready = 0;                                  // ready: first free-slot index at which the loads in flight may be parked
+        for (int i = 0; i < NLD; ++i) ext[fr[f++]] = (1 << 8) | i;
+        ready = f + 2 * per_tap;
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (f < ready) f = ready;
+            for (int i = 0; i < NLD; ++i) ext[fr[f++]] = (2 << 8) | (r * 8 + i);
+            if (r + 1 < ROUNDS) {
+                for (int i = 0; i < NLD; ++i) ext[fr[f++]] = (1 << 8) | ((r + 1) * 8 + i);
+                ready = f + 2 * per_tap;
+            }
+            for (int it = 0; it < NSPL; ++it) {
+                for (int h = 0; h < 2; h += MERGE ? 2 : 1) ext[fr[f++]] = ((MERGE ? 7 : 3) << 8) | (r * 4 + it * 2 + h);
+                for (int hs = 0; hs < 8; hs += MERGE ? 2 : 1) ext[fr[f++]] = ((MERGE ? 6 : 4) << 8) | (r * 16 + it * 8 + hs);
+                ext[fr[f++]] = (5 << 8) | (r * 2 + it);
+            }
         }
         used = f; nfree = nf;                                  // static_assert at the use: the steps must fit the free slots
     }
@@ -105,49 +114,53 @@ __device__ __forceinline__ f32x4 act_uniform(f32x4 v, int ac) {     // ac is wav
 }
 
 // Wave-local epilogue: the wave's accumulators (32 couts x RW rows x 32 pixels) go through a wave-private LDS scratch of
-// [8 couts][RW*32 pixels] floats in four passes and leave as 16-byte row pieces: bias, residual (one 16-byte load, requested a
-// pass ahead), activation, one 16-byte store.  Activation and residual mode are wave-uniform run-time switches.  `cbase` = first
-// cout of this wave's 32 in the tensor, `climit` = valid couts from there (partial last group).  Host guarantees: Wo % 4 == 0,
-// 16-byte aligned tensors, 32 * Ho * Wo < 2^31, act_split on an 8-cout boundary.
-template <int RW, bool RES>
+// [8 couts][RS rows x 32 pixels] floats in 4 * RW / RS passes and leave as 16-byte row pieces: bias, residual (one 16-byte load,
+// requested a pass ahead), activation, one 16-byte store.  Activation and residual mode are wave-uniform run-time switches.
+// `cbase` = first cout of this wave's 32 in the tensor, `climit` = valid couts from there (partial last group).  Host guarantees:
+// Wo % 4 == 0, 16-byte aligned tensors, 32 * Ho * Wo < 2^31, act_split on an 8-cout boundary.
+template <int RW, int RS, bool RES>
 __device__ __forceinline__ void conv_epilogue_wave(const ConvArgs& a, f32x16 (&acc)[RW], const float* bias_w, float* sc, int lane,
                                                    int cbase, int climit, int oy0, int ox0, const float* rb, float* ob) {
-    constexpr int S = RW * 32, NIT = RW;                              // 8 couts x RW rows x 8 quads = 64 * RW items per pass
+    constexpr int S = RS * 32, NIT = RS, NRP = RW / RS, NPASS = 4 * NRP;      // 8 couts x RS rows x 8 quads = 64 * RS items per pass
+    static_assert(RW % RS == 0, "row passes");
     const int half = lane >> 5, l31 = lane & 31;
     const unsigned HWo = (unsigned)(a.Ho * a.Wo);
     const int rm = a.res_mode;
-    unsigned loff[NIT]; int scoff[NIT], coi[NIT]; bool ok[NIT];
+    unsigned loff[NIT]; int scoff[NIT], coi[NIT], rowi[NIT], oxi[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int idx = lane + 64 * it;
-        const int co = idx / (RW * 8), q = idx - co * (RW * 8);
-        const int row = q >> 3, col = (q & 7) * 4;
-        const int oy = oy0 + row, ox = ox0 + col;
-        ok[it] = oy < a.Ho && ox < a.Wo;
-        loff[it] = ok[it] ? (unsigned)co * HWo + (unsigned)(oy * a.Wo + ox) : 0u;    // masked lanes read element 0, store nothing
-        scoff[it] = co * S + row * 32 + col;
+        const int co = idx / (RS * 8), q = idx - co * (RS * 8);
+        rowi[it] = q >> 3; oxi[it] = ox0 + (q & 7) * 4;
+        loff[it] = (unsigned)co * HWo + (unsigned)((oy0 + rowi[it]) * a.Wo + oxi[it]);
+        scoff[it] = co * S + rowi[it] * 32 + (q & 7) * 4;
         coi[it] = co;
     }
+    auto okat = [&](int pass, int it) {                               // inside the image and the cout group
+        const int oy = oy0 + (pass % NRP) * RS + rowi[it];
+        return oy < a.Ho && oxi[it] < a.Wo && 8 * (pass / NRP) + coi[it] < climit;
+    };
+    auto offat = [&](int pass, int it) { return loff[it] + (unsigned)(8 * (pass / NRP)) * HWo + (unsigned)((pass % NRP) * RS * a.Wo); };
     f32x4 rv[2][NIT];
     auto load_res = [&](int pass, f32x4 (&dst)[NIT]) {
-        const float* base = rb + (long)(8 * pass) * HWo;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) dst[it] = *(const f32x4*)(base + (8 * pass + coi[it] < climit ? loff[it] : 0u));
+        for (int it = 0; it < NIT; ++it) dst[it] = *(const f32x4*)(rb + (okat(pass, it) ? offat(pass, it) : 0u));   // masked lanes read element 0
     };
     if constexpr (RES) load_res(0, rv[0]);
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        if constexpr (RES) { if (pass + 1 < 4) load_res(pass + 1, rv[(pass + 1) & 1]); }
-        const int ac = (a.act_split > 0 && cbase + 8 * pass >= a.act_split) ? a.act2 : a.act;     // uniform per pass
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int cq = pass / NRP, r0 = (pass % NRP) * RS;
+        if constexpr (RES) { if (pass + 1 < NPASS) load_res(pass + 1, rv[(pass + 1) & 1]); }
+        const int ac = (a.act_split > 0 && cbase + 8 * cq >= a.act_split) ? a.act2 : a.act;     // uniform per pass
 #pragma unroll
-        for (int j = 0; j < RW; ++j)
+        for (int j = 0; j < RS; ++j)
 #pragma unroll
-            for (int r3 = 0; r3 < 4; ++r3) sc[(r3 + 4 * half) * S + j * 32 + l31] = acc[j][4 * pass + r3];
+            for (int r3 = 0; r3 < 4; ++r3) sc[(r3 + 4 * half) * S + j * 32 + l31] = acc[r0 + j][4 * cq + r3];
         f32x4 v[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             v[it] = *(const f32x4*)(sc + scoff[it]);
-            const float b = bias_w[8 * pass + coi[it]];
+            const float b = bias_w[8 * cq + coi[it]];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[it][e] += b;
         }
@@ -164,31 +177,36 @@ __device__ __forceinline__ void conv_epilogue_wave(const ConvArgs& a, f32x16 (&a
                 } else if (rm == 4) v[it] *= rv[pass & 1][it];
             }
         }
-        float* obp = ob + (long)(8 * pass) * HWo;
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
-            if (ok[it] && 8 * pass + coi[it] < climit) *(f32x4*)(obp + loff[it]) = v[it];
+            if (okat(pass, it)) *(f32x4*)(ob + offat(pass, it)) = v[it];
     }
 }
 }  // namespace
 
-// One workgroup = 8 waves, tile = 12 rows x 32 columns x 64 couts; wave (ct, rg) = cout tile ct (32 couts) x rows 3*rg .. 3*rg+2.
-__global__ __launch_bounds__(512) void conv_split2_kernel(ConvArgs a, int ntiles, int tiles_y) {
-    constexpr int NP = 3, RW = 3, TH = 4 * RW, PH = TH + 2, PW = 34, PHW = PH * PW;
+// Workgroup = WAVES waves, tile = (WAVES/2 * RW) rows x 32 columns x 64 couts; wave (ct, rg) = cout tile ct (32 couts) x rows
+// RW*rg .. RW*rg + RW-1.  Two shapes are built, both one 8-wave workgroup per CU: <8, 3, 1> -- 12-row tiles -- and <8, 2, 1> --
+// 8-row tiles, for the launches whose 12-row tiles would fill the rounds of the 256 CUs badly.  (A <4, 4, 2> shape -- two 4-wave
+// workgroups per CU, the wave's share staged in two rounds -- compiles to 250 spilled VGPRs and was not pursued.)
+template <int WAVES, int RW, int ROUNDS>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_split2_kernel(ConvArgs a, int ntiles, int tiles_y) {
+    constexpr int NP = 3, TH = (WAVES / 2) * RW, PH = TH + 2, PW = 34, PHW = PH * PW;
     constexpr int SLOTS = 2 * PHW + 4;                   // per part: [2 octets][PHW] 16-byte slots + dummy
     constexpr int STG = NP * SLOTS;                      // one bf16 staging buffer (u32x4)
-    constexpr int UW = 2 * PH * 2 / 8;                   // (octet, row, half row) units per wave: 8 channels x 5 pixel quads each
-    constexpr int NQ = UW * 40, NLD = (NQ + 63) / 64, LW = NLD * 64;     // landing area of one wave (u32x4)
-    constexpr int NITEM = UW * 17, NSPL = (NITEM + 63) / 64;             // (unit, pixel) items a wave splits per chunk
-    static_assert(2 * PH * 2 % 8 == 0 && 8 * RW * 32 * 4 <= LW * 16, "unit split / scratch must fit the landing area");
-    using SCHT = S2Sched<RW, NLD, NSPL>;
+    constexpr int UW = 2 * PH * 2 / WAVES, UWR = UW / ROUNDS;   // (octet, row, half row) units per wave / per round: 8 channels x 5 quads
+    constexpr int NQ = UWR * 40, NLD = (NQ + 63) / 64;   // 16-byte pieces of a round, loads per lane
+    constexpr int RS = WAVES == 8 ? RW : 2;              // rows per epilogue pass (scratch = 8 couts x RS rows)
+    constexpr int LW = NQ > 64 * RS ? NQ : 64 * RS;      // landing area of one wave (u32x4), reused as its epilogue scratch
+    constexpr int NITEM = UWR * 17, NSPL = (NITEM + 63) / 64;            // (unit, pixel) items a wave splits per round
+    static_assert(2 * PH * 2 % WAVES == 0 && UW % ROUNDS == 0 && NSPL <= 2 && NLD <= 8 && ROUNDS <= 2, "unit split");
+    using SCHT = S2Sched<RW, NLD, NSPL, ROUNDS>;
     constexpr int M = SCHT::M;
     extern __shared__ __attribute__((aligned(16))) u32x4 lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), ct = wave & 1, rg = wave >> 1;
-    float* bias_w = (float*)lds_raw + wave * 64;                       // [8 waves][64] (32 used)
-    u32x4* stg0 = lds_raw + 8 * 16;                                   // [2 buffers][NP][SLOTS]
-    u32x4* land = lds_raw + 8 * 16 + 2 * STG + wave * LW;             // [8 waves][LW]: fp32 landing area / epilogue scratch
+    float* bias_w = (float*)lds_raw + wave * 64;                       // [WAVES][64] (32 used)
+    u32x4* stg0 = lds_raw + WAVES * 16;                               // [2 buffers][NP][SLOTS]
+    u32x4* land = lds_raw + WAVES * 16 + 2 * STG + wave * LW;         // [WAVES][LW]: fp32 landing area / epilogue scratch
 
     const int G = gridDim.x, bq = xcd_block_id(blockIdx.x, G);
     if (bq >= ntiles) return;
@@ -221,7 +239,7 @@ __global__ __launch_bounds__(512) void conv_split2_kernel(ConvArgs a, int ntiles
     };
 
     // ---- staging plan of a tile (chunk-invariant) --------------------------------------------------------------------
-    int doff[NLD];                                       // per-lane source offset of each staging load (-1: outside the image)
+    int doff[ROUNDS][NLD];                               // per-lane source offset of each staging load (-1: outside the image)
     const float* in0n = nullptr; const float* in1n = nullptr;
     int st_g = 0;
     float bias_v = 0.f;
@@ -236,6 +254,10 @@ __global__ __launch_bounds__(512) void conv_split2_kernel(ConvArgs a, int ntiles
     auto wfrag = [&](__amdgpu_buffer_rsrc_t wb, int ks, int p) {
         return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wb, wvoff, (ks * NP + p) * (2 * 64 * 16), 0));
     };
+    auto unit_of = [&](int r, int ul, int& o, int& py, int& hx) {        // this wave's unit ul of round r -> (octet, patch row, half row)
+        const int U = wave * UW + r * UWR + ul;
+        o = U / (2 * PH); const int rem = U - o * (2 * PH); py = rem >> 1; hx = rem & 1;
+    };
     auto setup_stage = [&](const TileC& t) {
         int n, pz, g, cg, ty, tx;
         decode(t, n, pz, g, cg, ty, tx);
@@ -246,40 +268,45 @@ __global__ __launch_bounds__(512) void conv_split2_kernel(ConvArgs a, int ntiles
         bias_v = (bp && lane < 32 && cg * 64 + ct * 32 + lane < a.Cout_g) ? bp[g * a.Cout_g + cg * 64 + ct * 32 + lane] : 0.f;
         const int iy0 = ty * TH - 1, x0 = tx * 32 - 4;   // pad 1 (host); staged rows start 4 pixels left of the tile: aligned quads
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int qd = i * 64 + lane;
-            const int ul = qd / 40, r = qd - ul * 40, ch = r / 5, xq = r - ch * 5;
-            const int U = wave * UW + ul, o = U / (2 * PH), rem = U - o * (2 * PH), py = rem >> 1, hx = rem & 1;
-            const int iy = iy0 + py, x = x0 + 20 * hx + 4 * xq;
-            doff[i] = (qd < NQ && iy >= 0 && iy < a.H && x >= 0 && x < a.W) ? iy * a.W + x + (8 * o + ch) * HW : -1;
-        }
+        for (int r = 0; r < ROUNDS; ++r)
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int qd = i * 64 + lane;
+                const int ul = qd / 40, rr = qd - ul * 40, ch = rr / 5, xq = rr - ch * 5;
+                int o, py, hx;
+                unit_of(r, ul, o, py, hx);
+                const int iy = iy0 + py, x = x0 + 20 * hx + 4 * xq;
+                doff[r][i] = (qd < NQ && iy >= 0 && iy < a.H && x >= 0 && x < a.W) ? iy * a.W + x + (8 * o + ch) * HW : -1;
+            }
     };
-    // the four steps of staging one 16-channel chunk (this wave's 7 units), callable one small step at a time
+    // the steps of staging one 16-channel chunk (this wave's units, ROUNDS rounds), callable one small step at a time
     f32x4 gq[NLD];
-    auto st_load = [&](int i, int c0) {                  // global -> registers: 4 pixels of one channel
+    auto st_load = [&](int r, int i, int c0) {           // global -> registers: 4 pixels of one channel
         const int gch0 = st_g * a.Cin_g + c0;
         const float* base = (gch0 < a.C0) ? in0n + (long)gch0 * HW : in1n + (long)(gch0 - a.C0) * HW;
-        gq[i] = *(const f32x4*)(base + (doff[i] >= 0 ? doff[i] : 0));
+        gq[i] = *(const f32x4*)(base + (doff[r][i] >= 0 ? doff[r][i] : 0));
     };
-    auto st_park = [&](int i, int c0) {                  // zero what lies outside the image / beyond the last channel, park in LDS
+    auto st_park = [&](int r, int i, int c0) {           // zero what lies outside the image / beyond the last channel, park in LDS
         const int qd = i * 64 + lane;
         const int ul = qd / 40, ch = (qd - ul * 40) / 5;
-        const int o = (wave * UW + ul) / (2 * PH);
-        const bool ok = doff[i] >= 0 && c0 + 8 * o + ch < a.Cin_g;
+        int o, py, hx;
+        unit_of(r, ul, o, py, hx);
+        const bool ok = doff[r][i] >= 0 && c0 + 8 * o + ch < a.Cin_g;
         f32x4 v = gq[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
-        *(f32x4*)(land + qd) = v;
+        if (NLD * 64 == NQ || qd < NQ) *(f32x4*)(land + qd) = v;
     };
     float sv[8];
     u32x4 sparts[NP];
-    auto st_read = [&](int it, int q) {                  // landing area -> two channels of this lane's item
+    auto st_read = [&](int r, int it, int h4) {          // landing area -> four channels of this lane's item
         const int id = lane + 64 * it;
         const int ul = id / 17, pi = id - ul * 17;
-        const int hx = (wave * UW + ul) & 1;
-        const float* fw = (const float*)land + (ul < UW ? ul : 0) * 160 + pi + 3 - 3 * hx;
-        sv[2 * q] = fw[(2 * q) * 20];
-        sv[2 * q + 1] = fw[(2 * q + 1) * 20];
+        int o, py, hx;
+        unit_of(r, ul, o, py, hx);
+        const float* fw = (const float*)land + (ul < UWR ? ul : 0) * 160 + pi + 3 - 3 * hx;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sv[4 * h4 + q] = fw[(4 * h4 + q) * 20];
     };
     auto st_split = [&](int q, int hs) {                 // 3-way split of channel pair q: leading part | the two lower parts
         if (hs == 0) {
@@ -292,12 +319,14 @@ __global__ __launch_bounds__(512) void conv_split2_kernel(ConvArgs a, int ntiles
             sparts[2][q] = pk_bf16(sv[2 * q] - bf_lo(pk), sv[2 * q + 1] - bf_hi(pk));
         }
     };
-    auto st_store = [&](int it, int p, u32x4* dstbuf) {  // one part of the item -> staging buffer
+    auto st_store = [&](int r, int it, u32x4* dstbuf) {  // the item's three parts -> staging buffer
         const int id = lane + 64 * it;
         const int ul = id / 17, pi = id - ul * 17;
-        const int U = wave * UW + ul, o = U / (2 * PH), rem = U - o * (2 * PH), py = rem >> 1, hx = rem & 1;
+        int o, py, hx;
+        unit_of(r, ul, o, py, hx);
         const int slot = id < NITEM ? o * PHW + py * PW + 17 * hx + pi : 2 * PHW;      // surplus lanes write the dummy slot
-        dstbuf[p * SLOTS + slot] = sparts[p];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) dstbuf[p * SLOTS + slot] = sparts[p];
     };
 
     f32x16 acc[RW];
@@ -340,12 +369,14 @@ __global__ __launch_bounds__(512) void conv_split2_kernel(ConvArgs a, int ntiles
                     else if (STAGE) wf[(t + 2) % WB][p] = wfrag(wn, sc * 9 + t + 2 - 9, p);
                 }
                 if constexpr (STAGE) {
-                    const int e = SCH.ext[t * M + m], kind = e >> 4, idx = e & 15;
-                    if (kind == 1) st_load(idx, sc * 16);
-                    else if (kind == 2) st_park(idx, sc * 16);
-                    else if (kind == 3) st_read(idx >> 2, idx & 3);
+                    const int e = SCH.ext[t * M + m], kind = e >> 8, idx = e & 255;
+                    if (kind == 1) st_load(idx >> 3, idx & 7, sc * 16);
+                    else if (kind == 2) st_park(idx >> 3, idx & 7, sc * 16);
+                    else if (kind == 3) st_read(idx >> 2, (idx >> 1) & 1, idx & 1);
                     else if (kind == 4) st_split((idx & 7) >> 1, idx & 1);
-                    else if (kind == 5) st_store(idx / 3, idx % 3, dstbuf);
+                    else if (kind == 6) { st_split((idx & 7) >> 1, 0); st_split((idx & 7) >> 1, 1); }
+                    else if (kind == 7) { st_read(idx >> 2, (idx >> 1) & 1, 0); st_read(idx >> 2, (idx >> 1) & 1, 1); }
+                    else if (kind == 5) st_store(idx >> 1, idx & 1, dstbuf);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -361,8 +392,8 @@ __global__ __launch_bounds__(512) void conv_split2_kernel(ConvArgs a, int ntiles
         const float* rb = a.res_mode ? a.res[pz] + (long)n * a.res_bs[pz] + (long)cbase * HWo : nullptr;
         int lane_e = lane;                               // opaque copy: keeps the per-lane address arithmetic inside the tile loop
         asm volatile("" : "+v"(lane_e));
-        if (a.res_mode) conv_epilogue_wave<RW, true>(a, acc, bias_w, (float*)land, lane_e, cbase, climit, ty * TH + RW * rg, tx * 32, rb, ob);
-        else conv_epilogue_wave<RW, false>(a, acc, bias_w, (float*)land, lane_e, cbase, climit, ty * TH + RW * rg, tx * 32, rb, ob);
+        if (a.res_mode) conv_epilogue_wave<RW, RS, true>(a, acc, bias_w, (float*)land, lane_e, cbase, climit, ty * TH + RW * rg, tx * 32, rb, ob);
+        else conv_epilogue_wave<RW, RS, false>(a, acc, bias_w, (float*)land, lane_e, cbase, climit, ty * TH + RW * rg, tx * 32, rb, ob);
     };
 
     // ---- prologue: first chunk of the first tile (nothing to hide it under) --------------------------------------------
@@ -371,21 +402,22 @@ __global__ __launch_bounds__(512) void conv_split2_kernel(ConvArgs a, int ntiles
     S2TRACE(0);
     setup_stage(tc);
     wbase = wnext = wptr(tc);
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) st_load(i, 0);
     loadw(wbase, 0, wf[0]);
     loadw(wbase, 1, wf[1]);
-    if (lane < 32) bias_w[lane] = bias_v;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) st_park(i, 0);
+    for (int r = 0; r < ROUNDS; ++r) {
 #pragma unroll
-    for (int it = 0; it < NSPL; ++it) {
+        for (int i = 0; i < NLD; ++i) st_load(r, i, 0);
+        if (r == 0 && lane < 32) bias_w[lane] = bias_v;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) st_read(it, q);
+        for (int i = 0; i < NLD; ++i) st_park(r, i, 0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { st_split(q, 0); st_split(q, 1); }
+        for (int it = 0; it < NSPL; ++it) {
+            st_read(r, it, 0); st_read(r, it, 1);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) st_store(it, p, stg0);
+            for (int q = 0; q < 4; ++q) { st_split(q, 0); st_split(q, 1); }
+            st_store(r, it, stg0);
+        }
     }
 #pragma unroll
     for (int j = 0; j < RW; ++j)
@@ -434,7 +466,7 @@ int s2_cu_count() {                                      // init-once device pro
 }
 }  // namespace
 
-// What this kernel takes (everything else stays on conv_split_kernel): fp32-equivalent arithmetic, zero padding 1, rows of whole
+// What these kernels take (everything else stays on conv_split_kernel): fp32-equivalent arithmetic, zero padding 1, rows of whole
 // 16-byte units, 16-byte aligned tensors (16-byte staging loads and stores), activation split on an 8-cout boundary.
 bool motif_conv_split2_eligible(const MotifConvDesc* d, const ConvArgs& a, int P) {
     if (split_parts(d->mma) != 3 || d->pad != 1 || d->pad_mode != 0 || (d->W & 3)) return false;
@@ -448,16 +480,18 @@ bool motif_conv_split2_eligible(const MotifConvDesc* d, const ConvArgs& a, int P
         if (bits & 15) return false;
         if ((a.in0_bs[i] | a.out_bs[i] | (a.in1[i] ? a.in1_bs[i] : 0) | (a.res[i] ? a.res_bs[i] : 0)) & 3) return false;
     }
-    if (motif_opt(MOTIF_OPT_CONV_ENGINE) == 2) return true;             // forced (tests, tools)
-    // One 12-row tile per CU and round: launches whose tiles fill the rounds badly stay on the two-block kernel (8-row tiles, two
-    // blocks per CU), whose residual epilogue is the slower one -- measured crossover (tools/conv_bench.py, 18 shapes).
-    const long T = (long)((d->W + 31) / 32) * ((d->H + 11) / 12) * d->groups * ((Cout_g + 63) / 64) * d->N * P;
-    const long cus = s2_cu_count(), rounds = (T + cus - 1) / cus;
-    const double fill = (double)T / (double)(rounds * cus);
-    return fill >= 0.9;
+    const int force = motif_opt(MOTIF_OPT_CONV_ENGINE);
+    if (force == 2 || force == 3) return true;                         // forced (tests, tools)
+    // Measured crossover on the clip's launches (tools/r3_conv.sh: per-shape A/B inside the model): the 12-row shape wins where
+    // its tiles fill >= 0.9 of the rounds of the CUs (+3 ... +13 %), the 8-row shape where every CU gets at most one tile (+4 ... +20 %:
+    // the deep-K layers of RAFT's update block); in between the two-block kernel (8-row tiles, 512 block slots) is as good or better.
+    const long per_row_tile = (long)((d->W + 31) / 32) * d->groups * ((Cout_g + 63) / 64) * d->N * P, cus = s2_cu_count();
+    const long T12 = per_row_tile * ((d->H + 11) / 12), T8 = per_row_tile * ((d->H + 7) / 8);
+    return (double)T12 / (double)(((T12 + cus - 1) / cus) * cus) >= 0.9 || T8 <= cus;
 }
 
-// One persistent workgroup per CU (or per tile when there are fewer tiles than CUs); tile i of workgroup b = b' + i * G.
+// Persistent workgroups, tile i of workgroup b = b' + i * G.  Shape by tile count: 12-row tiles with one 8-wave workgroup per CU
+// where they fill >= 0.9 of the rounds of the CUs, else 8-row tiles (option conv_engine: 2 forces the first, 3 the second).
 int motif_conv_split2_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s) {
     const int Cin_g = (d->C0 + d->C1) / d->groups, Cout_g = d->Cout / d->groups;
     const int Ho = d->H, Wo = d->W;                      // pad 1
@@ -466,19 +500,29 @@ int motif_conv_split2_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStre
     a.ncg = (Cout_g + 63) / 64;
     a.tiles_x = (Wo + 31) / 32;
     const int ncgG = d->groups * a.ncg, cus = s2_cu_count();
-    const int tiles_y = (Ho + 11) / 12;
-    const long T = (long)a.tiles_x * tiles_y * ncgG * d->N * P;
-    if (T >= 0x7fffffffL) return MOTIF_ELIMIT;
-    const int G = (int)(T < cus ? T : cus);
-    const size_t ldsb = ((size_t)8 * 16 + (size_t)2 * 3 * (2 * 14 * 34 + 4) + (size_t)8 * 320) * 16;
+    a.Cout = d->Cout;
+    a.CK = ncgG;                                         // unused by these kernels otherwise: carries groups * ncg
+    const long per_row_tile = (long)a.tiles_x * ncgG * d->N * P;
+    const long T12 = per_row_tile * ((Ho + 11) / 12), T8 = per_row_tile * ((Ho + 7) / 8);
+    if (T8 >= 0x7fffffffL) return MOTIF_ELIMIT;
+    const long rounds12 = (T12 + cus - 1) / cus;
+    const int force = motif_opt(MOTIF_OPT_CONV_ENGINE);
+    const bool big = force == 2 || (force != 3 && (double)T12 / (double)(rounds12 * cus) >= 0.9);      // else: 8-row tiles (T8 <= CUs, or forced)
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_split2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_split2_kernel<8, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_split2_kernel<8, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    a.Cout = d->Cout;
-    a.CK = ncgG;                                         // unused by this kernel otherwise: carries groups * ncg
-    conv_split2_kernel<<<dim3(G, 1, 1), 512, ldsb, s>>>(a, (int)T, tiles_y);
+    if (big) {
+        const int G = (int)(T12 < cus ? T12 : cus);
+        const size_t ldsb = ((size_t)8 * 16 + (size_t)2 * 3 * (2 * 14 * 34 + 4) + (size_t)8 * 280) * 16;
+        conv_split2_kernel<8, 3, 1><<<dim3(G, 1, 1), 512, ldsb, s>>>(a, (int)T12, (Ho + 11) / 12);
+    } else {
+        const int G = (int)(T8 < cus ? T8 : cus);
+        const size_t ldsb = ((size_t)8 * 16 + (size_t)2 * 3 * (2 * 10 * 34 + 4) + (size_t)8 * 200) * 16;
+        conv_split2_kernel<8, 2, 1><<<dim3(G, 1, 1), 512, ldsb, s>>>(a, (int)T8, (Ho + 7) / 8);
+    }
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

@@ -194,8 +194,9 @@ def test_conv_split_multi_problem_and_views(keep_mma):
     assert float(buf[:, :8].abs().max()) == 0 and float(buf[:, 72:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("tile", [2, 3], ids=["rows12", "rows8"])
 @pytest.mark.parametrize("shape", [(3, 64, 64, 180, 320), (2, 64, 216, 90, 160), (5, 128, 64, 63, 100), (1, 48, 80, 19, 36)])
-def test_conv_split2_persistent_tiles(shape, keep_mma):
+def test_conv_split2_persistent_tiles(shape, tile, keep_mma):
     """The round-3 conv kernel over MANY tiles per workgroup (persistent loop, next tile staged under the last chunk, ragged last
     tile row / column, partial cout group, channel padding) against torch on the host and against the round-2 kernel."""
     from motif_amd import ops
@@ -210,7 +211,7 @@ def test_conv_split2_persistent_tiles(shape, keep_mma):
     m = m.to(dev())
     ops.set_conv_mma(ops.MMA_BF16X3)
     try:
-        ops.set_option("conv_engine", 2)                  # the round-3 kernel whatever the tile count
+        ops.set_option("conv_engine", tile)               # the round-3 kernel, 12-row (2) or 8-row (3) tiles, whatever the tile count
         out = m(x.to(dev()), act=ops.ACT_RELU, res=res.to(dev()), res_mode=2)
         ops.set_option("conv_engine", 1)
         old = m(x.to(dev()), act=ops.ACT_RELU, res=res.to(dev()), res_mode=2)

@@ -1,24 +1,34 @@
 #!/bin/bash
-# round-3 conv experiment: correctness, A/B against the two-block kernel (ENGINE=1), per-wave timeline
+# round-3 conv experiment: correctness, A/B of the engines (1 = two-block kernel, 2 / 3 = conv_split2 12- / 8-row tiles), timeline
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r3
-timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -k "conv" > gpurun_out/r3/conv_tests.log 2>&1
-echo "tests exit $?" >> gpurun_out/r3/conv_tests.log
+timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -k "conv" 2>&1 | tail -2
 out=gpurun_out/r3/conv_bench.log; : > $out
-for cfg in "1 0" "0 0" "1 1" "0 1"; do
-  set -- $cfg
-  echo "== ENGINE=$1 RES=$2" >> $out
-  if [ "$2" = "1" ]; then export RES=1; else unset RES; fi
-  ENGINE=$1 REPS=30 timeout 300 python tools/conv_bench.py 2>&1 | grep shape >> $out
+for e in 1 2 3; do
+  echo "== ENGINE=$e" >> $out
+  ENGINE=$e REPS=20 timeout 300 python tools/conv_bench.py 2>&1 | grep shape >> $out
 done
-unset RES
-out=gpurun_out/r3/conv_trace.log; : > $out
-for sh in ${TRACE_SHAPES:-6 0 11}; do
-  for v in ${TRACE_LIBS:-libmotif_hip}; do
-    echo "== trace shape $sh lib $v" >> $out
-    MOTIF_HIP_LIB=tools/_trace/$v.so timeout 300 python tools/trace_s2.py $sh 2>&1 | grep -v amdgpu.ids >> $out
-  done
+paste <(grep -A18 "ENGINE=1" $out | cut -c1-75) <(grep -A18 "ENGINE=2" $out | cut -c43-75) <(grep -A18 "ENGINE=3" $out | cut -c43-75)
+for sh in ${TRACE_SHAPES:-0}; do
+  MOTIF_CONV_ENGINE=3 MOTIF_HIP_LIB=tools/_trace/libmotif_hip.so timeout 300 python tools/trace_s2.py $sh 2>&1 | grep -E "prologue|chunk|epilogue|duration" | head -12
 done
-tail -3 gpurun_out/r3/conv_tests.log; cat gpurun_out/r3/conv_trace.log | head -${TRACE_LINES:-60}
-paste <(grep -A18 "ENGINE=1 RES=0" gpurun_out/r3/conv_bench.log | cut -c1-75) <(grep -A18 "ENGINE=0 RES=0" gpurun_out/r3/conv_bench.log | cut -c43-75)
-paste <(grep -A18 "ENGINE=1 RES=1" gpurun_out/r3/conv_bench.log | cut -c1-75) <(grep -A18 "ENGINE=0 RES=1" gpurun_out/r3/conv_bench.log | cut -c43-75)
+for e in 1 3; do
+MOTIF_BENCH_SHAPES=1 MOTIF_CONV_ENGINE=$e timeout 900 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fp32-leg > /dev/null 2> gpurun_out/r3/shapes_e$e.txt
+done
+python - <<'PY'
+import re
+def load(f):
+    d={}
+    for l in open(f):
+        m=re.match(r"# (\(.*?\))\s+(\d+)\s+([\d.]+)\s+([\d.]+)",l)
+        if m: d[m.group(1)]=(int(m.group(2)),float(m.group(3)),float(m.group(4)))
+    return d
+a=load("gpurun_out/r3/shapes_e1.txt"); b=load("gpurun_out/r3/shapes_e3.txt")
+tot1=tot2=0
+for k,(n,ms,tf) in sorted(a.items(), key=lambda kv:-kv[1][1]):
+    if k in b and ", 3, 3," in k:
+        ms2=b[k][1]
+        if abs(ms2-ms)/ms>0.02 and ms>0.1: print("%-38s x%-3d legacy %6.3f ms  rows8 %6.3f ms  %+5.1f%%" % (k,n,ms,ms2,100*(ms2-ms)/ms))
+        tot1+=ms; tot2+=ms2
+print("total 3x3: legacy %.2f  rows8-forced %.2f" % (tot1,tot2))
+PY
