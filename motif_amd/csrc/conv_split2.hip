@@ -126,21 +126,23 @@ __device__ __forceinline__ void conv_epilogue_wave(const ConvArgs& a, f32x16 (&a
     const int half = lane >> 5, l31 = lane & 31;
     const unsigned HWo = (unsigned)(a.Ho * a.Wo);
     const int rm = a.res_mode;
-    unsigned loff[NIT]; int scoff[NIT], coi[NIT], rowi[NIT], oxi[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
+    // per-lane item geometry, recomputed from the lane id where it is used (a handful of VALU operations; held in registers
+    // across the passes it cost 15 VGPRs and pushed the kernel into scratch)
+    auto item = [&](int it, int& co, int& row, int& col) {
         const int idx = lane + 64 * it;
-        const int co = idx / (RS * 8), q = idx - co * (RS * 8);
-        rowi[it] = q >> 3; oxi[it] = ox0 + (q & 7) * 4;
-        loff[it] = (unsigned)co * HWo + (unsigned)((oy0 + rowi[it]) * a.Wo + oxi[it]);
-        scoff[it] = co * S + rowi[it] * 32 + (q & 7) * 4;
-        coi[it] = co;
-    }
-    auto okat = [&](int pass, int it) {                               // inside the image and the cout group
-        const int oy = oy0 + (pass % NRP) * RS + rowi[it];
-        return oy < a.Ho && oxi[it] < a.Wo && 8 * (pass / NRP) + coi[it] < climit;
+        co = idx / (RS * 8); const int q = idx - co * (RS * 8);
+        row = q >> 3; col = (q & 7) * 4;
     };
-    auto offat = [&](int pass, int it) { return loff[it] + (unsigned)(8 * (pass / NRP)) * HWo + (unsigned)((pass % NRP) * RS * a.Wo); };
+    auto okat = [&](int pass, int it) {                               // inside the image and the cout group
+        int co, row, col;
+        item(it, co, row, col);
+        return oy0 + (pass % NRP) * RS + row < a.Ho && ox0 + col < a.Wo && 8 * (pass / NRP) + co < climit;
+    };
+    auto offat = [&](int pass, int it) {
+        int co, row, col;
+        item(it, co, row, col);
+        return (unsigned)(8 * (pass / NRP) + co) * HWo + (unsigned)((oy0 + (pass % NRP) * RS + row) * a.Wo + ox0 + col);
+    };
     f32x4 rv[2][NIT];
     auto load_res = [&](int pass, f32x4 (&dst)[NIT]) {
 #pragma unroll
@@ -159,8 +161,10 @@ __device__ __forceinline__ void conv_epilogue_wave(const ConvArgs& a, f32x16 (&a
         f32x4 v[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            v[it] = *(const f32x4*)(sc + scoff[it]);
-            const float b = bias_w[8 * cq + coi[it]];
+            int co, row, col;
+            item(it, co, row, col);
+            v[it] = *(const f32x4*)(sc + co * S + row * 32 + col);
+            const float b = bias_w[8 * cq + co];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[it][e] += b;
         }

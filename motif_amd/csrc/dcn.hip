@@ -417,6 +417,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 // only place that waits.  One 8-wave block per CU: col 2 x 36 KB + window 2 x 18 KB + weights 2 x 18 KB = 147 KB.
 // ================================================================================================
 #define DW_R 8
+#ifdef MOTIF_DCN_LOCKSTEP
+static constexpr bool motif_dcn_lockstep = true;
+#else
+static constexpr bool motif_dcn_lockstep = false;
+#endif
 #ifdef MOTIF_DCN_TRACE
 __device__ long long g_dcn_trace[64 * 8];
 extern "C" int motif_debug_dcn_trace(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dcn_trace), sizeof(long long) * n); }
@@ -663,39 +668,48 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
         if (newg) geometry();                                 // were requested a whole group ago (and drained at the last barrier)
         DT(5);
         if (more2) win_request((ch + 2) * DF_CH);             // window two chunks ahead: sampling + MFMA stretch cover its latency
+        // The two waves of a SIMD (w and w + WAVES/2) take the two stretches of an iteration in OPPOSITE order: one samples chunk
+        // ch+1 (LDS reads + blend arithmetic) while the other multiplies chunk ch, then they swap.  Both orders are legal inside
+        // one barrier interval (col(ch) and window(ch+1) are complete since the last barrier).  In lock step both waves wanted the
+        // matrix pipe at the same time and the older one then waited 1.9 k of the 7.4 k cycles of a chunk at the barrier.
+        auto mfma_stretch = [&]() {
+        {
+                const float* colp = col0 + cur * DF_ROWS * NPX + wave * 32 + l31;
+                const dcn_u32x4* wfr = (const dcn_u32x4*)(wl0 + cur * WCH) + lane;
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = 16 * ks + 8 * half + e;
+                        v[e] = (ks < 2 || r < DF_ROWS) ? colp[(r < DF_ROWS ? r : 0) * NPX] : 0.f;
+                        if (ks == 2 && r >= DF_ROWS) v[e] = 0.f;
+                    }
+                    dcn_u32x4 x[3];
+                    dcn_split8(v, x);
+                    dcn_u32x4 w[2][3];
+#pragma unroll
+                    for (int part = 0; part < 3; ++part)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) w[t][part] = wfr[((ks * 3 + part) * 2 + t) * 64];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dcn_bf16x8, w[t][DCN_PW[k]]),
+                                                                              __builtin_bit_cast(dcn_bf16x8, x[DCN_PX[k]]), acc[t], 0, 0, 0);
+                }
+            }
+        };
+        const bool mfma_first = WAVES == 8 && __builtin_amdgcn_readfirstlane(wave) >= WAVES / 2 && !motif_dcn_lockstep;
+        if (mfma_first) mfma_stretch();
         if (more) sample(cnext, (ch + 1) & 1);                // LDS only (plus the rare fallback)
         DT(6);
         if (newg && cnext / cpg + 1 < a.dg) geom_request(cnext / cpg + 1);
         if (more) w_request(ch + 1, cur ^ 1);                 // LDS-DMA last (hipcc drains vmcnt at the next ordinary load behind a
                                                               // pending LDS-DMA); weight buffer cur^1 was last read before the previous barrier
         DT(1);
-        {
-            const float* colp = col0 + cur * DF_ROWS * NPX + wave * 32 + l31;
-            const dcn_u32x4* wfr = (const dcn_u32x4*)(wl0 + cur * WCH) + lane;
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int r = 16 * ks + 8 * half + e;
-                    v[e] = (ks < 2 || r < DF_ROWS) ? colp[(r < DF_ROWS ? r : 0) * NPX] : 0.f;
-                    if (ks == 2 && r >= DF_ROWS) v[e] = 0.f;
-                }
-                dcn_u32x4 x[3];
-                dcn_split8(v, x);
-                dcn_u32x4 w[2][3];
-#pragma unroll
-                for (int part = 0; part < 3; ++part)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) w[t][part] = wfr[((ks * 3 + part) * 2 + t) * 64];
-#pragma unroll
-                for (int k = 0; k < 6; ++k)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dcn_bf16x8, w[t][DCN_PW[k]]),
-                                                                          __builtin_bit_cast(dcn_bf16x8, x[DCN_PX[k]]), acc[t], 0, 0, 0);
-            }
-        }
+        if (!mfma_first) mfma_stretch();
         DT(2);
         if (more) col_commit(cur ^ 1);
         if (more2) win_commit(ch & 1);                        // window(ch+2) replaces window(ch), last read in the previous iteration
