@@ -49,8 +49,8 @@ struct S2Order {
 //   widx[m]: weight fragment (part) of the tap after next requested after MFMA m;
 //   ext[s]: staging step of the NEXT chunk done after slot s: kind << 8 | index.  The wave's share of the chunk is staged in
 //           ROUNDS rounds through one landing area; per round r: 1 = global load (r*8 + i), 2 = mask + park it (r*8 + i),
-//           3 = read four channels of item set it (r*4 + it*2 + half), 4 = split half-step (r*16 + it*8 + 2*pair + half),
-//           5 = store the three parts of item set it (r*2 + it), 6 = both half-steps of a pair (as 4), 7 = all eight channels (as 3) -- MERGE.
+//           3 = read four channels of item set it (r*8 + it*2 + half), 4 = split half-step (r*32 + it*8 + 2*pair + half),
+//           5 = store the three parts of item set it (r*4 + it), 6 = both half-steps of a pair (as 4), 7 = all eight channels (as 3) -- MERGE.
 template <int RW, int NLD, int NSPL, int ROUNDS>
 struct S2Sched {
     static constexpr bool MERGE = RW < 3;                      // few free slots per tap: a channel pair's two split half-steps share a slot
@@ -77,19 +77,19 @@ struct S2Sched {
         for (int s = 0; s < S; ++s) { const int m = s % M; if (bpart[m] < 0 && widx[m] < 0) fr[nf++] = s; }
         const int per_tap = nf / 9;
         int f = 0, ready = 0;                                  // ready: first free-slot index at which the loads in flight may be parked
+        ready = f + 2 * per_tap;                               // (two taps after the round's FIRST load was issued)
         for (int i = 0; i < NLD; ++i) ext[fr[f++]] = (1 << 8) | i;
-        ready = f + 2 * per_tap;
         for (int r = 0; r < ROUNDS; ++r) {
             if (f < ready) f = ready;
             for (int i = 0; i < NLD; ++i) ext[fr[f++]] = (2 << 8) | (r * 8 + i);
             if (r + 1 < ROUNDS) {
-                for (int i = 0; i < NLD; ++i) ext[fr[f++]] = (1 << 8) | ((r + 1) * 8 + i);
                 ready = f + 2 * per_tap;
+                for (int i = 0; i < NLD; ++i) ext[fr[f++]] = (1 << 8) | ((r + 1) * 8 + i);
             }
             for (int it = 0; it < NSPL; ++it) {
-                for (int h = 0; h < 2; h += MERGE ? 2 : 1) ext[fr[f++]] = ((MERGE ? 7 : 3) << 8) | (r * 4 + it * 2 + h);
-                for (int hs = 0; hs < 8; hs += MERGE ? 2 : 1) ext[fr[f++]] = ((MERGE ? 6 : 4) << 8) | (r * 16 + it * 8 + hs);
-                ext[fr[f++]] = (5 << 8) | (r * 2 + it);
+                for (int h = 0; h < 2; h += MERGE ? 2 : 1) ext[fr[f++]] = ((MERGE ? 7 : 3) << 8) | (r * 8 + it * 2 + h);
+                for (int hs = 0; hs < 8; hs += MERGE ? 2 : 1) ext[fr[f++]] = ((MERGE ? 6 : 4) << 8) | (r * 32 + it * 8 + hs);
+                ext[fr[f++]] = (5 << 8) | (r * 4 + it);
             }
         }
         used = f; nfree = nf;                                  // static_assert at the use: the steps must fit the free slots
@@ -199,10 +199,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
     constexpr int STG = NP * SLOTS;                      // one bf16 staging buffer (u32x4)
     constexpr int UW = 2 * PH * 2 / WAVES, UWR = UW / ROUNDS;   // (octet, row, half row) units per wave / per round: 8 channels x 5 quads
     constexpr int NQ = UWR * 40, NLD = (NQ + 63) / 64;   // 16-byte pieces of a round, loads per lane
-    constexpr int RS = WAVES == 8 ? RW : 2;              // rows per epilogue pass (scratch = 8 couts x RS rows)
+    constexpr int RS = (WAVES == 8 || RW % 2) ? RW : 2;  // rows per epilogue pass (scratch = 8 couts x RS rows)
     constexpr int LW = NQ > 64 * RS ? NQ : 64 * RS;      // landing area of one wave (u32x4), reused as its epilogue scratch
     constexpr int NITEM = UWR * 17, NSPL = (NITEM + 63) / 64;            // (unit, pixel) items a wave splits per round
-    static_assert(2 * PH * 2 % WAVES == 0 && UW % ROUNDS == 0 && NSPL <= 2 && NLD <= 8 && ROUNDS <= 2, "unit split");
+    static_assert(2 * PH * 2 % WAVES == 0 && UW % ROUNDS == 0 && NSPL <= 4 && NLD <= 8 && ROUNDS <= 2, "unit split");
     using SCHT = S2Sched<RW, NLD, NSPL, ROUNDS>;
     constexpr int M = SCHT::M;
     extern __shared__ __attribute__((aligned(16))) u32x4 lds_raw[];
@@ -376,11 +376,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
                     const int e = SCH.ext[t * M + m], kind = e >> 8, idx = e & 255;
                     if (kind == 1) st_load(idx >> 3, idx & 7, sc * 16);
                     else if (kind == 2) st_park(idx >> 3, idx & 7, sc * 16);
-                    else if (kind == 3) st_read(idx >> 2, (idx >> 1) & 1, idx & 1);
+                    else if (kind == 3) st_read(idx >> 3, (idx >> 1) & 3, idx & 1);
                     else if (kind == 4) st_split((idx & 7) >> 1, idx & 1);
                     else if (kind == 6) { st_split((idx & 7) >> 1, 0); st_split((idx & 7) >> 1, 1); }
-                    else if (kind == 7) { st_read(idx >> 2, (idx >> 1) & 1, 0); st_read(idx >> 2, (idx >> 1) & 1, 1); }
-                    else if (kind == 5) st_store(idx >> 1, idx & 1, dstbuf);
+                    else if (kind == 7) { st_read(idx >> 3, (idx >> 1) & 3, 0); st_read(idx >> 3, (idx >> 1) & 3, 1); }
+                    else if (kind == 5) st_store(idx >> 2, idx & 3, dstbuf);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -485,7 +485,7 @@ bool motif_conv_split2_eligible(const MotifConvDesc* d, const ConvArgs& a, int P
         if ((a.in0_bs[i] | a.out_bs[i] | (a.in1[i] ? a.in1_bs[i] : 0) | (a.res[i] ? a.res_bs[i] : 0)) & 3) return false;
     }
     const int force = motif_opt(MOTIF_OPT_CONV_ENGINE);
-    if (force == 2 || force == 3) return true;                         // forced (tests, tools)
+    if (force == 2 || force == 3 || force == 4) return true;           // forced (tests, tools)
     // Measured crossover on the clip's launches (tools/r3_conv.sh: per-shape A/B inside the model): the 12-row shape wins where
     // its tiles fill >= 0.9 of the rounds of the CUs (+3 ... +13 %), the 8-row shape where every CU gets at most one tile (+4 ... +20 %:
     // the deep-K layers of RAFT's update block); in between the two-block kernel (8-row tiles, 512 block slots) is as good or better.
@@ -518,7 +518,15 @@ int motif_conv_split2_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStre
         (void)hipFuncSetAttribute((const void*)conv_split2_kernel<8, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (big) {
+    if (force == 4) {                                    // 6-row tiles, two 4-wave workgroups per CU: best on the smallest maps in isolation
+                                                         // (+10 ... +35 % on 45x80 / 90x160 single launches), a draw or worse inside the model; opt-in
+        const long T6 = per_row_tile * ((Ho + 5) / 6);
+        const int G = (int)(T6 < 2 * cus ? T6 : 2 * cus);
+        const size_t ldsb = ((size_t)4 * 16 + (size_t)2 * 3 * (2 * 8 * 34 + 4) + (size_t)4 * 320) * 16;
+        static bool attr4 = false;
+        if (!attr4) { (void)hipFuncSetAttribute((const void*)conv_split2_kernel<4, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr4 = true; }
+        conv_split2_kernel<4, 3, 1><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T6, (Ho + 5) / 6);
+    } else if (big) {
         const int G = (int)(T12 < cus ? T12 : cus);
         const size_t ldsb = ((size_t)8 * 16 + (size_t)2 * 3 * (2 * 14 * 34 + 4) + (size_t)8 * 280) * 16;
         conv_split2_kernel<8, 3, 1><<<dim3(G, 1, 1), 512, ldsb, s>>>(a, (int)T12, (Ho + 11) / 12);

@@ -194,7 +194,7 @@ def test_conv_split_multi_problem_and_views(keep_mma):
     assert float(buf[:, :8].abs().max()) == 0 and float(buf[:, 72:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("tile", [2, 3], ids=["rows12", "rows8"])
+@pytest.mark.parametrize("tile", [2, 3, 4], ids=["rows12", "rows8", "rows6x2"])
 @pytest.mark.parametrize("shape", [(3, 64, 64, 180, 320), (2, 64, 216, 90, 160), (5, 128, 64, 63, 100), (1, 48, 80, 19, 36)])
 def test_conv_split2_persistent_tiles(shape, tile, keep_mma):
     """The round-3 conv kernel over MANY tiles per workgroup (persistent loop, next tile staged under the last chunk, ragged last
