@@ -14,6 +14,7 @@ struct ConvArgs {
     int KH, KW, stride, pad, dil, pad_mode;
     int act, act2, act_split, res_mode;
     int CK, PH, PW, Kpad, tiles_x, ncg;
+    int xoff;  // conv_igemm VEC staging: the LDS patch rows start xoff pixels left of the patch (16-byte aligned loads), PW = their pitch
     int dbg;   // tuning aid: 1 = skip staging, 2 = skip MFMA loop
 };
 

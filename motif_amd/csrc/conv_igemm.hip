@@ -16,13 +16,20 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
-// SPEC 1: 3x3, stride 1, dilation 1 (patch pitch 34): tap offsets are immediates, the MFMA loop has no VALU.
-template <int NC, int RPW, int SPEC>
+// SPEC 1: 3x3, stride 1, dilation 1 (patch pitch 34, or 40 with VEC): tap offsets are immediates, the MFMA loop has no VALU.
+// VEC (round 3): the patch is staged in 16-byte row pieces -- 4 pixels of one channel per lane instead of one -- into LDS rows
+// that start a.xoff pixels left of the patch (so that every piece is an aligned quad of the image row): a quarter of the
+// vector-memory instructions.  The narrow / 1x1 layers this engine serves are bandwidth-bound, and their 4-byte-per-lane staging
+// loads cost ~45 cycles each on the CU's texture addresser (what round 3 found to bound conv_split_kernel too).  Needs
+// W % 4 == 0, 16-byte aligned inputs and zero padding (host check); everything else takes the scalar plan.
+template <int NC, int RPW, int SPEC, bool VEC>
 __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = 64 * (8 / RPW);       // threads: one wave per RPW output rows of the 8-row tile
     constexpr int WN = 32 * NC;               // weight slab row width
     constexpr int NE_MAX = PATCH_MAX / NT;    // patch elements a thread prefetches per chunk
+    constexpr int NE4 = NE_MAX / 4;           // ... as 16-byte pieces (VEC)
+    constexpr int PITCH = VEC ? 40 : 34;      // SPEC 1 row pitch
     constexpr int NW_MAX = WCHUNK_MAX / 4 / NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int tile_id = (a.dbg & 64) ? (int)blockIdx.x : xcd_tile_id();
@@ -46,24 +53,41 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
     // chunk-invariant staging plan, in registers: element e = tid + NT*j of the [CK][PH][PW] patch comes from
     // input offset eoff[j] = c*HW + iy*W + ix relative to the chunk's first channel plane (-1: padding),
     // ech[j] = chunk-local channel (to cut off the tail chunk).  Integer divisions happen once per block.
-    const int iy0 = ty * 8 * a.stride - a.pad, ix0 = tx * 32 * a.stride - a.pad;
-    int eoff[NE_MAX];
-    int ech[NE_MAX];
+    const int iy0 = ty * 8 * a.stride - a.pad, ix0 = tx * 32 * a.stride - a.pad - (VEC ? a.xoff : 0);
+    int eoff[VEC ? NE4 : NE_MAX];
+    int ech[VEC ? NE4 : NE_MAX];
+    if constexpr (VEC) {
+        const int PWQ = a.PW >> 2, PHQ = a.PH * PWQ, nq = a.CK * PHQ;          // quads per row / channel / chunk
 #pragma unroll
-    for (int j = 0; j < NE_MAX; ++j) {
-        const int e = tid + NT * j;
-        eoff[j] = -1;
-        ech[j] = 1 << 20;
-        if (e < CKPHW) {
-            const int c = e / PHW, p = e - c * PHW;
-            const int py = p / a.PW, px = p - py * a.PW;
-            int iy = iy0 + py, ix = ix0 + px;
-            if (a.pad_mode == 1) {
-                if (iy < 0) iy = -iy; else if (iy >= a.H) iy = 2 * (a.H - 1) - iy;
-                if (ix < 0) ix = -ix; else if (ix >= a.W) ix = 2 * (a.W - 1) - ix;
+        for (int j = 0; j < NE4; ++j) {
+            const int e = tid + NT * j;
+            eoff[j] = -1;
+            ech[j] = 1 << 20;
+            if (e < nq) {
+                const int c = e / PHQ, p = e - c * PHQ;
+                const int py = p / PWQ, xq = p - py * PWQ;
+                const int iy = iy0 + py, ix = ix0 + 4 * xq;                    // ix % 4 == 0, W % 4 == 0: a quad is inside or outside as a whole
+                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) eoff[j] = c * (int)HW + iy * a.W + ix;
+                ech[j] = c;
             }
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) eoff[j] = c * (int)HW + iy * a.W + ix;
-            ech[j] = c;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NE_MAX; ++j) {
+            const int e = tid + NT * j;
+            eoff[j] = -1;
+            ech[j] = 1 << 20;
+            if (e < CKPHW) {
+                const int c = e / PHW, p = e - c * PHW;
+                const int py = p / a.PW, px = p - py * a.PW;
+                int iy = iy0 + py, ix = ix0 + px;
+                if (a.pad_mode == 1) {
+                    if (iy < 0) iy = -iy; else if (iy >= a.H) iy = 2 * (a.H - 1) - iy;
+                    if (ix < 0) ix = -ix; else if (ix >= a.W) ix = 2 * (a.W - 1) - ix;
+                }
+                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) eoff[j] = c * (int)HW + iy * a.W + ix;
+                ech[j] = c;
+            }
         }
     }
     // K order inside a chunk: (channel pair, tap, half) -- an MFMA step takes tap t of channel 2cp from the lower
@@ -88,20 +112,32 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
     const float* wbase = a_wp + ((long)(g * a.ncg + cg) * a.Kpad) * WN;
     int pix[RPW];
 #pragma unroll
-    for (int j = 0; j < RPW; ++j) pix[j] = (RPW * wave + j) * a.stride * a.PW + l31 * a.stride;
+    for (int j = 0; j < RPW; ++j) pix[j] = (RPW * wave + j) * a.stride * a.PW + l31 * a.stride + (VEC ? a.xoff : 0);
 
-    float pre[NE_MAX];
+    float pre[VEC ? 1 : NE_MAX];
+    f32x4 pre4[VEC ? NE4 : 1];
     f32x4 wreg[NW_MAX];
     // the two-source concat never straddles a chunk when C0 % CK == 0 (host falls back to CK | C0 otherwise)
     auto issue = [&](int c0) {            // global -> registers for the chunk starting at channel c0
         const int gch0 = g * a.Cin_g + c0;
         const float* base = (gch0 < a.C0) ? in0n + (long)gch0 * HW : in1n + (long)(gch0 - a.C0) * HW;
         const int cvalid = a.Cin_g - c0;                 // channels of this chunk that exist
+        if constexpr (VEC) {
 #pragma unroll
-        for (int j = 0; j < NE_MAX; ++j) {
-            float v = 0.f;
-            if (eoff[j] >= 0 && ech[j] < cvalid) v = base[eoff[j]];
-            pre[j] = v;
+            for (int j = 0; j < NE4; ++j) {              // branch-free: padding quads read the chunk's first quad and are zeroed
+                const bool ok = eoff[j] >= 0 && ech[j] < cvalid;
+                f32x4 v = *(const f32x4*)(base + (ok ? eoff[j] : 0));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = ok ? v[u] : 0.f;
+                pre4[j] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NE_MAX; ++j) {
+                float v = 0.f;
+                if (eoff[j] >= 0 && ech[j] < cvalid) v = base[eoff[j]];
+                pre[j] = v;
+            }
         }
         const int r0 = c0 * T;
         int rows = a.Kpad - r0; if (rows > KC) rows = KC;
@@ -117,10 +153,18 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
     auto commit = [&](int buf, int rows) {   // registers -> LDS buffer `buf`
         float* patch = patch0 + buf * patch_elems;
         f32x4* w4 = (f32x4*)(wl0 + buf * KC * WN);
+        if constexpr (VEC) {
 #pragma unroll
-        for (int j = 0; j < NE_MAX; ++j) {
-            const int e = tid + NT * j;
-            if (e < CKPHW) patch[e] = pre[j];
+            for (int j = 0; j < NE4; ++j) {
+                const int e = tid + NT * j;
+                if (4 * e < CKPHW) *(f32x4*)(patch + 4 * e) = pre4[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NE_MAX; ++j) {
+                const int e = tid + NT * j;
+                if (e < CKPHW) patch[e] = pre[j];
+            }
         }
         const int n4 = rows * WN / 4;
 #pragma unroll
@@ -152,7 +196,7 @@ __global__ __launch_bounds__(64 * (8 / RPW)) void conv_igemm_kernel(ConvArgs a) 
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
 #pragma unroll
-                    for (int j = 0; j < RPW; ++j) bv[t][j] = bc[(t / 3) * 34 + (t % 3) + pix[j]];
+                    for (int j = 0; j < RPW; ++j) bv[t][j] = bc[(t / 3) * PITCH + (t % 3) + pix[j]];
 #pragma unroll
                     for (int i = 0; i < NC; ++i) av[t][i] = wc[t * 2 * WN + i * 32];
                 }
@@ -233,7 +277,7 @@ __global__ void conv_pack_kernel(const float* w, float* wp, int Cout_g, int Cin_
 namespace {
 struct ConvPlan { int Cin, Cin_g, Cout_g, K, Kpad, NC, WN, ncg, Ho, Wo, PH, PW, CK, T; size_t lds; };
 
-bool plan_conv(const MotifConvDesc* d, ConvPlan* p) {
+bool plan_conv(const MotifConvDesc* d, ConvPlan* p, bool vec = false) {
     if (!d || d->groups < 1 || d->KH < 1 || d->KW < 1 || d->stride < 1 || d->dil < 1) return false;
     p->Cin = d->C0 + d->C1;
     if (p->Cin % d->groups || d->Cout % d->groups || p->Cin <= 0 || d->Cout <= 0) return false;
@@ -251,6 +295,11 @@ bool plan_conv(const MotifConvDesc* d, ConvPlan* p) {
     if ((long)d->H * d->W >= 0xFFFFFF) return false;     // plane offsets are packed into 24 bits
     p->PH = 7 * d->stride + (d->KH - 1) * d->dil + 1;
     p->PW = 31 * d->stride + (d->KW - 1) * d->dil + 1;
+    if (vec) {                                           // rows of whole aligned quads: xoff pixels of slack on the left (conv_igemm_kernel VEC)
+        const int xoff = (4 - d->pad % 4) % 4;
+        p->PW = 4 * ((xoff + p->PW + 3) / 4);
+        if (d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1) p->PW = 40;    // the pitch SPEC 1 is compiled for
+    }
     // chunk: as many channels as fit the register-prefetch limits and ~29 KB per LDS buffer, CK*T even
     const long PHW = (long)p->PH * p->PW;
     auto ok = [&](int c) {
@@ -329,25 +378,33 @@ extern "C" int motif_conv2d_fwd_multi(const MotifConvDesc* d, int P, const float
         a.act = d->act; a.act2 = d->act2; a.act_split = d->act_split; a.res_mode = d->res_mode;
         return motif_conv_split_launch(d, a, P, (hipStream_t)stream);
     }
+    // 16-byte staging (conv_igemm_kernel VEC) where the layout allows it: rows of whole quads, aligned inputs, zero padding
+    bool vec = (d->W & 3) == 0 && d->pad_mode == 0 && !motif_opt(MOTIF_OPT_CONV_NOVEC);
+    for (int i = 0; i < P && vec; ++i)
+        vec = ((((unsigned long long)a.in0[i] | (unsigned long long)a.in1[i]) & 15) == 0) && (((a.in0_bs[i] | (a.in1[i] ? a.in1_bs[i] : 0)) & 3) == 0);
+    if (vec && !plan_conv(d, &p, true)) { vec = false; if (!plan_conv(d, &p)) return MOTIF_ELIMIT; }
     a.C0 = d->C0; a.H = d->H; a.W = d->W; a.Ho = p.Ho; a.Wo = p.Wo;
     a.Cin_g = p.Cin_g; a.Cout_g = p.Cout_g; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil; a.pad_mode = d->pad_mode;
     a.act = d->act; a.act2 = d->act2; a.act_split = d->act_split; a.res_mode = d->res_mode;
     a.CK = p.CK; a.PH = p.PH; a.PW = p.PW; a.Kpad = p.Kpad;
+    a.xoff = vec ? (4 - d->pad % 4) % 4 : 0;
     a.tiles_x = (p.Wo + 31) / 32;
     const int tiles_y = (p.Ho + 7) / 8;
     a.ncg = p.ncg;
     dim3 grid(a.tiles_x * tiles_y, d->groups * p.ncg, d->N * P);
     hipStream_t s = (hipStream_t)stream;
     const bool spec = d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1 && !motif_opt(MOTIF_OPT_CONV_NOSPEC);
-#define MOTIF_LAUNCH_CONV(NCV, SPECV)                                                                                        \
+#define MOTIF_LAUNCH_CONV(NCV, SPECV, VECV)                                                                                  \
     do {                                                                                                                     \
         if (p.lds > 64 * 1024)                                                                                               \
-            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NCV, 1, SPECV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
-        conv_igemm_kernel<NCV, 1, SPECV><<<grid, 512, p.lds, s>>>(a);                                                      \
+            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<NCV, 1, SPECV, VECV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
+        conv_igemm_kernel<NCV, 1, SPECV, VECV><<<grid, 512, p.lds, s>>>(a);                                                \
     } while (0)
-    if (p.NC == 2) { if (spec) MOTIF_LAUNCH_CONV(2, 1); else MOTIF_LAUNCH_CONV(2, 0); }
-    else { if (spec) MOTIF_LAUNCH_CONV(1, 1); else MOTIF_LAUNCH_CONV(1, 0); }
+#define MOTIF_LAUNCH_CONV2(NCV, SPECV) do { if (vec) MOTIF_LAUNCH_CONV(NCV, SPECV, true); else MOTIF_LAUNCH_CONV(NCV, SPECV, false); } while (0)
+    if (p.NC == 2) { if (spec) MOTIF_LAUNCH_CONV2(2, 1); else MOTIF_LAUNCH_CONV2(2, 0); }
+    else { if (spec) MOTIF_LAUNCH_CONV2(1, 1); else MOTIF_LAUNCH_CONV2(1, 0); }
+#undef MOTIF_LAUNCH_CONV2
 #undef MOTIF_LAUNCH_CONV
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;

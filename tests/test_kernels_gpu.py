@@ -103,6 +103,33 @@ def test_conv2d_matches_torch_cpu(case, engine):
     close(out, ref, 2e-5, 2e-5, "conv")
 
 
+@pytest.mark.parametrize("case", [(32, 8, 1, 1, 0, 1, 40, 64, 2), (3, 32, 7, 2, 3, 1, 64, 96, 2), (8, 8, 3, 2, 1, 1, 40, 64, 1),
+                                  (128, 2, 3, 1, 1, 1, 16, 24, 1), (96, 64, 3, 1, 16, 16, 24, 40, 1), (14, 24, 3, 1, 1, 1, 30, 52, 2)])
+def test_conv_igemm_16_byte_staging_is_bit_identical_to_the_scalar_plan(case, keep_mma):
+    """The fp32 engine's VEC staging (4 pixels per lane, LDS rows shifted to aligned quads) changes how the patch reaches LDS,
+    not a single product: outputs must equal the 4-byte plan (option conv_novec) bit for bit -- 1x1, 7x7 stride 2, 3x3 stride 2,
+    a 2-cout head, a dilated layer, odd channel count; zero padding of every width."""
+    from motif_amd import ops
+    from motif_amd.models.modules.layers import Conv2d
+    cin, cout, k, stride, pad, dil, H, W, N = case
+    ops.set_conv_mma(ops.MMA_FP32)
+    m = Conv2d(cin, cout, k, stride, pad, dil, 1, True, "zeros")
+    with torch.no_grad():
+        m.weight.copy_(rnd(*m.weight.shape, seed=1, scale=1.0 / math.sqrt(cin * k * k)))
+        m.bias.copy_(rnd(cout, seed=2, scale=0.1))
+    x = rnd(N, cin, H, W, seed=3).to(dev())
+    m = m.to(dev())
+    try:
+        a = m(x, act=ops.ACT_RELU).clone()
+        ops.set_option("conv_novec", 1)
+        b = m(x, act=ops.ACT_RELU).clone()
+    finally:
+        ops.set_option("conv_novec", 0)
+    assert torch.equal(a, b)
+    ref = F.relu(F.conv2d(x.cpu(), m.weight.cpu(), m.bias.cpu(), stride, pad, dil))
+    close(a, ref, 2e-5, 2e-5, "vec staging vs torch")
+
+
 def test_conv2d_fused_epilogues_and_concat(engine):
     from motif_amd import ops
     from motif_amd.models.modules.layers import Conv2d
