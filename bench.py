@@ -457,10 +457,15 @@ def main():
             ach = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
             split = a.mma == "bf16x3"
             traffic, traffic_src = None, None
-            for name in ("r02_conv_split_traffic.json", "r01_conv_split_traffic.json") if split else ("r01_conv_traffic.json",):
+            for name in ("r03_conv_traffic.json", "r02_conv_split_traffic.json") if split else ("r01_conv_traffic.json",):
                 tj = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tj):          # rocprofv3 PMC passes of this kernel (FETCH_SIZE / WRITE_SIZE), not collected in this run
-                    traffic, traffic_src = json.load(open(tj)).get("hbm_bytes_per_launch"), "profiles/" + name
+                    tdoc = json.load(open(tj))
+                    traffic = tdoc.get("hbm_bytes_per_launch")
+                    if traffic is None:         # round-3 file: one entry per kernel of the 3x3 engine, on the trunk launch (80 of the 184)
+                        traffic = {k: v["hbm_bytes_per_launch"] for k, v in tdoc.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
+                        traffic["algorithmic_bytes_per_launch"] = tdoc.get("algorithmic_bytes_per_launch")
+                    traffic_src = "profiles/" + name
                     break
             peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
             clip_flop = sum(v.get("tflop", 0.0) for k, v in r["table"].items() if isinstance(v, dict)) * 1e12

@@ -354,6 +354,25 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__
     const float mean = (float)(stats[plane * 2] / (double)HW);
     const float var = (float)(stats[plane * 2 + 1] / (double)HW);
     const float inv = 1.0f / sqrtf(var + 1e-5f);
+    // 16 bytes per lane where the plane allows it (4-byte accesses cost the same vector-memory instruction for a quarter of the bytes)
+    const bool v4 = (HW & 3) == 0 && ((((unsigned long long)(x + base)) | ((unsigned long long)(out + base)) | (mode == 2 ? (unsigned long long)(res + base) : 0ull)) & 15) == 0;
+    if (v4) {
+        const f32x4* x4 = (const f32x4*)(x + base); const f32x4* r4 = (const f32x4*)(res + base); f32x4* o4 = (f32x4*)(out + base);
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (HW >> 2); i += gridDim.x * blockDim.x) {
+            f32x4 v = x4[i];
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            if (mode == 2) r = r4[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = (v[e] - mean) * inv;
+                if (mode >= 1) t = t > 0.f ? t : 0.f;
+                if (mode == 2) { t += r[e]; t = t > 0.f ? t : 0.f; }
+                v[e] = t;
+            }
+            o4[i] = v;
+        }
+        return;
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
         float v = (x[base + i] - mean) * inv;
         if (mode >= 1) v = v > 0.f ? v : 0.f;
@@ -389,10 +408,21 @@ __global__ __launch_bounds__(256) void in_moments_kernel(const float* __restrict
     const long base = (long)plane * HW;
     const int per = (HW + S - 1) / S, i0 = sb * per, i1 = min(HW, i0 + per);
     double s = 0.0, q = 0.0;
-    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        const double v = (double)x[base + i];
-        s += v;
-        q = fma(v, v, q);
+    // 16-byte loads where the slice allows it: a thread then takes 4 consecutive values per step instead of every 256th -- another
+    // (equally valid) fp64 summation order; the moments may differ in their last fp64 bits.
+    if ((per & 3) == 0 && (HW & 3) == 0 && (((unsigned long long)(x + base)) & 15) == 0) {
+        const f32x4* x4 = (const f32x4*)(x + base);
+        for (int i = (i0 >> 2) + threadIdx.x; i < (i1 >> 2); i += blockDim.x) {
+            const f32x4 v4 = x4[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double v = (double)v4[e]; s += v; q = fma(v, v, q); }
+        }
+    } else {
+        for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+            const double v = (double)x[base + i];
+            s += v;
+            q = fma(v, v, q);
+        }
     }
     const double ts = block_sum_d(s, sh), tq = block_sum_d(q, sh);
     if (threadIdx.x == 0) { part[((long)plane * S + sb) * 2] = ts; part[((long)plane * S + sb) * 2 + 1] = tq; }
@@ -519,49 +549,95 @@ extern "C" int motif_nchw_to_nhwc(const float* in, float* out, int N, int C, int
     return MOTIF_OK;
 }
 
-__global__ void gru_update_kernel(const float* z, const float* q, const float* h, float* out, long n) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (1.f - z[i]) * h[i] + z[i] * q[i];
+// four values per thread with 16-byte accesses where the tensors allow it; the last n % 4 values (and unaligned tensors) go one by one
+__global__ void gru_update_kernel(const float* __restrict__ z, const float* __restrict__ q, const float* __restrict__ h,
+                                  float* __restrict__ out, long n, int v4) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v4) {
+        const long i = t * 4;
+        if (i + 4 <= n) {
+            const f32x4 zz = *(const f32x4*)(z + i), qq = *(const f32x4*)(q + i), hh = *(const f32x4*)(h + i);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (1.f - zz[e]) * hh[e] + zz[e] * qq[e];
+            *(f32x4*)(out + i) = o;
+        } else
+            for (long j = i; j < n; ++j) out[j] = (1.f - z[j]) * h[j] + z[j] * q[j];
+    } else if (t < n)
+        out[t] = (1.f - z[t]) * h[t] + z[t] * q[t];
 }
 
 extern "C" int motif_gru_update(const float* z, const float* q, const float* h, float* out, long n, void* stream) {
     if (!z || !q || !h || !out || n < 1) return MOTIF_EINVAL;
-    gru_update_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(z, q, h, out, n);
+    const int v4 = ((((unsigned long long)z | (unsigned long long)q | (unsigned long long)h | (unsigned long long)out)) & 15) == 0;
+    gru_update_kernel<<<cdiv(v4 ? cdiv(n, 4) : n, 256), 256, 0, (hipStream_t)stream>>>(z, q, h, out, n, v4);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
+// V = values per thread: 4 (16-byte accesses) when HW % 4 == 0 and the tensors are 16-byte aligned, else 1
+template <int V>
 __global__ void lstm_gates_kernel(const float* __restrict__ cc, const float* __restrict__ c_cur, float* __restrict__ h_next,
                                   float* __restrict__ c_next, int hid, long HW, long n) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*hid*HW
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * V;   // over B*hid*HW
     if (i >= n) return;
     const long per = (long)hid * HW;
     const long b = i / per, r = i - b * per;
     const float* g4 = cc + b * 4 * per + r;
-    const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[per]), og = sigmoidf_(g4[2 * per]), gg = tanhf(g4[3 * per]);
-    const float cn = fg * c_cur[i] + ig * gg;
-    c_next[i] = cn;
-    h_next[i] = og * tanhf(cn);
+    float gi[V], gf[V], go[V], gg[V], cc_[V], cn[V], hn[V];
+    if constexpr (V == 4) {
+        *(f32x4*)gi = *(const f32x4*)g4; *(f32x4*)gf = *(const f32x4*)(g4 + per);
+        *(f32x4*)go = *(const f32x4*)(g4 + 2 * per); *(f32x4*)gg = *(const f32x4*)(g4 + 3 * per);
+        *(f32x4*)cc_ = *(const f32x4*)(c_cur + i);
+    } else { gi[0] = g4[0]; gf[0] = g4[per]; go[0] = g4[2 * per]; gg[0] = g4[3 * per]; cc_[0] = c_cur[i]; }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        cn[e] = sigmoidf_(gf[e]) * cc_[e] + sigmoidf_(gi[e]) * tanhf(gg[e]);
+        hn[e] = sigmoidf_(go[e]) * tanhf(cn[e]);
+    }
+    if constexpr (V == 4) { *(f32x4*)(c_next + i) = *(f32x4*)cn; *(f32x4*)(h_next + i) = *(f32x4*)hn; }
+    else { c_next[i] = cn[0]; h_next[i] = hn[0]; }
 }
 
 extern "C" int motif_lstm_gates(const float* cc, const float* c_cur, float* h_next, float* c_next, int B, int hid, int HW, void* stream) {
     if (!cc || !c_cur || !h_next || !c_next || B < 1 || hid < 1 || HW < 1) return MOTIF_EINVAL;
     const long n = (long)B * hid * HW;
-    lstm_gates_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(cc, c_cur, h_next, c_next, hid, HW, n);
+    const bool v4 = (HW & 3) == 0 && ((((unsigned long long)cc | (unsigned long long)c_cur | (unsigned long long)h_next | (unsigned long long)c_next)) & 15) == 0;
+    if (v4) lstm_gates_kernel<4><<<cdiv(n / 4, 256), 256, 0, (hipStream_t)stream>>>(cc, c_cur, h_next, c_next, hid, HW, n);
+    else lstm_gates_kernel<1><<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(cc, c_cur, h_next, c_next, hid, HW, n);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }
 
-__global__ void axpby_kernel(const float* x, const float* y, float a, float b, float* out, long n) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = y ? a * x[i] + b * y[i] : a * x[i];
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float a, float b, float* __restrict__ out, long n,
+                             int v4) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v4) {
+        const long i = t * 4;
+        if (i + 4 <= n) {
+            const f32x4 xx = *(const f32x4*)(x + i);
+            f32x4 o;
+            if (y) {
+                const f32x4 yy = *(const f32x4*)(y + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = a * xx[e] + b * yy[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = a * xx[e];
+            }
+            *(f32x4*)(out + i) = o;
+        } else
+            for (long j = i; j < n; ++j) out[j] = y ? a * x[j] + b * y[j] : a * x[j];
+    } else if (t < n)
+        out[t] = y ? a * x[t] + b * y[t] : a * x[t];
 }
 
 extern "C" int motif_axpby(const float* x, const float* y, float a, float b, float* out, long n, void* stream) {
     if (!x || !out || n < 1) return MOTIF_EINVAL;
-    axpby_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(x, y, a, b, out, n);
+    const int v4 = ((((unsigned long long)x | (unsigned long long)y | (unsigned long long)out)) & 15) == 0;
+    axpby_kernel<<<cdiv(v4 ? cdiv(n, 4) : n, 256), 256, 0, (hipStream_t)stream>>>(x, y, a, b, out, n, v4);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

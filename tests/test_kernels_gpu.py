@@ -354,6 +354,20 @@ def test_resize_bilinear(shape, align):
     close(ops.resize_bilinear(x.to(dev()), (ho, wo), align, 0.25), ref, 2e-6, 0, "resize")
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 360, 640), (2, 96, 90, 160), (1, 5, 37, 53)])
+def test_instance_norm_all_modes_large_planes(shape):
+    """The split-plane instance norm (moments in fp64 over slices, 16-byte accesses where the plane allows) against torch, with
+    the fused relu / residual epilogues; the odd plane takes the 4-byte path."""
+    from motif_amd import ops
+    n, c, h, w = shape
+    x, res = rnd(n, c, h, w, seed=5, scale=2.0) + 0.3, rnd(n, c, h, w, seed=6)
+    ref = F.instance_norm(x, eps=1e-5)
+    xd, rd = x.to(dev()), res.to(dev())
+    close(ops.instance_norm(xd, 0), ref, 2e-5, 1e-5, "mode 0")
+    close(ops.instance_norm(xd, 1), F.relu(ref), 2e-5, 1e-5, "mode 1")
+    close(ops.instance_norm(xd, 2, res=rd), F.relu(F.relu(ref) + res), 2e-5, 1e-5, "mode 2")
+
+
 def test_instance_norm_with_statistics_over_row_bands():
     """motif_instance_norm_moments / _apply (statistics of a row-tiled clip all-reduced over ranks): moments over two disjoint row
     ranges, summed, then applied to the whole plane == F.instance_norm of the plane, for every epilogue mode; a halo row outside the
@@ -451,6 +465,18 @@ def test_pool_transpose_gates_axpby():
     close(h2, hn, 2e-6)
     close(c2, cn, 2e-6)
     close(ops.axpby(x.to(dev()), (x * 2).to(dev()), 1.0, -1.0), -x, 0)
+    # ragged sizes: the 16-byte paths hand the last n % 4 values (or an odd plane) to the one-by-one code
+    z, q, h = torch.sigmoid(rnd(1, 3, 7, 9, seed=12)), rnd(1, 3, 7, 9, seed=13), rnd(1, 3, 7, 9, seed=14)
+    close(ops.gru_update(z.to(dev()), q.to(dev()), h.to(dev())), (1 - z) * h + z * q, 1e-6)
+    xr = rnd(1, 3, 7, 9, seed=15)
+    close(ops.axpby(xr.to(dev()), (xr * 2).to(dev()), 1.0, -1.0), -xr, 0)
+    close(ops.axpby(xr.to(dev()), None, 0.5, 0.0), xr * 0.5, 0)
+    cc, c = rnd(2, 8, 5, 7, seed=16, scale=3), rnd(2, 2, 5, 7, seed=17)
+    i, f, o, g = torch.split(cc, 2, 1)
+    cn = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+    h2, c2 = ops.lstm_gates(cc.to(dev()), c.to(dev()))
+    close(h2, torch.sigmoid(o) * torch.tanh(cn), 2e-6)
+    close(c2, cn, 2e-6)
     pred = rnd(3, 3, 24, 40, seed=9, scale=0.3)
     for ratio in (4.0, 3.0, 2.5):
         want = pred[:, :2] * 20.0 * ratio / 20.0 / ratio
