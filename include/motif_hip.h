@@ -84,7 +84,10 @@ int motif_splat_motif_acc_fwd(const float* imnet_out, const float* pred, const f
  *   g_lr  [2B,64,H,W] = W0[:, 66:130] . encoder feature (a 1x1 convolution at LR; gathered by the nearest tables here),
  *   ab    [2,64]      = W0[:, 64], W0[:, 65] (the raw predicted-flow channels, Ours.py:789),
  * a source carries u + g + a*p0 + b*p1.   acc [B*N, 67, HH, WW]: planes 0..63 sums, 64 sum of e^z*w, 65 max (init 1),
- * 66 count; consumed by motif_siren_synth_pre_fwd. */
+ * 66 count; consumed by motif_siren_synth_pre_fwd.
+ * g_lr = NULL: u_hr already holds u + g (motif_siren_imnet_add_fwd added the gathered LR term when it stored u -- the
+ * same fp32 sum, so the result is bit-identical); the kernel then reads one value per source and plane, which is the form
+ * its plane pipeline is sized for (a third faster than with g_lr).  Plane values are clamped to +-2^17 (see splat.hip). */
 int motif_splat_motif_pre_fwd(const float* u_hr, const float* pred, const float* g_lr, const float* ab,
                               const int32_t* iy, const int32_t* ix, const float* alpha, float flow_scale,
                               float* acc, int B, int N, int H, int W, int HH, int WW, int row0, int accumulate, void* stream);
@@ -113,6 +116,12 @@ long motif_siren_pack_split(int mode, const float* const* w, const float* const*
 int motif_siren_imnet_fwd(const float* packed, const float* feat_lr, const int32_t* iy, const int32_t* ix,
                           const float* rel_y, const float* rel_x, float* out,
                           int B2, int H, int W, int HH, int WW, int pre, void* stream);
+/* motif_siren_imnet_fwd with an LR tensor add_lr [2B,64,H,W] gathered through the same tables and ADDED to the 64 output planes
+ * (fp32 add after the head): the pre-contracted splat's G term (see motif_splat_motif_pre_fwd, g_lr = NULL), which costs the
+ * splat one load per source and plane instead of two.  pre must be 2; add_lr = NULL is motif_siren_imnet_fwd. */
+int motif_siren_imnet_add_fwd(const float* packed, const float* feat_lr, const float* add_lr, const int32_t* iy, const int32_t* ix,
+                              const float* rel_y, const float* rel_x, float* out,
+                              int B2, int H, int W, int HH, int WW, int pre, void* stream);
 /* flow_imnet: in = [flow_feat_lr(64 gathered) | t | rel_y | rel_x] -> pred [B2*N,3,Q] planar,
  * image index i = b2*N + n, t taken from times[(i) % (B*N)] laid out [B,N] (Ours.py:727-733). */
 int motif_siren_flow_fwd(const float* packed, const float* flowfeat_lr, const int32_t* iy, const int32_t* ix,

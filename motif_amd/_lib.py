@@ -38,6 +38,7 @@ _SIGS = {
     "motif_frames_f32_to_u8": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_siren_pack_split": (c_long, [c_int, POINTER(c_void_p), POINTER(c_void_p), P, P]),
     "motif_siren_imnet_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "motif_siren_imnet_add_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_siren_flow_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_siren_synth_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_synth_input_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -477,6 +477,9 @@ bool motif_conv_split2_eligible(const MotifConvDesc* d, const ConvArgs& a, int P
     const long HW = (long)d->H * d->W;
     if (HW * 64 >= 0x7fffffffL) return false;
     const int Cout_g = d->Cout / d->groups;
+    // the staging loads fetch whole 16-channel chunks and zero the channels beyond Cin afterwards: with a ragged last chunk they would read
+    // up to 15 planes past the end of the input tensor (PWC-Net's 81 / 209 / ... channel stacks, RAFT's 242) -- those layers stay on conv_split.hip
+    if (((d->C0 + d->C1) / d->groups) % 16) return false;
     if (d->act_split > 0 && ((d->act_split & 7) || (d->groups > 1 && (Cout_g & 7)))) return false;
     if (d->C1 > 0 && (d->groups != 1 || d->C0 % 16)) return false;
     for (int i = 0; i < P; ++i) {

@@ -483,6 +483,17 @@ extern "C" int motif_siren_imnet_fwd(const float* packed, const float* feat_lr, 
     return pre ? launch_siren<MODE_IMNET, SIREN_TP_IMNET, true>(a, stream) : launch_siren<MODE_IMNET, SIREN_TP_IMNET, false>(a, stream);
 }
 
+extern "C" int motif_siren_imnet_add_fwd(const float* packed, const float* feat_lr, const float* add_lr, const int32_t* iy, const int32_t* ix,
+                                         const float* rel_y, const float* rel_x, float* out,
+                                         int B2, int H, int W, int HH, int WW, int pre, void* stream) {
+    if (!add_lr) return motif_siren_imnet_fwd(packed, feat_lr, iy, ix, rel_y, rel_x, out, B2, H, W, HH, WW, pre, stream);
+    if (!packed || !feat_lr || !iy || !ix || !rel_y || !rel_x || !out || B2 < 1) return MOTIF_EINVAL;
+    if (pre != 2) return MOTIF_EINVAL;                // the added LR term exists for the split (bf16 matrix core) engine only
+    SirenArgs a{packed, feat_lr, nullptr, iy, ix, rel_y, rel_x, nullptr, out, B2, 1, B2, H, W, HH, WW};
+    a.add_lr = add_lr;
+    return motif_siren_split_launch(MODE_IMNET, a, stream);
+}
+
 extern "C" int motif_siren_flow_fwd(const float* packed, const float* flowfeat_lr, const int32_t* iy, const int32_t* ix,
                                     const float* rel_y, const float* rel_x, const float* times, float* pred,
                                     int B2, int N, int H, int W, int HH, int WW, int pre, void* stream) {

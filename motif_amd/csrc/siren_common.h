@@ -84,6 +84,8 @@ struct SirenArgs {
     float* out;
     int NB, N, B, H, W, HH, WW;   // NB = number of HR images processed
     int stagger;                  // start offset of the second wave per SIMD, in s_sleep(127) units (~8k cycles)
+    const float* add_lr;          // imnet, split engine: optional LR tensor [NB,64,H,W] gathered like src_lr and ADDED to the output planes
+                                  // (the pre-contracted splat's G term: motif_siren_imnet_add_fwd); last so that older initialisers leave it null
 };
 
 enum { MODE_IMNET = 0, MODE_FLOW = 1, MODE_SYNTH = 2, MODE_SYNTHC = 3 };   // SYNTHC: first layer pre-contracted into the splat (siren_split.hip)

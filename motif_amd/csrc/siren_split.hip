@@ -616,6 +616,14 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
             for (int p = 0; p < TP; ++p) {
                 if (!cur.valid[p]) continue;
+                if (a.add_lr) {
+                    // + the gathered LR term, rounded like the sum the splat kernel used to form (splat.hip, PRE form): u + g in fp32
+                    const float* gp = a.add_lr + (long)img * 64 * HWl + cur.lr[p] + (long)(4 * hf) * HWl;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc3[p][t][r] = acc3[p][t][r] + gp[(long)(32 * t + (r & 3) + 8 * (r >> 2)) * HWl];
+                }
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll

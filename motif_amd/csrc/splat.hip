@@ -9,6 +9,7 @@
 // Bit-level contract with the kernel text (softsplat_cp.py:27-38 etc.): floor -> int corners, weights
 // as (SE - o) products, bounds test >=0 & <size, addend = (value*e^z) rounded, then * weight rounded.
 #include "common.h"
+#include <type_traits>
 
 // The reference forms its flow tensor with separately rounded torch multiplies (Ours.py:794) and its kernel then ADDS the pixel
 // index (softsplat_cp.py:27-28).  hipcc contracts a*b+c into one FMA by default, which rounds once and can move a coordinate
@@ -111,35 +112,42 @@ extern "C" int motif_splat_fwd(const float* src, const float* flow, const float*
 // ---------------------------------------------------------------- fused MoTIF form: owner-computes
 // Forward splatting is a scatter, but the predicted HR flow is locally bounded, so it can be turned
 // inside out: a workgroup OWNS a 16x64 tile of the accumulator, scans the source pixels of BOTH
-// directions within +-R of the tile, keeps those whose 2x2 footprint touches the tile (compacted into an
-// LDS list in scan order: ballot counts per 64-source segment + one prefix sum), accumulates 8 accumulator planes at a time in LDS (the padded
-// 18x66 tile absorbs footprint cells that spill over the border, so the inner loop has no bounds tests),
-// and writes each finished plane tile with plain coalesced stores.
-// LDS accumulation is 32.32 FIXED POINT with ds_add_u64, on a PER-CELL binary scale: measured on MI355X
-// (tools/ubench_atomics.hip) ds_add_f32 retires one wave-instruction per ~194 cycles per CU, integer LDS
-// atomics one per ~5 -- float LDS atomics are 40x slower than integer ones and slower than
-// global_atomic_add_f32.  The reliability weight e^z = exp(-20 relu(p2)) (Ours.py:794) spans the whole fp32
-// range, so a fixed 2^-32 grid would flush exactly the occluded sources soft-splatting exists for.  A scale
-// pass therefore first takes, per accumulator cell, the maximum of e^z*weight over the contributing sources
-// (the reference's max plane, softsplat_max_cp.py:12-58, before its init-1 clamp) and its binary exponent E.
-// Each addend (value*e^z, then *weight, both rounded to fp32 exactly as softsplat_cp.py:35-40 does) is
-// multiplied by 2^-E -- exact, folded into the four corner weights -- so that the largest e^z*weight of a cell
-// lands in [1,2), then converted exactly up to 2^-32 (floor / fract / two cvt), summed as integers -- order
-// independent, deterministic -- and rounded to fp32 ONCE, together with the 2^E back-scale, at write-out.
-// Error bound: every addend is exact to 2^-32 of the cell's largest weight, so a normalised output
-// sum/warped_z (Ours.py:811-814) is off by at most (hits per cell) * 2^-32 * max|value| -- below one fp32 ulp
-// of the reference's own atomic sums, which vary run to run by more.
-// No global atomics, no zero-fill pass, and the two directions are summed in LDS.  A source whose
-// footprint leaves its own +-R neighbourhood ("far") is skipped here and scattered by
-// splat_far_kernel afterwards with global atomics -- both kernels evaluate the same predicate on the
-// same inputs, so every source is accounted exactly once.
+// directions within +-R of the tile and keeps those whose 2x2 footprint touches the tile (compacted into an
+// LDS list in scan order: ballot counts per 64-source segment + one prefix sum).
+//
+// Round 3: the accumulation itself is a GATHER, one thread per accumulator cell.  (Rounds 1-2 scattered with
+// ds_add_u64 into an LDS tile: 4 atomics per source and plane.  rocprofv3 on that kernel: LDS pipe busy 70 % of the
+// workgroup's life at 16 cycles per atomic instruction -- half of them bank / same-address conflict cycles, a
+// conflict-free ds_add_u64 costs 6.9 (tools/ubench_atomics.hip) -- vector ALU 28 %.)  Per tile:
+//   1. scale pass: per cell, the maximum of e^z*weight over its sources (= the reference's max plane,
+//      softsplat_max_cp.py:12-58, before its init-1 clamp), its binary exponent E, and the hit count (LDS integer atomics,
+//      once per tile, not per plane);
+//   2. the (source, corner) pairs are bucketed by cell (prefix sum of the counts, one returning atomic per pair);
+//   3. per chunk of 8 planes: every listed source stages value*e^z (fp32, rounded as softsplat_cp.py:35-40 rounds it) in LDS,
+//      then every cell walks its bucket: addend = staged value * corner weight (fp32, the reference's addend bit for bit),
+//      scaled by 2^(32-E) and rounded to an integer in double precision (one fma against 1.5*2^52) and summed in a double
+//      REGISTER accumulator -- sums of integers below 2^53 are exact, so the result does not depend on the order of the
+//      bucket (which the atomics of step 2 do not fix) and is bit-identical run to run and across tilings;
+//   4. the sum is scaled back by 2^(E-32) and rounded to fp32 ONCE, and stored with plain coalesced stores.
+// The per-cell scale E exists because the reliability weight e^z = exp(-20 relu(p2)) (Ours.py:794) spans the whole fp32
+// range: a fixed 2^-32 grid would flush exactly the occluded sources soft-splatting exists for.  With it every addend is
+// exact to 2^-32 of the cell's largest weight, so a normalised output sum/warped_z (Ours.py:811-814) is off by at most
+// (hits per cell) * 2^-32 * max|value| -- below one fp32 ulp of the reference's own atomic sums, which vary run to run by more.
+// No global atomics, no accumulator tile in LDS, no zero-fill pass, and the two directions are summed in registers.  A
+// source whose footprint leaves its own +-R neighbourhood ("far") is skipped here and scattered by splat_far_kernel
+// afterwards with global atomics -- both kernels evaluate the same predicate on the same inputs, so every source is
+// accounted exactly once.  Tiles that collect more than OT_EB sources (sinks) are processed in batches of OT_EB with the
+// buckets rebuilt per batch; the double accumulators run across the batches, so the result is the same exact sum.
 #define OT_H 16
 #define OT_W 64
-#define OT_CC 8
+#define OT_CC 4                         // planes per chunk
 #define OT_TPH (OT_H + 2)
 #define OT_TPW (OT_W + 2)
 #define OT_TP (OT_TPH * OT_TPW)
-#define OT_THREADS 1024
+#define OT_THREADS 1024                 // = OT_H * OT_W: thread t owns cell (t >> 6, t & 63) in the gather
+#define OT_EB 2560                      // sources staged at a time (a tile of smooth flow lists ~2 * 17 * 65 = 2210; flow_imnet's flows with
+                                        // the synthetic weights: p99 2313, max 2346 -- tools/splat_model_flow.py)
+#define OT_NCACHE 3                     // list entries per thread whose geometry stays in registers (>= OT_EB / OT_THREADS)
 
 struct MotifSplatArgs {
     const float* imnet_out; const float* pred; const float* feat_lr;
@@ -155,10 +163,20 @@ struct MotifSplatArgs {
 
 struct SrcGeom {
     float p0, p1, e;
+    float ox, oy;     // target position (global rows)
     int x0, y0;
     float wnw, wne, wsw, wse;
     bool near_;
 };
+
+// bilinear weight of corner q (bit 0: east, bit 1: south) of a source landing at (ox, oy): softsplat_cp.py:30-38
+__device__ __forceinline__ float corner_weight(float ox, float oy, int q) {
+    const float flx = floorf(ox), fly = floorf(oy);
+    const float xe = flx + 1.f, ye = fly + 1.f;
+    const float wx = (q & 1) ? ox - flx : xe - ox;
+    const float wy = (q & 2) ? oy - fly : ye - oy;
+    return wx * wy;
+}
 
 // geometry of one source pixel; `near_` = footprint within +-R of the source (float test: safe for huge flows)
 __device__ __forceinline__ SrcGeom src_geom(const MotifSplatArgs& a, int img, int x, int y, bool need_z) {
@@ -174,6 +192,7 @@ __device__ __forceinline__ SrcGeom src_geom(const MotifSplatArgs& a, int img, in
     g.near_ = (flx >= (float)x - R) && (flx + 1.f <= (float)x + R) && (fly >= yg - R) && (fly + 1.f <= yg + R);
     g.x0 = g.near_ ? (int)flx : 0;
     g.y0 = g.near_ ? (int)fly - a.row0 : 0;
+    g.ox = ox; g.oy = oy;
     const float xe = flx + 1.f, ye = fly + 1.f;
     g.wnw = (xe - ox) * (ye - oy);
     g.wne = (ox - flx) * (ye - oy);
@@ -187,21 +206,37 @@ __device__ __forceinline__ SrcGeom src_geom(const MotifSplatArgs& a, int img, in
     return g;
 }
 
-__device__ __forceinline__ void add_fix(unsigned long long* cell, float x) {
-    const float fl = floorf(x);
-    const unsigned lo = (unsigned)((x - fl) * 4294967296.0f);        // fract < 1, exact; cvt saturates
-    const int hi = (int)fl;
-    atomicAdd(cell, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)lo);
-}
-
-__device__ __forceinline__ float fix_to_float(unsigned long long v, int E) {
-    return (float)ldexp((double)(long long)v, E - 32);        // one rounding: exact integer sum * 2^(E-32)
-}
-
 // binary exponent E of a cell's largest e^z*weight m (float bits; m >= 0): m * 2^-E in [1,2); E = 0 for an empty cell
 __device__ __forceinline__ int cell_exponent(unsigned bits) {
     return bits ? (int)(bits >> 23) - 127 : 0;
 }
+
+// Workgroup barrier that orders LDS accesses only.  __syncthreads() also waits for every global load and store in flight
+// (vmcnt(0)): in the plane loop that would end the prefetch of the next chunk's plane values at the first barrier and make each
+// barrier wait for the acknowledgement of the previous chunk's stores.  No thread reads global memory another thread of the
+// workgroup wrote, so LDS ordering is all the loop needs.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Fixed point without conversion instructions: for |y| < 2^51 the significand field of the double (y + 1.5 * 2^52) is
+// 2^51 + round(y) (RNE), so the RAW BITS of such doubles can be summed as 64-bit integers (one v_lshl_add_u64 each) and
+// n * bits(1.5 * 2^52) subtracted at the end: what is left is the exact integer sum of the round(y).  y = addend * 2^(32-E)
+// with |addend| < |value| * 2^(E+1), so plane values are clamped to +-2^17 when they are staged.
+#define FIX_MAGIC 6755399441055744.0                        // 1.5 * 2^52
+#define FIX_MAGIC_BITS 0x4338000000000000ull                // its bit pattern
+#define FIX_VMAX 131072.0f                                  // 2^17
+
+#ifdef MOTIF_TRACE
+// phase clocks of the owner kernel (s_memtime), thread 0 of the first 2048 workgroups:
+// 0 scan | 1 list | 2 scale + buckets | 3 barrier after staging | 4 barrier after gather | 5 write | 6 (list length) | 7 staging | 8 gather loop
+__device__ long long g_sptrace[2048 * 12];
+__device__ long long g_sptrace2[64 * 16 * 12];     // absolute clocks of chunk 3, every wave of the first 64 workgroups
+extern "C" int motif_debug_splat_trace2(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sptrace2), sizeof(long long) * n); }
+extern "C" int motif_debug_splat_trace(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sptrace), sizeof(long long) * n); }
+#define SPH(i) do { const long long now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - tlast; tlast = now_; if (trace_k == 3) ts[i] = now_; } while (0)
+
+#else
+#define SPH(i)
+#endif
 
 // PRE = false: the 130 source planes of Ours.py:786-791 -> acc [.,133,Q].
 // PRE = true : the splat is linear in its sources and synth_net's first layer is linear in the normalised splat
@@ -209,15 +244,36 @@ __device__ __forceinline__ int cell_exponent(unsigned bits) {
 //   the 64 values  U[c] + G[c] + A[c]*p0 + B[c]*p1  with  U = (W0[:, 0:64] . imnet head) (HR, folded into the imnet
 //   kernel's head weights),  G = W0[:, 66:130] . feat_low (a 1x1 convolution at LR, gathered here),  A, B = W0[:, 64],
 //   W0[:, 65].  Half the planes to accumulate, write and re-read: acc [.,67,Q] = 64 sums | norm | max | count.
-template <bool PRE>
+//   GLR = false (PRE only): the caller's U already holds U + G (motif_siren_imnet_add_fwd adds the gathered LR term when it
+//   stores U, same rounding as the sum formed here), so a source costs ONE load per plane and a.feat_lr is not read.
+template <bool PRE, bool GLR>
 __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs a, int cap) {
+    static_assert(OT_CC == 4, "a staged source is one 16-byte vector");
+    static_assert(PRE || GLR, "the literal form always gathers the LR features");
+#ifdef MOTIF_TRACE
+    long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = __builtin_amdgcn_s_memtime();
+    const long long tstart = tlast;
+    long long ts[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int trace_k = -1;
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    unsigned long long* tile = (unsigned long long*)lds;            // [OT_CC][OT_TP] 32.32 fixed point
-    unsigned* tmaxb = (unsigned*)(tile + OT_CC * OT_TP);             // [OT_TP] float bits of max e^z*w (>= 0: unsigned order)
+    float* stage = lds;                                              // [2][OT_EB][OT_CC] value * e^z of the staged sources, two chunk buffers, 16 bytes
+                                                                     // per source (consecutive sources = consecutive banks)
+    float* oxy = stage + 2 * OT_EB * OT_CC;                          // [OT_EB][2] their target positions (batched form)
+    unsigned short* list = (unsigned short*)(oxy + OT_EB * 2);       // [cap] (direction << 15) | (region row << 8) | region column
+    float* bucket_w = oxy;                                           // [4 * OT_EB] single-batch form: corner weight of each bucket entry, over
+                                                                     // oxy + list (the list is dead once the entries are cached in registers)
+    unsigned* tmaxb = (unsigned*)(bucket_w + 4 * OT_EB);             // [OT_TP] float bits of max e^z*w (>= 0: unsigned order)
     unsigned* tcnt = tmaxb + OT_TP;                                  // [OT_TP] hit count
-    int* texp = (int*)(tcnt + OT_TP);                                // [OT_TP] per-cell scale exponent E
-    unsigned* list = (unsigned*)(texp + OT_TP);                      // [cap]
-    unsigned* segbase = list + cap;                                  // [192] hits per 64-source segment, then their prefix sums
+    unsigned* cfill = tcnt + OT_TP;                                  // [OT_TP] bucket counts / fill cursors of the current batch
+    unsigned* segbase = cfill + OT_TP;                               // [192] hits per 64-source segment, then their prefix sums
+    unsigned short* cstart = (unsigned short*)(segbase + 192);       // [OT_TP + 2] bucket starts of the current batch (< 4 * OT_EB)
+    unsigned short* bucket = cstart + OT_TP + 2;                     // [4 * OT_EB] (staged source << 2) | corner
+    float* abl = (float*)(bucket + 4 * OT_EB);                       // [128] PRE: a.ab (read through LDS: the compiler will not use scalar loads
+                                                                     // for a pointer it cannot prove unaliased with the stores, and every
+                                                                     // vector load of a uniform value waits for all loads in flight)
+    signed char* texp = (signed char*)(abl + 128);                   // [OT_TP] per-cell scale exponent E
     __shared__ unsigned count;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bn = blockIdx.z, b = bn / a.N, n = bn % a.N;
@@ -228,6 +284,7 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
     const long Q = (long)a.HH * a.WW, HWl = (long)a.H * a.W;
     if (tid == 0) count = 0;
     for (int i = tid; i < OT_TP; i += OT_THREADS) { tmaxb[i] = 0u; tcnt[i] = 0u; }
+    if (PRE && tid < 128) abl[tid] = a.ab[tid];
     __syncthreads();
 
     // ---- pass 1: compact the contributing sources of both directions
@@ -237,12 +294,12 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
     const int xiters = (RW + 63) >> 6;
     // The list is written in SCAN ORDER (direction, row, column), not in the order the waves happen to finish: ballot counts per
     // 64-source segment, one prefix sum, then every hit goes to its rank.  Consecutive entries are then consecutive sources of
-    // one row -- whose targets are consecutive accumulator cells for any smooth flow -- so the 64 lanes of an LDS-atomic instruction
-    // in pass 2 hit 64 consecutive 8-byte cells (bank-conflict free) instead of pieces of several rows (rocprofv3: 56 % of the LDS
-    // cycles of this kernel were bank conflicts with the append-as-you-go list).  Slot j = (row step, direction, segment) is a
-    // compile-time loop with unconditional, clamped loads.
+    // one row, so the plane loads of the staging step are coalesced.  Slot j = (row step, direction, segment) is a compile-time
+    // loop with unconditional, clamped loads.
     constexpr int NWV = OT_THREADS / 64, RSTEPS = (OT_H + 32 + NWV - 1) / NWV, XIT = (OT_W + 32 + 63) / 64, NJ = RSTEPS * 2 * XIT;
     static_assert(NJ <= 32 && 2 * (OT_H + 32) * XIT <= 192, "hit bits / segment scan sizes");
+    static_assert(OT_H + 32 <= 128 && OT_W + 32 <= 128, "list entry fields");
+    static_assert(OT_EB * 4 <= 65536 && OT_EB % 4 == 0 && OT_TP % 2 == 0, "bucket entries / starts are 16 bits: (staged source << 2) | corner");
     const unsigned long long lt = (1ull << lane) - 1ull;
     unsigned hitbits = 0;
 #pragma unroll
@@ -257,6 +314,7 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
         if (hit) hitbits |= 1u << j;
     }
     __syncthreads();
+    SPH(0);
     if (wave == 0) {
         const int nseg = 2 * RH * xiters;
         unsigned v[3], sum = 0;
@@ -277,108 +335,334 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
         const int row = wave + NWV * r;
         const bool hit = (hitbits >> j) & 1u;
         const unsigned long long m = __ballot(hit);
-        if (hit) list[segbase[(d * RH + row) * xiters + it] + (unsigned)__popcll(m & lt)] = ((unsigned)d << 16) | ((unsigned)row << 8) | (unsigned)(it * 64 + lane);
+        if (hit) list[segbase[(d * RH + row) * xiters + it] + (unsigned)__popcll(m & lt)] = (unsigned short)((d << 15) | (row << 8) | (it * 64 + lane));
     }
     __syncthreads();
+    SPH(1);
     const int cnt = (int)count;
 
-    // ---- scale pass: per cell max of e^z*weight (= the max plane before its init-1 clamp) and the hit count
-    for (int e = tid; e < cnt; e += OT_THREADS) {
+    // ---- scale pass: per cell max of e^z*weight (= the max plane before its init-1 clamp) and the hit count.
+    // The geometry of a thread's first OT_NCACHE list entries (entry = tid + i * OT_THREADS) stays in registers for everything
+    // below; longer lists (sinks) recompute theirs from the list.
+    // c_up / c_fp: the entry's element of plane 0 of the HR / LR source tensors -- plane c is a UNIFORM offset away, so a plane
+    // load costs one 64-bit add (per-lane 64-bit index products cost six vector instructions per load, two of them quarter rate)
+    struct Ent { int off; float ox, oy, e, p0, p1; const float* up; const float* fp; };
+    auto make_ent = [&](int e) -> Ent {
         const unsigned ent = list[e];
-        const int d = ent >> 16, y = ry0 + ((ent >> 8) & 255), x = rx0 + (ent & 255);
+        const int d = ent >> 15, y = ry0 + ((ent >> 8) & 127), x = rx0 + (ent & 255);
         const SrcGeom g = src_geom(a, (d * a.B + b) * a.N + n, x, y, true);
-        const int off = (g.y0 - (ty0 - 1)) * OT_TPW + (g.x0 - (tx0 - 1));
-        unsigned* tm = tmaxb + off;
-        atomicMax(tm, __float_as_uint(g.e * g.wnw));
-        atomicMax(tm + 1, __float_as_uint(g.e * g.wne));
-        atomicMax(tm + OT_TPW, __float_as_uint(g.e * g.wsw));
-        atomicMax(tm + OT_TPW + 1, __float_as_uint(g.e * g.wse));
-        unsigned* tn = tcnt + off;
+        Ent t;
+        t.off = (g.y0 - (ty0 - 1)) * OT_TPW + (g.x0 - (tx0 - 1));
+        t.ox = g.ox; t.oy = g.oy; t.e = g.e; t.p0 = g.p0; t.p1 = g.p1;
+        t.up = a.imnet_out + (long)(d * a.B + b) * 64 * Q + ((long)y * a.WW + x);
+        t.fp = GLR ? a.feat_lr + (long)(d * a.B + b) * 64 * HWl + ((long)a.iy[y] * a.W + a.ix[x]) : nullptr;
+        return t;
+    };
+    // Two forms of everything below.  SINGLE (cnt <= OT_EB, every tile of a smooth flow): one batch, buckets built once, all entries
+    // cached.  Otherwise (sinks): batches of OT_EB, buckets rebuilt per batch and chunk, entries recomputed from the list.
+    Ent ce[OT_NCACHE];
+    const int niter = (cnt + OT_THREADS - 1) / OT_THREADS;
+    const bool single = cnt <= OT_EB;
+    if (single) {
+#pragma unroll
+        for (int i = 0; i < OT_NCACHE; ++i) {
+            const int e = tid + i * OT_THREADS;
+            ce[i].off = 0; ce[i].ox = 0.f; ce[i].oy = 0.f; ce[i].e = 0.f; ce[i].p0 = 0.f; ce[i].p1 = 0.f; ce[i].up = a.imnet_out; ce[i].fp = GLR ? a.feat_lr : nullptr;
+            if (e < cnt) ce[i] = make_ent(e);
+        }
+    }
+    // f(entry, list index) for this thread's entries in [b0, b1)
+    auto for_entries = [&](auto single_tag, int b0, int b1, auto&& f) {
+        if constexpr (decltype(single_tag)::value) {
+#pragma unroll
+            for (int i = 0; i < OT_NCACHE; ++i) {
+                const int e = tid + i * OT_THREADS;
+                if (e < b1) f(ce[i], e);
+            }
+        } else {
+            for (int i = 0; i < niter; ++i) {
+                const int e = tid + i * OT_THREADS;
+                if (e >= b0 && e < b1) f(make_ent(e), e);
+            }
+        }
+    };
+    auto scale_entry = [&](const Ent& t, int) {
+        unsigned* tm = tmaxb + t.off;
+        atomicMax(tm, __float_as_uint(t.e * corner_weight(t.ox, t.oy, 0)));
+        atomicMax(tm + 1, __float_as_uint(t.e * corner_weight(t.ox, t.oy, 1)));
+        atomicMax(tm + OT_TPW, __float_as_uint(t.e * corner_weight(t.ox, t.oy, 2)));
+        atomicMax(tm + OT_TPW + 1, __float_as_uint(t.e * corner_weight(t.ox, t.oy, 3)));
+        unsigned* tn = tcnt + t.off;
         atomicAdd(tn, 1u);
         atomicAdd(tn + 1, 1u);
         atomicAdd(tn + OT_TPW, 1u);
         atomicAdd(tn + OT_TPW + 1, 1u);
-    }
+    };
+    if (single) for_entries(std::true_type{}, 0, cnt, scale_entry);
+    else for_entries(std::false_type{}, 0, cnt, scale_entry);
     __syncthreads();
-    for (int i = tid; i < OT_TP; i += OT_THREADS) texp[i] = cell_exponent(tmaxb[i]);
+    for (int i = tid; i < OT_TP; i += OT_THREADS) texp[i] = (signed char)min(cell_exponent(tmaxb[i]), 127);
+    __syncthreads();
 
-    // ---- pass 2: the feature planes in chunks of 8, then [remaining features, norm | max | count]
     constexpr int NPL = PRE ? 64 : 130, NCH = NPL / OT_CC, NREM = NPL - NCH * OT_CC;    // 130 = 16*8 + 2, 64 = 8*8 + 0
     float* abase = a.acc + (long)bn * (NPL + 3) * Q;
-    for (int k = 0; k <= NCH; ++k) {
-        const bool last = (k == NCH);
-        const int n64 = (last ? NREM + 1 : OT_CC) * OT_TP;
-        for (int i = tid; i < n64; i += OT_THREADS) tile[i] = 0ull;
-        __syncthreads();
-        for (int e = tid; e < cnt; e += OT_THREADS) {
-            const unsigned ent = list[e];
-            const int d = ent >> 16, y = ry0 + ((ent >> 8) & 255), x = rx0 + (ent & 255);
-            const int db = d * a.B + b, img = db * a.N + n;
-            const SrcGeom g = src_geom(a, img, x, y, true);
-            const int off = (g.y0 - (ty0 - 1)) * OT_TPW + (g.x0 - (tx0 - 1));
-            const int* te = texp + off;
-            // weight * 2^-E(cell): exact, so (v*e)*w' == ((v*e)*w) * 2^-E bit for bit
-            const float wnw = ldexpf(g.wnw, -te[0]), wne = ldexpf(g.wne, -te[1]);
-            const float wsw = ldexpf(g.wsw, -te[OT_TPW]), wse = ldexpf(g.wse, -te[OT_TPW + 1]);
-            const long p = (long)y * a.WW + x;
-            const long lr = (long)a.iy[y] * a.W + a.ix[x];
-            if (!last) {
-                float v[OT_CC];
+    // c is uniform (chunk index * 8 + unrolled plane)
+    auto plane_value = [&](int c, const Ent& t) -> float {
+        if constexpr (PRE) {
+            float u = t.up[(long)c * Q];
+            if constexpr (GLR) u = u + t.fp[(long)c * HWl];
+            return fmaf(abl[64 + c], t.p1, fmaf(abl[c], t.p0, u));
+        } else {
+            if (c < 64) return t.up[(long)c * Q];
+            if (c == 64) return t.p0;
+            if (c == 65) return t.p1;
+            return t.fp[(long)(c - 66) * HWl];
+        }
+    };
+    const int ly = tid >> 6, lx = tid & 63, mycell = (ly + 1) * OT_TPW + lx + 1;
+    const int Y = ty0 + ly, X = tx0 + lx;
+    const int myE = (int)texp[mycell];
+
+    auto planes = [&](auto single_tag) {
+        constexpr bool SINGLE = decltype(single_tag)::value;
+        // ---- buckets of one batch of list entries [b0, b1): (staged index, corner) pairs grouped by cell
+        auto build_buckets = [&](int b0, int b1) {
+            for (int i = tid; i < OT_TP; i += OT_THREADS) cfill[i] = 0u;
+            __syncthreads();
+            for_entries(single_tag, b0, b1, [&](const Ent& t, int) {
+                atomicAdd(cfill + t.off, 1u); atomicAdd(cfill + t.off + 1, 1u); atomicAdd(cfill + t.off + OT_TPW, 1u); atomicAdd(cfill + t.off + OT_TPW + 1, 1u);
+            });
+            __syncthreads();
+            if (wave == 0) {                                              // exclusive prefix sum over the OT_TP cells, 19 per lane
+                constexpr int PER = (OT_TP + 63) / 64;
+                unsigned sum = 0;
+#pragma unroll 1
+                for (int i = 0; i < PER; ++i) { const int c = lane * PER + i; sum += c < OT_TP ? cfill[c] : 0u; }
+                unsigned incl = sum;
 #pragma unroll
-                for (int cc = 0; cc < OT_CC; ++cc) {
-                    const int c = k * OT_CC + cc;
-                    if constexpr (PRE) {
-                        const float u = a.imnet_out[((long)db * 64 + c) * Q + p] + a.feat_lr[((long)db * 64 + c) * HWl + lr];
-                        v[cc] = fmaf(a.ab[64 + c], g.p1, fmaf(a.ab[c], g.p0, u));
-                    } else {
-                        if (c < 64) v[cc] = a.imnet_out[((long)db * 64 + c) * Q + p];
-                        else if (c == 64) v[cc] = g.p0;
-                        else if (c == 65) v[cc] = g.p1;
-                        else v[cc] = a.feat_lr[((long)db * 64 + (c - 66)) * HWl + lr];
+                for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+                unsigned run = incl - sum;
+#pragma unroll 1
+                for (int i = 0; i < PER; ++i) {
+                    const int c = lane * PER + i;
+                    if (c < OT_TP) { const unsigned v = cfill[c]; cstart[c] = (unsigned short)run; cfill[c] = 0u; run += v; }
+                }
+                if (lane == 63) cstart[OT_TP] = (unsigned short)incl;
+            }
+            __syncthreads();
+            for_entries(single_tag, b0, b1, [&](const Ent& t, int e) {
+                const unsigned le = (unsigned)(e - b0) << 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cell = t.off + (q & 1) + (q >> 1) * OT_TPW;
+                    const unsigned slot = cstart[cell] + atomicAdd(cfill + cell, 1u);
+                    bucket[slot] = (unsigned short)(le | (unsigned)q);
+                    if constexpr (SINGLE) bucket_w[slot] = corner_weight(t.ox, t.oy, q);
+                }
+                if constexpr (!SINGLE) { oxy[2 * (e - b0)] = t.ox; oxy[2 * (e - b0) + 1] = t.oy; }
+            });
+            __syncthreads();
+        };
+        if constexpr (SINGLE) build_buckets(0, cnt);
+        SPH(2);
+
+        // ---- the feature planes in chunks of OT_CC, then [remaining features, norm | max | count]
+        auto plane_store = [&](int c, float v) {                     // accumulator plane c of this thread's cell
+            float* o = abase + (long)c * Q + (long)Y * a.WW + X;
+            if (a.accumulate) v = *o + v;
+            // The store is hidden from the compiler's wait-count bookkeeping on purpose: gfx9 counts loads and stores in ONE counter
+            // (vmcnt) and they may complete out of order with respect to each other, so with a store pending every wait for a load
+            // becomes vmcnt(0) -- which also waits for the plane loads just issued for the chunk after next.  Uncounted stores can
+            // only make a wait for the k-th oldest load longer, never shorter (loads complete in order among themselves).
+            asm volatile("global_store_dword %0, %1, off" :: "v"(o), "v"(v) : "memory");
+        };
+        // gather: this thread's cell walks its bucket over the staged values in `buf`; raw bits of (addend * 2^(32-E) + 1.5 * 2^52)
+        // are summed as integers
+        auto gather = [&](const f32x4* buf, unsigned long long (&acci)[OT_CC], auto nst_tag) {
+            constexpr int nst = decltype(nst_tag)::value;
+            const double up_scale = __longlong_as_double((long long)(1023 + 32 - myE) << 52);      // 2^(32-E)
+            const int j0 = cstart[mycell], j1 = cstart[mycell + 1];
+            if (j0 >= j1) return;
+            // (a two-deep software pipeline of the LDS reads of this loop measured 7 % SLOWER: the four waves of a SIMD already cover them)
+            auto weight = [&](int j, unsigned be) -> float {
+                if constexpr (SINGLE) return bucket_w[j];
+                else return corner_weight(oxy[2 * (be >> 2)], oxy[2 * (be >> 2) + 1], be & 3);
+            };
+            for (int j = j0; j < j1; ++j) {
+                const unsigned be = bucket[j];
+                const float w = weight(j, be);
+                const f32x4 sv = buf[be >> 2];
+#pragma unroll
+                for (int cc = 0; cc < nst; ++cc) {
+                    const float x = sv[cc] * w;
+                    acci[cc] += (unsigned long long)__double_as_longlong(fma((double)x, up_scale, FIX_MAGIC));
+                }
+            }
+        };
+        const unsigned long long nadd = tcnt[mycell];                                              // addends per plane of this cell
+        auto finish = [&](unsigned long long v) -> float {                                         // one rounding: exact integer sum * 2^(E-32)
+            const double down_scale = __longlong_as_double((long long)(1023 - 32 + myE) << 52);
+            return (float)((double)(long long)(v - nadd * FIX_MAGIC_BITS) * down_scale);
+        };
+        const bool inside = Y < a.HH && X < a.WW;
+        auto write_last = [&](const unsigned long long (&acci)[OT_CC]) {
+            if (!inside) return;
+#pragma unroll
+            for (int cc = 0; cc < NREM + 1; ++cc) plane_store(NCH * OT_CC + cc, finish(acci[cc]));
+            float* om = abase + (long)(NCH * OT_CC + NREM + 1) * Q + (long)Y * a.WW + X;
+            float vm = fmaxf(1.0f, __uint_as_float(tmaxb[mycell]));                                 // max-splat output starts at ones (softsplat_max_cp.py:254)
+            if (a.accumulate) vm = fmaxf(*om, vm);
+            *om = vm;
+            plane_store(NCH * OT_CC + NREM + 2, (float)tcnt[mycell]);
+        };
+        f32x4* const sbuf = (f32x4*)stage;                                                         // two buffers of [OT_EB] x 4 planes
+
+        if constexpr (SINGLE) {
+            // Software pipeline over the chunks: the plane values of chunk k+2 are in flight (registers pvA / pvB alternate) while chunk
+            // k is gathered from one stage buffer and chunk k+1 is staged into the other; one barrier per chunk.  A dependent batch of
+            // these loads has a tail latency of several microseconds on the loaded chip (one DRAM page per plane and row), which is what
+            // the two-chunk distance is for.
+            constexpr int NLD = (PRE && GLR) ? 2 * OT_CC : OT_CC;
+            float pvA[OT_NCACHE][NLD], pvB[OT_NCACHE][NLD];
+            auto issue_loads = [&](int k, float (&pv)[OT_NCACHE][NLD]) {     // invalid entries read plane 0 of the tensors
+#pragma unroll
+                for (int i = 0; i < OT_NCACHE; ++i)
+#pragma unroll
+                    for (int cc = 0; cc < OT_CC; ++cc) {
+                        const int c = k * OT_CC + cc;                       // uniform
+                        if constexpr (PRE) {
+                            pv[i][cc] = ce[i].up[(long)c * Q];
+                            if constexpr (GLR) pv[i][OT_CC + cc] = ce[i].fp[(long)c * HWl];
+                        } else {
+                            pv[i][cc] = c < 64 ? ce[i].up[(long)c * Q] : c >= 66 ? ce[i].fp[(long)(c - 66) * HWl] : 0.f;
+                        }
+                    }
+            };
+            auto stage_chunk = [&](int k, const float (&pv)[OT_NCACHE][NLD], f32x4* buf) {
+#pragma unroll
+                for (int i = 0; i < OT_NCACHE; ++i) {
+                    const int e = tid + i * OT_THREADS;
+                    f32x4 v;
+#pragma unroll
+                    for (int cc = 0; cc < OT_CC; ++cc) {
+                        const int c = k * OT_CC + cc;
+                        float x;
+                        if constexpr (PRE) x = fmaf(abl[64 + c], ce[i].p1, fmaf(abl[c], ce[i].p0, GLR ? pv[i][cc] + pv[i][NLD - OT_CC + cc] : pv[i][cc]));
+                        else x = c == 64 ? ce[i].p0 : c == 65 ? ce[i].p1 : pv[i][cc];
+                        v[cc] = __builtin_amdgcn_fmed3f(x, -FIX_VMAX, FIX_VMAX) * ce[i].e;
+                    }
+                    if (e < cnt) buf[e] = v;
+                }
+            };
+            auto stage_last = [&](f32x4* buf) {                            // remaining feature planes (literal form: 128, 129) and the norm plane
+#pragma unroll
+                for (int i = 0; i < OT_NCACHE; ++i) {
+                    const int e = tid + i * OT_THREADS;
+                    if (e < cnt) {
+                        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int cc = 0; cc < NREM + 1; ++cc) {
+                            float x = 1.0f;
+                            if (cc < NREM) x = __builtin_amdgcn_fmed3f(ce[i].fp[(long)(62 + cc) * HWl], -FIX_VMAX, FIX_VMAX);
+                            v[cc] = x * ce[i].e;
+                        }
+                        buf[e] = v;
                     }
                 }
+            };
+            static_assert(NCH % 2 == 0 && NCH >= 4, "the pipeline is unrolled by two chunks");
+            issue_loads(0, pvA);
+            issue_loads(1, pvB);
+            stage_chunk(0, pvA, sbuf);
+            issue_loads(2, pvA);
+            lds_barrier();
+            SPH(3);
+            // one step: gather chunk k from buffer (k & 1), stage chunk k + 1 into the other, request chunk k + 3, store chunk k
+            auto step = [&](int k, float (&pvn)[OT_NCACHE][NLD]) {
+                unsigned long long acci[OT_CC];
 #pragma unroll
-                for (int cc = 0; cc < OT_CC; ++cc) {
-                    const float ve = v[cc] * g.e;
-                    unsigned long long* tc = tile + cc * OT_TP + off;
-                    add_fix(tc, ve * wnw);
-                    add_fix(tc + 1, ve * wne);
-                    add_fix(tc + OT_TPW, ve * wsw);
-                    add_fix(tc + OT_TPW + 1, ve * wse);
+                for (int cc = 0; cc < OT_CC; ++cc) acci[cc] = 0ull;
+                gather(sbuf + (k & 1) * OT_EB, acci, std::integral_constant<int, OT_CC>{});
+                SPH(8);
+                if (k + 1 < NCH) {
+                    stage_chunk(k + 1, pvn, sbuf + ((k + 1) & 1) * OT_EB);
+                    if (k + 3 < NCH) issue_loads(k + 3, pvn);
+                } else {
+                    stage_last(sbuf + ((k + 1) & 1) * OT_EB);
                 }
-            } else {
+                SPH(7);
+                if (inside) {
 #pragma unroll
-                for (int cc = 0; cc < NREM + 1; ++cc) {
-                    const float ve = (cc < NREM) ? a.feat_lr[((long)db * 64 + 62 + cc) * HWl + lr] * g.e : g.e;
-                    unsigned long long* tc = tile + cc * OT_TP + off;
-                    add_fix(tc, ve * wnw);
-                    add_fix(tc + 1, ve * wne);
-                    add_fix(tc + OT_TPW, ve * wsw);
-                    add_fix(tc + OT_TPW + 1, ve * wse);
+                    for (int cc = 0; cc < OT_CC; ++cc) plane_store(k * OT_CC + cc, finish(acci[cc]));
+                }
+                SPH(5);
+                lds_barrier();
+                SPH(4);
+            };
+            for (int k = 0; k < NCH; k += 2) {
+                step(k, pvB);
+                step(k + 1, pvA);
+            }
+            unsigned long long accl[OT_CC];
+#pragma unroll
+            for (int cc = 0; cc < OT_CC; ++cc) accl[cc] = 0ull;
+            gather(sbuf + (NCH & 1) * OT_EB, accl, std::integral_constant<int, NREM + 1>{});
+            SPH(9);
+            write_last(accl);
+            SPH(11);
+        } else {
+            // sinks: batches of OT_EB, buckets rebuilt per batch and chunk, plane values loaded where they are staged
+            const int nbatch = (cnt + OT_EB - 1) / OT_EB;
+            for (int k = 0; k <= NCH; ++k) {
+                unsigned long long acci[OT_CC];
+#pragma unroll
+                for (int cc = 0; cc < OT_CC; ++cc) acci[cc] = 0ull;
+                for (int bb = 0; bb < nbatch; ++bb) {
+                    const int b0 = bb * OT_EB, b1 = min(cnt, b0 + OT_EB);
+                    build_buckets(b0, b1);
+                    for_entries(single_tag, b0, b1, [&](const Ent& t, int e) {
+                        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int cc = 0; cc < OT_CC; ++cc) {
+                            float x = 1.0f;
+                            if (k < NCH) x = plane_value(k * OT_CC + cc, t);
+                            else if (cc < NREM) x = t.fp[(long)(62 + cc) * HWl];
+                            v[cc] = __builtin_amdgcn_fmed3f(x, -FIX_VMAX, FIX_VMAX) * t.e;
+                        }
+                        sbuf[e - b0] = v;
+                    });
+                    __syncthreads();
+                    if (k < NCH) gather(sbuf, acci, std::integral_constant<int, OT_CC>{});
+                    else gather(sbuf, acci, std::integral_constant<int, NREM + 1>{});
+                    __syncthreads();
+                }
+                if (k < NCH) {
+                    if (inside) {
+#pragma unroll
+                        for (int cc = 0; cc < OT_CC; ++cc) plane_store(k * OT_CC + cc, finish(acci[cc]));
+                    }
+                } else {
+                    write_last(acci);
                 }
             }
         }
-        __syncthreads();
-        const int nplanes = last ? NREM + 3 : OT_CC;
-        for (int i = tid; i < nplanes * OT_H * OT_W; i += OT_THREADS) {
-            const int cc = i >> 10, rem = i & 1023, ly = rem >> 6, lx = rem & 63;
-            const int Y = ty0 + ly, X = tx0 + lx;
-            if (Y >= a.HH || X >= a.WW) continue;
-            const int cell = (ly + 1) * OT_TPW + lx + 1;
-            float v;
-            if (!last || cc < NREM + 1) v = fix_to_float(tile[cc * OT_TP + cell], texp[cell]);
-            else if (cc == NREM + 1) v = fmaxf(1.0f, __uint_as_float(tmaxb[cell]));     // max-splat output starts at ones (softsplat_max_cp.py:254)
-            else v = (float)tcnt[cell];
-            float* o = abase + (long)(k * OT_CC + cc) * Q + (long)Y * a.WW + X;
-            if (a.accumulate) v = (last && cc == NREM + 1) ? fmaxf(*o, v) : *o + v;
-            *o = v;
-        }
-        __syncthreads();
+    };
+    if (single) planes(std::true_type{});
+    else planes(std::false_type{});
+#ifdef MOTIF_TRACE
+    const int blk = blockIdx.z * gridDim.x + blockIdx.x;
+    if (tid == 0 && blk < 2048) {
+        ph[6] = cnt;
+        ph[10] = __builtin_amdgcn_s_memtime() - tstart;
+        for (int i = 0; i < 12; ++i) g_sptrace[blk * 12 + i] = ph[i];
     }
+    if (lane == 0 && blk < 64)
+        for (int i = 0; i < 12; ++i) g_sptrace2[(blk * 16 + wave) * 12 + i] = ts[i];
+#endif
 }
 
 // far sources (footprint outside their own +-R neighbourhood): rare; global atomics, after the owner pass
-template <bool PRE>
+template <bool PRE, bool GLR>
 __global__ __launch_bounds__(256) void splat_far_kernel(MotifSplatArgs a, int tiles_x) {
     const int img = blockIdx.z;
     const int n = img % a.N, db = img / a.N, b = db % a.B;
@@ -405,7 +689,8 @@ __global__ __launch_bounds__(256) void splat_far_kernel(MotifSplatArgs a, int ti
     for (int c = 0; c < NPL; ++c) {
         float v;
         if constexpr (PRE) {
-            const float u = a.imnet_out[((long)db * 64 + c) * Q + p] + a.feat_lr[((long)db * 64 + c) * HWl + lr];
+            float u = a.imnet_out[((long)db * 64 + c) * Q + p];
+            if constexpr (GLR) u = u + a.feat_lr[((long)db * 64 + c) * HWl + lr];
             v = fmaf(a.ab[64 + c], p1, fmaf(a.ab[c], p0, u));
         } else {
             if (c < 64) v = a.imnet_out[((long)db * 64 + c) * Q + p];
@@ -420,18 +705,20 @@ __global__ __launch_bounds__(256) void splat_far_kernel(MotifSplatArgs a, int ti
     s.count(abase + (long)(NPL + 2) * Q, 1.0f);
 }
 
-template <bool PRE>
+template <bool PRE, bool GLR>
 static int launch_motif_splat(MotifSplatArgs a, void* stream) {
     const int cap = 2 * (OT_H + 2 * a.R) * (OT_W + 2 * a.R);
-    const size_t lds = (size_t)OT_CC * OT_TP * 8 + (size_t)3 * OT_TP * 4 + (size_t)cap * 4 + 192 * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)splat_owner_kernel<PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if ((size_t)OT_EB * 8 + (size_t)cap * 2 > (size_t)OT_EB * 16) return MOTIF_EINVAL;      // oxy + list lie inside the bucket_w region
+    const size_t lds = (size_t)OT_EB * 2 * OT_CC * 4 + (size_t)OT_EB * 16 + (size_t)(3 * OT_TP + 192) * 4 + (size_t)(OT_TP + 2) * 2 + (size_t)4 * OT_EB * 2
+                       + 128 * 4 + ((OT_TP + 3) & ~3);
+    hipError_t e = hipFuncSetAttribute((const void*)splat_owner_kernel<PRE, GLR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     dim3 grid(((a.WW + OT_W - 1) / OT_W) * ((a.HH + OT_H - 1) / OT_H), 1, a.B * a.N);
-    splat_owner_kernel<PRE><<<grid, OT_THREADS, lds, (hipStream_t)stream>>>(a, cap);
+    splat_owner_kernel<PRE, GLR><<<grid, OT_THREADS, lds, (hipStream_t)stream>>>(a, cap);
     MOTIF_LAUNCH_CHECK();
     const int tiles_x = (a.WW + 63) / 64, tiles_y = (a.HH + 3) / 4;
     dim3 grid2(tiles_x * tiles_y, 1, 2 * a.B * a.N);
-    splat_far_kernel<PRE><<<grid2, 256, 0, (hipStream_t)stream>>>(a, tiles_x);
+    splat_far_kernel<PRE, GLR><<<grid2, 256, 0, (hipStream_t)stream>>>(a, tiles_x);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }
@@ -442,16 +729,16 @@ extern "C" int motif_splat_motif_acc_fwd(const float* imnet_out, const float* pr
     if (!imnet_out || !pred || !feat_lr || !iy || !ix || !alpha || !acc) return MOTIF_EINVAL;
     if (B < 1 || N < 1 || H < 1 || W < 1 || HH < 1 || WW < 1 || row0 < 0) return MOTIF_EINVAL;
     MotifSplatArgs a{imnet_out, pred, feat_lr, nullptr, iy, ix, alpha, 20.0f, flow_scale, acc, B, N, H, W, HH, WW, 16, row0, accumulate ? 1 : 0};
-    return launch_motif_splat<false>(a, stream);
+    return launch_motif_splat<false, true>(a, stream);
 }
 
 extern "C" int motif_splat_motif_pre_fwd(const float* u_hr, const float* pred, const float* g_lr, const float* ab,
                                          const int32_t* iy, const int32_t* ix, const float* alpha, float flow_scale,
                                          float* acc, int B, int N, int H, int W, int HH, int WW, int row0, int accumulate, void* stream) {
-    if (!u_hr || !pred || !g_lr || !ab || !iy || !ix || !alpha || !acc) return MOTIF_EINVAL;
+    if (!u_hr || !pred || !ab || !iy || !ix || !alpha || !acc) return MOTIF_EINVAL;      // g_lr may be NULL: u_hr already holds U + G
     if (B < 1 || N < 1 || H < 1 || W < 1 || HH < 1 || WW < 1 || row0 < 0) return MOTIF_EINVAL;
     MotifSplatArgs a{u_hr, pred, g_lr, ab, iy, ix, alpha, 20.0f, flow_scale, acc, B, N, H, W, HH, WW, 16, row0, accumulate ? 1 : 0};
-    return launch_motif_splat<true>(a, stream);
+    return g_lr ? launch_motif_splat<true, true>(a, stream) : launch_motif_splat<true, false>(a, stream);
 }
 
 extern "C" int motif_splat_motif_fwd(const float* imnet_out, const float* pred, const float* feat_lr,

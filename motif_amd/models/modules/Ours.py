@@ -466,18 +466,22 @@ class LunaTokis(nn.Module):
         """imnet over the HR grid described by the tables (whole image or a row band); in the pre-contracted form its head
         already carries W0[:, 0:64]."""
         split = ops.get_siren_mma() == ops.MMA_BF16X3
+        add_lr = None
         if self._pc():
-            blob = self._pre_plan()["imnet_blob"]
+            # U + G: the imnet kernel adds the gathered LR term of the splat sources (W0[:, 66:130] . feature) when it stores U, so
+            # the splat reads one value per source and plane (motif_splat_motif_pre_fwd with g_lr = NULL)
+            blob, add_lr = self._pre_plan()["imnet_blob"], c["g_lr"]
         else:
             blob = self.imnet.packed_split(ops.SIREN_IMNET) if split else self.imnet.packed()
-        return ops.siren_imnet(blob, ops.conv2d(self.imnet.l0_plan(0, 64), c["feat01"]), iy, ix, rel_y, rel_x, HH, WW, pre=2 if split else 1)
+        return ops.siren_imnet(blob, ops.conv2d(self.imnet.l0_plan(0, 64), c["feat01"]), iy, ix, rel_y, rel_x, HH, WW, pre=2 if split else 1,
+                               add_lr=add_lr)
 
     def _splat_synth(self, c, imnet_out, pred, sl, iy, ix, times, B, N, H, HH, WW, synth_blob, synth_l0, pre, acc, accumulate, row0=0, finish=True):
         """fused splat of one direction pair (+ synth_net when `finish`); -> acc, frames"""
         if self._pc():
             pp = self._pre_plan()
-            acc = ops.splat_motif_pre(imnet_out, pred, c["g_lr"][sl], pp["ab"], iy, ix, self.alpha, HH_over_H(c, H), B, N, HH, WW,
-                                      acc=acc, row0=row0, accumulate=accumulate)
+            acc = ops.splat_motif_pre(imnet_out, pred, None, pp["ab"], iy, ix, self.alpha, HH_over_H(c, H), B, N, HH, WW,
+                                      acc=acc, row0=row0, accumulate=accumulate, lr_size=c["lr_size"])
             frames = ops.siren_synth_pre(pp["synth_blob"], acc, synth_l0, iy, ix, times, B, N, HH, WW) if finish else None
         else:
             acc = ops.splat_motif(imnet_out, pred, c["feat01"][sl], iy, ix, self.alpha, HH_over_H(c, H), B, N, HH, WW,
@@ -508,7 +512,7 @@ class LunaTokis(nn.Module):
         # evaluate it once per clip at LR resolution (1x1 convs), the HR kernels start from it (pre=1)
         flow_l0 = ops.conv2d(self.flow_imnet.l0_plan(0, 64), flow_feat)
         c = dict(flow_l0=flow_l0, flow=flow, psies=psies, flow_feat_in=flow_feat_in, feat=feat, feat01=feat_src,
-                 flow_feat=flow_feat, imnet_out=None, tables=(iy, ix, rel_y, rel_x), scale_y=HH / H)
+                 flow_feat=flow_feat, imnet_out=None, tables=(iy, ix, rel_y, rel_x), scale_y=HH / H, lr_size=(H, W))
         if self._pc():
             c["g_lr"] = ops.conv2d(self._pre_plan()["g_plan"], feat_src)
         if self.band is None:                                                   # band mode renders imnet per band
@@ -567,6 +571,7 @@ class LunaTokis(nn.Module):
         c = {k: tensors[k] for k in self.clip_cache_names()}
         c["tables"] = gather_tables(H, W, HH, WW, x.device)
         c["scale_y"] = HH / H
+        c["lr_size"] = (H, W)
         c["x"] = x
         self._cache, self._cache_key = c, self._clip_key(x, HH, WW, iters)
 

@@ -393,11 +393,20 @@ def siren_pack_split(kind, linears):
     return blob
 
 
-def siren_imnet(blob, feat_lr, iy, ix, rel_y, rel_x, HH, WW, pre=False):
+def siren_imnet(blob, feat_lr, iy, ix, rel_y, rel_x, HH, WW, pre=False, add_lr=None):
+    """add_lr [2B,64,H,W] (pre=2 only): gathered through the same tables and added to the output planes
+    (motif_siren_imnet_add_fwd) -- the G term of the pre-contracted splat."""
     lib = _lib.load()
     feat_lr = _c(feat_lr)
     b2, c, h, w = feat_lr.shape
     out = torch.empty(b2, 64, HH, WW, dtype=torch.float32, device=feat_lr.device)
+    if add_lr is not None:
+        add_lr = _c(add_lr)
+        if tuple(add_lr.shape) != (b2, 64, h, w):
+            raise RuntimeError("siren_imnet: add_lr must be [%d,64,%d,%d]" % (b2, h, w))
+        check(lib.motif_siren_imnet_add_fwd(_p(blob), _p(feat_lr), _p(add_lr), _p(iy), _p(ix), _p(rel_y), _p(rel_x), _p(out),
+                                            b2, h, w, HH, WW, int(pre), _stream()), "motif_siren_imnet_add_fwd")
+        return out
     check(lib.motif_siren_imnet_fwd(_p(blob), _p(feat_lr), _p(iy), _p(ix), _p(rel_y), _p(rel_x), _p(out),
                                     b2, h, w, HH, WW, int(pre), _stream()), "motif_siren_imnet_fwd")
     return out
@@ -480,18 +489,24 @@ def splat_motif(imnet_out, pred, feat_lr, iy, ix, alpha, flow_scale, B, N, HH, W
     return acc
 
 
-def splat_motif_pre(u_hr, pred, g_lr, ab, iy, ix, alpha, flow_scale, B, N, HH, WW, acc=None, row0=0, accumulate=False):
+def splat_motif_pre(u_hr, pred, g_lr, ab, iy, ix, alpha, flow_scale, B, N, HH, WW, acc=None, row0=0, accumulate=False, lr_size=None):
     """Pre-contracted fused soft-splat (motif_splat_motif_pre_fwd): acc [B*N,67,HH,WW] = 64 first-layer pre-activation
-    sums | norm | max | count."""
+    sums | norm | max | count.  g_lr=None: u_hr already holds U + G (siren_imnet(..., add_lr=g_lr) added the gathered LR term);
+    lr_size=(H, W) is then required (the gather tables' LR size)."""
     lib = _lib.load()
-    g_lr = _c(g_lr)
-    _, _, h, w = g_lr.shape
+    if g_lr is not None:
+        g_lr = _c(g_lr)
+        _, _, h, w = g_lr.shape
+    else:
+        if lr_size is None:
+            raise RuntimeError("splat_motif_pre(g_lr=None) needs lr_size=(H, W)")
+        h, w = lr_size
     if acc is None:
         if accumulate:
             raise RuntimeError("splat_motif_pre(accumulate=True) needs the accumulator of the first call")
         acc = torch.empty(B * N, 67, HH, WW, dtype=torch.float32, device=pred.device)
-    check(lib.motif_splat_motif_pre_fwd(_p(_c(u_hr)), _p(_c(pred)), _p(g_lr), _p(_c(ab)), _p(iy), _p(ix), _p(alpha.detach()), float(flow_scale),
-                                        _p(acc), B, N, h, w, HH, WW, int(row0), int(bool(accumulate)), _stream()), "motif_splat_motif_pre_fwd")
+    check(lib.motif_splat_motif_pre_fwd(_p(_c(u_hr)), _p(_c(pred)), _p(g_lr) if g_lr is not None else None, _p(_c(ab)), _p(iy), _p(ix), _p(alpha.detach()),
+                                        float(flow_scale), _p(acc), B, N, h, w, HH, WW, int(row0), int(bool(accumulate)), _stream()), "motif_splat_motif_pre_fwd")
     return acc
 
 

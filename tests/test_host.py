@@ -302,9 +302,10 @@ Siren.packed = Siren.packed_split = lambda self, *a: None
 def siren_flow(blob, flow_l0, iy, ix, rel_y, rel_x, times, N, HH, WW, pre=False):
     calls["flow"].append([float(v) for v in times.reshape(-1)])
     return times.reshape(1, -1, 1, 1, 1).expand(2, N, 3, HH, WW).reshape(2 * N, 3, HH, WW) * 0.01 + flow_l0.mean()
-def splat_motif_pre(u_hr, pred, g_lr, ab, iy, ix, alpha, flow_scale, B, N, HH, WW, acc=None, row0=0, accumulate=False):
+def splat_motif_pre(u_hr, pred, g_lr, ab, iy, ix, alpha, flow_scale, B, N, HH, WW, acc=None, row0=0, accumulate=False, lr_size=None):
     assert abs(flow_scale - 4.0) < 1e-9
-    return pred[:N, :1].repeat(1, 67, 1, 1) * 0 + u_hr.mean() + g_lr.mean()
+    assert g_lr is None and lr_size == (H, W)             # the LR term is added by the imnet kernel (siren_imnet(add_lr=...))
+    return pred[:N, :1].repeat(1, 67, 1, 1) * 0 + u_hr.mean()
 def siren_synth_pre(blob, acc, synth_l0, iy, ix, times, B, N, HH, WW):
     calls["synth"].append(N)
     t = times.reshape(B, N).permute(1, 0).reshape(N, B, 1, 1, 1)
@@ -321,6 +322,7 @@ def clip_stage(x, HH, WW, iters):                       # rank-dependent on purp
     c = {k: torch.full(v, base * (i + 1)) for i, (k, v) in enumerate(sorted(shp.items()))}
     c["tables"] = Ours.gather_tables(x.shape[3], x.shape[4], HH, WW, x.device)
     c["scale_y"] = HH / x.shape[3]
+    c["lr_size"] = (x.shape[3], x.shape[4])
     return c
 net._clip_stage = clip_stage
 x = torch.zeros(B, 4, 3, H, W)
@@ -333,7 +335,7 @@ assert calls["synth"] == ([3] if r == 0 else [2])                             # 
 assert calls["clip_stage"] == (1 if (os.environ["SHARE"] == "replicate" or r == 0) else 0)
 if r == 0:
     assert out.shape == (T, B, HH, WW, 3) and out.dtype == torch.uint8
-    const = 0.3 + 0.2 + 0.4                             # imnet_out + g_lr (acc) + synth_l0: rank 0's values on every rank
+    const = 0.3 + 0.4                                   # imnet_out (holds U + G) + synth_l0: rank 0's values on every rank
     want = [round((i / (T - 1) * 0.4 + const) * 100.0) for i in range(T)]
     assert [int(out[i, 0, 0, 0, 0]) for i in range(T)] == want, ([int(out[i, 0, 0, 0, 0]) for i in range(T)], want)
     print("TS_OK", os.environ["SHARE"])

@@ -222,10 +222,12 @@ def test_conv_split_multi_problem_and_views(keep_mma):
 
 
 @pytest.mark.parametrize("tile", [2, 3, 4], ids=["rows12", "rows8", "rows6x2"])
-@pytest.mark.parametrize("shape", [(3, 64, 64, 180, 320), (2, 64, 216, 90, 160), (5, 128, 64, 63, 100), (1, 48, 80, 19, 36)])
+@pytest.mark.parametrize("shape", [(3, 64, 64, 180, 320), (2, 64, 216, 90, 160), (5, 128, 64, 63, 100), (1, 48, 80, 19, 36), (2, 81, 96, 12, 16)])
 def test_conv_split2_persistent_tiles(shape, tile, keep_mma):
     """The round-3 conv kernel over MANY tiles per workgroup (persistent loop, next tile staged under the last chunk, ragged last
-    tile row / column, partial cout group, channel padding) against torch on the host and against the round-2 kernel."""
+    tile row / column, partial cout group, channel padding) against torch on the host and against the round-2 kernel.  The 81-channel
+    case (PWC-Net's first decoder layer) is one the kernel must REFUSE even when forced: its 16-channel staging loads would read past
+    the end of the tensor, so the launch has to come out of the round-2 kernel."""
     from motif_amd import ops
     from motif_amd.models.modules.layers import Conv2d
     n, cin, cout, H, W = shape
@@ -592,7 +594,17 @@ def test_siren_kernels_vs_torch(HW):
     close(o, r, 5e-6, 1e-4, "imnet")
     l0 = ops.conv2d(mine.imnet.l0_plan(0, 64), feat.to(dev()))          # LR partial of layer 0, then pre=1
     close(ops.siren_imnet(mine.imnet.packed(), l0, iy, ix, rel_y, rel_x, HH, WW, pre=True), r, 5e-6, 1e-4, "imnet pre")
-    close(ops.siren_imnet(mine.imnet.packed_split(ops.SIREN_IMNET), l0, iy, ix, rel_y, rel_x, HH, WW, pre=2), r, 5e-6, 1e-4, "imnet split")
+    osp = ops.siren_imnet(mine.imnet.packed_split(ops.SIREN_IMNET), l0, iy, ix, rel_y, rel_x, HH, WW, pre=2)
+    close(osp, r, 5e-6, 1e-4, "imnet split")
+    # motif_siren_imnet_add_fwd: + an LR tensor gathered through the same tables, one fp32 add after the head
+    g = rnd(*l0.shape, seed=77).to(dev())
+    h_, w_ = l0.shape[2], l0.shape[3]
+    idx = (iy.long()[:, None] * w_ + ix.long()[None, :]).reshape(-1)
+    want = osp + g.reshape(l0.shape[0], 64, h_ * w_)[:, :, idx].reshape(l0.shape[0], 64, HH, WW)
+    got = ops.siren_imnet(mine.imnet.packed_split(ops.SIREN_IMNET), l0, iy, ix, rel_y, rel_x, HH, WW, pre=2, add_lr=g)
+    assert torch.equal(got, want), "imnet + gathered LR term"
+    with pytest.raises(RuntimeError):
+        ops.siren_imnet(mine.imnet.packed(), l0, iy, ix, rel_y, rel_x, HH, WW, pre=True, add_lr=g)      # split engine only
     # flow_imnet
     times = torch.tensor([[0.0, 0.5], [0.25, 1.0]])
     g = gather(feat).repeat(1, N, 1, 1).reshape(2 * B * N, 64, HH, WW)
@@ -886,6 +898,11 @@ def test_precontracted_splat_and_synth_equal_the_literal_path():
     blob = ops.siren_pack_split(ops.SIREN_SYNTH_PRE, mine.synth_net.linears())
     o = ops.siren_synth_pre(blob, acc, l0, iy, ix, times.to(dev()), B, N, HH, WW)
     close(o, r, 2e-5, 1e-4, "synth on the pre-contracted accumulator")
+    # fused-source form (what LunaTokis runs): U already holds U + G -- the same fp32 sum the kernel forms from g_lr -- and g_lr = None
+    up = iy.long()[:, None] * W + ix.long()[None, :]
+    ug = u_hr.to(dev()) + g_lr.reshape(2 * B, 64, H * W)[:, :, up.reshape(-1)].reshape(2 * B, 64, HH, WW)
+    accf = ops.splat_motif_pre(ug, pred.to(dev()), None, ab, iy, ix, alpha.to(dev()), HH / H, B, N, HH, WW, lr_size=(H, W))
+    assert torch.equal(accf, acc), "U + G added upstream must give the accumulator of the g_lr form bit for bit"
     # accumulate form: the same two directions added twice == sums doubled, count doubled, max unchanged
     acc2 = ops.splat_motif_pre(*args, acc=acc.clone(), accumulate=True)
     assert torch.equal(acc2[:, 66], 2 * acc[:, 66]) and torch.equal(acc2[:, 65], acc[:, 65])
