@@ -41,15 +41,14 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[3]) {
     }
 }
 
-// sin(x), x = 30 * pre-activation already rounded to fp32 like the reference's `omega_0 * linear(x)`:
-// x / 2pi - rint(x / 2pi) through two FMAs (1/2pi = hi + lo), then the hardware sine (argument in revolutions).
-// Reduction error < 2e-7 for |x| <= 300 (same bound as sin_cw, one multiply less).
-__device__ __forceinline__ float sin_rev(float x) {
-    const float j = rintf(x * 0.15915494f);
-    float r = fmaf(x, 0.15915494f, -j);
-    r = fmaf(x, 6.4206382e-09f, r);
-    return __builtin_amdgcn_sinf(r);
-}
+// The sine layers compute sin(30 * (W h + b)) (SIREN.py:44-45, omega_0 = 30).  Here every layer that feeds a sine is packed with its
+// weights and bias multiplied by 30 / 2pi (in fp64, before the 3-way bf16 split), so its accumulator holds the argument IN TURNS and the
+// sine is  v_fract_f32 + v_sin_f32  (the hardware sine takes turns; fract is exact) instead of the six instructions of a scaled
+// Cody-Waite reduction.  Accuracy: the accumulator is an fp32 sum either way -- its rounding (|x| * 2^-24 in radians, x the argument)
+// is the error of the argument in both forms; what is dropped is only the reference's extra rounding of 30 * (W h + b).  Measured
+// against the oracle in tests/test_kernels_gpu.py (same tolerances as before) and end to end in bench.py's parity block.
+#define SIREN_TURNS 4.774648292756860                         // 30 / (2 pi)
+__device__ __forceinline__ float sin_turns(float t) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t)); }
 
 template <int MODE> struct SLayout {
     static constexpr bool SYN = MODE >= MODE_SYNTH;       // both synth forms: five linear layers, first layer streamed
@@ -137,7 +136,7 @@ __device__ __forceinline__ void split_layer(const u32x4 (&h)[TP][KS][3], f32x16 
     }
 }
 
-// h[p][2t+u] = split(sin(30 * acc[p][t][8u .. 8u+7]))
+// h[p][2t+u] = split(sin(2 pi * acc[p][t][8u .. 8u+7]))   (accumulators are in turns)
 template <int TP, int MT>
 __device__ __forceinline__ void sine_split(const f32x16 (&acc)[TP][MT], u32x4 (&h)[TP][2 * MT][3]) {
 #pragma unroll
@@ -148,7 +147,7 @@ __device__ __forceinline__ void sine_split(const f32x16 (&acc)[TP][MT], u32x4 (&
             for (int u = 0; u < 2; ++u) {
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = sin_rev(30.0f * acc[p][t][8 * u + e]);
+                for (int e = 0; e < 8; ++e) v[e] = sin_turns(acc[p][t][8 * u + e]);
                 split8(v, h[p][2 * t + u]);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -187,7 +186,7 @@ __device__ __forceinline__ void sine_f32(const f32x16 (&acc)[TP][MT], float (&h)
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                h[p][t * 16 + r] = sin_rev(30.0f * acc[p][t][r]);
+                h[p][t * 16 + r] = sin_turns(acc[p][t][r]);
             }
 }
 
@@ -199,7 +198,7 @@ __device__ __forceinline__ void ss_unit(int u, const f32x16 (&src)[TP][2], int k
 #pragma unroll
     for (int p = 0; p < TP; ++p) {
         if (u < 8) {
-            tmp[p][u] = sin_rev(30.0f * src[p][t][8 * uu + u]);
+            tmp[p][u] = sin_turns(src[p][t][8 * uu + u]);
         } else {
             const int q = u - 8;
             float x0 = tmp[p][2 * q], x1 = tmp[p][2 * q + 1];
@@ -330,7 +329,7 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[p][t][r] = gp[(long)(32 * t + (r & 3) + 8 * (r >> 2)) * HWl];
+                for (int r = 0; r < 16; ++r) acc[p][t][r] = gp[(long)(32 * t + (r & 3) + 8 * (r >> 2)) * HWl] * (float)SIREN_TURNS;   // LR partial -> turns
         }
     };
     const unsigned utotal = (unsigned)total, stride = gridDim.x * SIREN_WAVES;
@@ -389,7 +388,7 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
                 if (wz == 0.f) wz = 1.0f;                                 // Ours.py:813
                 const float cnt_ = (cnt == 0.f) ? 1.0f : cnt;             // Ours.py:828
                 const float wz_ = (wz == 1.0f) ? 0.f : wz;                // Ours.py:830
-                const float iw = 1.0f / wz;
+                const float iw = (1.0f / wz) * (float)SIREN_TURNS;          // the normalised sums enter the first layer's pre-activation: in turns
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -501,7 +500,7 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
                 auto valu_unit = [&](int u) {                // 32 sines, then 24 x (4 FMAs of one head output)
                     if (u < 32) {
 #pragma unroll
-                        for (int p = 0; p < TP; ++p) hc[p][u] = sin_rev(30.0f * acc2[c & 1][p][u >> 4][u & 15]);
+                        for (int p = 0; p < TP; ++p) hc[p][u] = sin_turns(acc2[c & 1][p][u >> 4][u & 15]);
                     } else if (u < 56) {
                         const int q = (u - 32) / 3, o = (u - 32) % 3;
                         const f32x4 w4 = *(const f32x4*)(headw + ((o * 32 + 8 * c + q) * 2 + hf) * 4);
@@ -678,6 +677,7 @@ __device__ void siren_split_pack_elem(const SplitPackArgs& pa, unsigned short* f
             k = 32 * tt + (e & 3) + 8 * (2 * u + (e >> 2)) + 4 * hfl;
         }
         float v = (k >= 0 && k < K && m < M) ? pa.w[layer][(long)m * K + k] : 0.f;
+        if (!(MODE == MODE_IMNET && layer == NL - 1)) v = (float)((double)v * SIREN_TURNS);     // every fragment layer but imnet's linear head feeds a sine
         unsigned short out = 0;
         for (int p = 0; p <= part; ++p) {
             const unsigned pk = pk_bf16(v, 0.f);
@@ -695,9 +695,9 @@ __device__ void siren_split_pack_elem(const SplitPackArgs& pa, unsigned short* f
         return m < M ? b[m] : 0.f;
     };
     float v;
-    if (j < L::O_B1B) v = bias_cd(pa.b[1], j - L::O_B1, 64);
-    else if (j < L::O_B2) v = bias_cd(pa.b[2], j - L::O_B1B, 64);
-    else if (j < L::O_HEAD) v = bias_cd(pa.b[NL - 2], j - L::O_B2, 256);
+    if (j < L::O_B1B) v = (float)((double)bias_cd(pa.b[1], j - L::O_B1, 64) * SIREN_TURNS);
+    else if (j < L::O_B2) v = (float)((double)bias_cd(pa.b[2], j - L::O_B1B, 64) * SIREN_TURNS);
+    else if (j < L::O_HEAD) v = (float)((double)bias_cd(pa.b[NL - 2], j - L::O_B2, 256) * SIREN_TURNS);
     else if (MODE == MODE_IMNET) v = bias_cd(pa.b[NL - 1], j - L::O_HEAD, 64);
     else {
         const int jj = j - L::O_HEAD;
