@@ -280,26 +280,26 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
                 int o, py, hx;
                 unit_of(r, ul, o, py, hx);
                 const int iy = iy0 + py, x = x0 + 20 * hx + 4 * xq;
-                doff[r][i] = (qd < NQ && iy >= 0 && iy < a.H && x >= 0 && x < a.W) ? iy * a.W + x + (8 * o + ch) * HW : -1;
+                // BYTE offset from the chunk's first plane; 2^31 = "outside the image": beyond any descriptor's range, so the load returns 0
+                doff[r][i] = (qd < NQ && iy >= 0 && iy < a.H && x >= 0 && x < a.W) ? (iy * a.W + x + (8 * o + ch) * HW) * 4 : (int)0x80000000;
             }
     };
     // the steps of staging one 16-channel chunk (this wave's units, ROUNDS rounds), callable one small step at a time
     f32x4 gq[NLD];
+    // Staging loads are BUFFER loads with a descriptor that ends where the chunk's channels end (the last channel of the group /
+    // of the source tensor): the hardware range check returns 0 for the channels beyond Cin of a ragged last chunk and for the
+    // quads outside the image (offset 2^31) -- no per-lane masking, and nothing is read past the end of the tensor.
     auto st_load = [&](int r, int i, int c0) {           // global -> registers: 4 pixels of one channel
         const int gch0 = st_g * a.Cin_g + c0;
-        const float* base = (gch0 < a.C0) ? in0n + (long)gch0 * HW : in1n + (long)(gch0 - a.C0) * HW;
-        gq[i] = *(const f32x4*)(base + (doff[r][i] >= 0 ? doff[r][i] : 0));
+        const bool first = gch0 < a.C0;
+        const float* base = first ? in0n + (long)gch0 * HW : in1n + (long)(gch0 - a.C0) * HW;
+        const int nch = (first && in1n) ? a.C0 - c0 : a.Cin_g - c0;           // channels from c0 to the end of the group / of the first source
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nch * HW * 4, 0x00020000);
+        gq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, doff[r][i], 0, 0));
     };
-    auto st_park = [&](int r, int i, int c0) {           // zero what lies outside the image / beyond the last channel, park in LDS
+    auto st_park = [&](int r, int i, int c0) {           // park in LDS (zeros already in place)
         const int qd = i * 64 + lane;
-        const int ul = qd / 40, ch = (qd - ul * 40) / 5;
-        int o, py, hx;
-        unit_of(r, ul, o, py, hx);
-        const bool ok = doff[r][i] >= 0 && c0 + 8 * o + ch < a.Cin_g;
-        f32x4 v = gq[i];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
-        if (NLD * 64 == NQ || qd < NQ) *(f32x4*)(land + qd) = v;
+        if (NLD * 64 == NQ || qd < NQ) *(f32x4*)(land + qd) = gq[i];
     };
     float sv[8];
     u32x4 sparts[NP];
@@ -477,9 +477,7 @@ bool motif_conv_split2_eligible(const MotifConvDesc* d, const ConvArgs& a, int P
     const long HW = (long)d->H * d->W;
     if (HW * 64 >= 0x7fffffffL) return false;
     const int Cout_g = d->Cout / d->groups;
-    // the staging loads fetch whole 16-channel chunks and zero the channels beyond Cin afterwards: with a ragged last chunk they would read
-    // up to 15 planes past the end of the input tensor (PWC-Net's 81 / 209 / ... channel stacks, RAFT's 242) -- those layers stay on conv_split.hip
-    if (((d->C0 + d->C1) / d->groups) % 16) return false;
+    if ((long)((d->C0 + d->C1) / d->groups) * HW * 4 >= 0x7fffffffL) return false;       // byte offsets of the staging buffer loads
     if (d->act_split > 0 && ((d->act_split & 7) || (d->groups > 1 && (Cout_g & 7)))) return false;
     if (d->C1 > 0 && (d->groups != 1 || d->C0 % 16)) return false;
     for (int i = 0; i < P; ++i) {

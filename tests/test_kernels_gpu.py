@@ -226,8 +226,8 @@ def test_conv_split_multi_problem_and_views(keep_mma):
 def test_conv_split2_persistent_tiles(shape, tile, keep_mma):
     """The round-3 conv kernel over MANY tiles per workgroup (persistent loop, next tile staged under the last chunk, ragged last
     tile row / column, partial cout group, channel padding) against torch on the host and against the round-2 kernel.  The 81-channel
-    case (PWC-Net's first decoder layer) is one the kernel must REFUSE even when forced: its 16-channel staging loads would read past
-    the end of the tensor, so the launch has to come out of the round-2 kernel."""
+    case (PWC-Net's first decoder layer) has a ragged last 16-channel chunk at the very end of the tensor: the staging loads are
+    range-checked buffer loads, so the 15 missing planes read as zeros instead of reading (and once faulting) past the allocation."""
     from motif_amd import ops
     from motif_amd.models.modules.layers import Conv2d
     n, cin, cout, H, W = shape
