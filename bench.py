@@ -304,7 +304,8 @@ def cpu_baseline_and_parity(times, model, mma, lr=(180, 320), scale=4):
             "c1": {"value": 3 * 128 * 128 / dt1, "unit": "HR px/s",
                    "sample": "BASELINE configs[0]: LR 64x64 -> 128x128 (x2 spatial, x2 temporal = 3 timestamps), %.1f s" % dt1}}
     data = {"LQs": sample["LQs"].cuda(), "GT": sample["GT"][:, :1].cuda(), "time": [t.cuda() for t in sample["time"]], "scale": sample["scale"]}
-    parity = {"clip": "c2 cropped to LR %dx%d, all %d timestamps" % (h, w, times), "tolerance": "PSNR >= 60 dB, flow L-inf <= 2e-3 (tests/test_model_gpu.py)"}
+    parity = {"clip": "c2 cropped to LR %dx%d, all %d timestamps" % (h, w, times), "tolerance": "PSNR >= 60 dB, flow L-inf <= 2e-3 (tests/test_model_gpu.py); the frame L-inf is reported, not gated: "
+                                                                                                       "isolated pixels where a splat target coordinate floors to the other side of an integer"}
     try:
         for mode in ("bf16x3", "fp32"):
             ops.set_mma(mode)
