@@ -313,8 +313,10 @@ def cpu_baseline_and_parity(times, model, mma, lr=(180, 320), scale=4):
             model.test()
             out = model.fake_H.float().cpu()
             mse = float(((out.double() - ref.double()) ** 2).mean())
+            ad = (out - ref).abs()
             parity[mode] = {"psnr_vs_oracle": 99.0 if mse == 0 else round(10 * np.log10(1.0 / mse), 2),
-                            "linf_vs_oracle": float((out - ref).abs().max()),
+                            "linf_vs_oracle": float(ad.max()),
+                            "values_over_1e-4": int((ad > 1e-4).sum()), "values_over_1e-3": int((ad > 1e-3).sum()), "values": int(ad.numel()),
                             "linf_flow": float((model.flow.float().cpu() - rflow).abs().max())}
     finally:
         ops.set_mma(mma)
