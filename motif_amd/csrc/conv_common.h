@@ -216,3 +216,6 @@ bool motif_conv_split_eligible(const MotifConvDesc* d);
 long motif_conv_split_packed_floats(const MotifConvDesc* d);
 int motif_conv_split_pack(const MotifConvDesc* d, const float* weight, float* packed, hipStream_t s);
 int motif_conv_split_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s);
+// conv_direct.hip: narrow layers (<= 32 couts, 1x1 / 3x3) on large maps, vector ALU, reads conv_igemm's packed weights
+bool motif_conv_direct_eligible(const MotifConvDesc* d, const ConvArgs& a, int P);
+int motif_conv_direct_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s);

@@ -1,0 +1,170 @@
+// Bandwidth-shaped convolution for the NARROW layers on large maps (RAFT-small's bottleneck blocks at half resolution: 32 -> 8,
+// 8 -> 8 (3x3), 32 -> 16 channels at 360x640): a few hundred MACs per pixel against 150-300 bytes of traffic per pixel.
+// In the MFMA engine (conv_igemm.hip) such a layer fills 8 of the 32 rows of a matrix tile and spends its time in the
+// load -> LDS -> barrier -> MFMA -> store latency of one block after the other (37-55 us per launch against 6-20 us of HBM time).
+// Here a thread owns FOUR consecutive output pixels and up to 16 couts: per input channel it loads the pixels it needs with
+// 16-byte accesses (the 3x3 halo columns with two dword loads), the weights of that channel are wave-uniform (scalar loads from
+// the packed block conv_igemm.hip already uses: [k = (channel, tap)][32 couts], zero padded), and the whole layer is
+// COUT * Cin * K * K fused multiply-adds per pixel on the vector ALU with nothing but occupancy between a load and its use.
+// fp32 multiply-add in (channel, tap) order: the same arithmetic class as the fp32 MFMA engine (not the same summation order).
+#include "conv_common.h"
+#include <type_traits>
+
+namespace {
+template <int ACT> __device__ __forceinline__ float actd(float v) { return act_c<ACT>(v); }
+
+__device__ __forceinline__ float act_any(float v, int ac) {          // ac is wave-uniform
+    if (ac == MOTIF_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ac == MOTIF_ACT_LRELU) return v > 0.f ? v : 0.1f * v;
+    if (ac == MOTIF_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    if (ac == MOTIF_ACT_TANH) return tanhf(v);
+    return v;
+}
+}  // namespace
+
+// NCO = couts per thread (8 or 16), K = 1 or 3 (pad K/2, stride 1).  grid = (ceil(W/4 * H / 256), cout slices of NCO, N * P)
+template <int NCO, int K>
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
+    const int pz = blockIdx.z / a.N, n = blockIdx.z - pz * a.N;
+    const int W4 = a.W >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;            // quad index in the image
+    if (q >= W4 * a.H) return;
+    const int y = q / W4, x = (q - y * W4) * 4;
+    const int co0 = blockIdx.y * NCO;
+    const long HW = (long)a.H * a.W;
+    const float* in0n = a.in0[pz] + (long)n * a.in0_bs[pz];
+    const float* in1n = a.in1[pz] ? a.in1[pz] + (long)n * a.in1_bs[pz] : nullptr;
+    // [Kpad][32]: row ((c >> 1) * T + t) * 2 + (c & 1), 32 couts (Cout <= 32: one group).  Read through the constant address space:
+    // the indices are wave-uniform, and only a pointer the compiler knows to be read-only becomes scalar loads (s_load_dwordx8).
+    typedef const __attribute__((address_space(4))) float* cptr;
+    cptr wp = (cptr)a.wp[pz];
+    constexpr int T = K * K;
+
+    f32x4 acc[NCO];
+#pragma unroll
+    for (int o = 0; o < NCO; ++o) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int Cin = a.Cin_g;
+    auto plane_of = [&](int c) { return c < a.C0 ? in0n + (long)c * HW : in1n + (long)(c - a.C0) * HW; };
+    auto wrow_of = [&](int c) { return wp + (long)(((c >> 1) * T) * 2 + (c & 1)) * 32 + co0; };       // tap t: + t * 64
+    // channels in groups of CG: all of a group's loads are requested before the first multiply (a loop over single channels keeps
+    // ONE load in flight per thread -- the trip count is a run-time value, the compiler will not pipeline it)
+    constexpr int CG = K == 1 ? 8 : 2;
+    auto group = [&](int c0, auto n_tag) {
+        constexpr int NG = decltype(n_tag)::value;
+        if constexpr (K == 1) {
+            f32x4 v[NG];
+#pragma unroll
+            for (int i = 0; i < NG; ++i) v[i] = *(const f32x4*)(plane_of(c0 + i) + (long)y * a.W + x);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                cptr wrow = wrow_of(c0 + i);
+#pragma unroll
+                for (int o = 0; o < NCO; ++o) {
+                    const float w = wrow[o];
+                    acc[o] += v[i] * w;
+                }
+            }
+        } else {
+            // rows y-1 .. y+1, columns x-1 .. x+4 (zero outside the image)
+            f32x4 m[NG][3];
+            float l[NG][3], rr[NG][3];
+#pragma unroll
+            for (int i = 0; i < NG; ++i)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int yy = y + dy - 1;
+                    const bool rowok = yy >= 0 && yy < a.H;
+                    const float* rp = plane_of(c0 + i) + (long)(rowok ? yy : y) * a.W + x;
+                    m[i][dy] = *(const f32x4*)rp;
+                    l[i][dy] = rp[x > 0 ? -1 : 0];
+                    rr[i][dy] = rp[x + 4 < a.W ? 4 : 3];
+                }
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                cptr wrow = wrow_of(c0 + i);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int yy = y + dy - 1;
+                    const bool rowok = yy >= 0 && yy < a.H;
+                    float r[6];
+                    r[0] = (rowok && x > 0) ? l[i][dy] : 0.f; r[5] = (rowok && x + 4 < a.W) ? rr[i][dy] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[1 + e] = rowok ? m[i][dy][e] : 0.f;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        cptr wt = wrow + (dy * 3 + dx) * 64;
+#pragma unroll
+                        for (int o = 0; o < NCO; ++o) {
+                            const float w = wt[o];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(r[dx + e], w, acc[o][e]);
+                        }
+                    }
+                }
+            }
+        }
+    };
+    int c = 0;
+    for (; c + CG <= Cin; c += CG) group(c, std::integral_constant<int, CG>{});
+    for (; c < Cin; ++c) group(c, std::integral_constant<int, 1>{});
+
+    const float* bias = a.bias[pz];
+    const float* resn = a.res_mode ? a.res[pz] + (long)n * a.res_bs[pz] : nullptr;
+    float* outn = a.out[pz] + (long)n * a.out_bs[pz];
+    const int rm = a.res_mode;
+    const long pix = (long)y * a.W + x;
+#pragma unroll
+    for (int o = 0; o < NCO; ++o) {
+        const int co = co0 + o;
+        if (co >= a.Cout) break;
+        const int ac = (a.act_split > 0 && co >= a.act_split) ? a.act2 : a.act;
+        const float b = bias ? bias[co] : 0.f;
+        f32x4 v = acc[o] + b;
+        f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rm) rv = *(const f32x4*)(resn + (long)co * HW + pix);
+        if (rm == 1) v += rv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_any(v[e], ac);
+        if (rm == 2) v += rv;
+        else if (rm == 3) {
+            v += rv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        } else if (rm == 4) v *= rv;
+        *(f32x4*)(outn + (long)co * HW + pix) = v;
+    }
+}
+
+// ---- host side (called from conv_igemm.hip's forward entry; the packed weights are conv_igemm's) -------------------------
+// Decided per launch (map size and alignment matter), never at pack time: both kernels read the same packed block.
+bool motif_conv_direct_eligible(const MotifConvDesc* d, const ConvArgs& a, int P) {
+    if (motif_opt(MOTIF_OPT_CONV_NODIRECT)) return false;
+    if (d->groups != 1 || d->stride != 1 || d->dil != 1 || d->KH != d->KW || (d->KH != 1 && d->KH != 3) || d->pad != d->KH / 2) return false;
+    if (d->KH == 3 && d->pad_mode != 0) return false;
+    const int Cin = d->C0 + d->C1;
+    if (d->Cout > 16 || Cin > 64 || (d->W & 3)) return false;               // measured on the 360x640 layers: 32->8 38 -> 22 us, 8->8 3x3 33 -> 24,
+                                                                             // 32->16 40 -> 29; 8->32 (store bound, two cout slices) 27 -> 31: not taken
+    if ((long)Cin * d->Cout * d->KH * d->KW > 4096) return false;            // MACs per pixel: beyond this the matrix engine wins
+    if ((long)d->N * P * d->H * d->W < 131072) return false;                 // small maps: the MFMA engine's blocks fill the chip anyway
+    for (int i = 0; i < P; ++i) {
+        unsigned long long bits = (unsigned long long)a.in0[i] | (unsigned long long)a.out[i] | (unsigned long long)a.in1[i] | (unsigned long long)a.res[i];
+        if (bits & 15) return false;
+        if ((a.in0_bs[i] | a.out_bs[i] | (a.in1[i] ? a.in1_bs[i] : 0) | (a.res[i] ? a.res_bs[i] : 0)) & 3) return false;
+    }
+    return true;
+}
+
+int motif_conv_direct_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s) {
+    a.Ho = d->H; a.Wo = d->W; a.Cin_g = d->C0 + d->C1; a.Cout_g = d->Cout;
+    const long quads = (long)(d->W >> 2) * d->H;
+    const int nco = d->Cout <= 16 ? 8 : 16;
+    dim3 grid((unsigned)((quads + 255) / 256), (d->Cout + nco - 1) / nco, d->N * P);
+    if (d->KH == 1) {
+        if (nco == 8) conv_direct_kernel<8, 1><<<grid, 256, 0, s>>>(a); else conv_direct_kernel<16, 1><<<grid, 256, 0, s>>>(a);
+    } else {
+        if (nco == 8) conv_direct_kernel<8, 3><<<grid, 256, 0, s>>>(a); else conv_direct_kernel<16, 3><<<grid, 256, 0, s>>>(a);
+    }
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}

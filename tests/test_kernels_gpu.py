@@ -198,6 +198,55 @@ def test_conv_split_engine_is_fp32_equivalent(case, keep_mma):
     assert 1e-4 * scale < err[ops.MMA_BF16] < 3e-2 * scale, err      # really ran in bf16
 
 
+DIRECT_CASES = [  # cin, cout, k, H, W, N, two-source split, act, res_mode, act_split
+    (32, 8, 1, 360, 640, 2, 0, "relu", 0, 0),         # RAFT-small bottleneck conv1 at half resolution
+    (8, 8, 3, 360, 640, 2, 0, "relu", 0, 0),          # conv2 (3x3): image borders, halo columns
+    (8, 16, 1, 360, 640, 2, 0, "none", 2, 0),         # two cout slices of 8, residual after
+    (32, 16, 1, 200, 332, 2, 16, "lrelu", 1, 0),      # two-source input, residual before the activation
+    (5, 12, 3, 190, 364, 2, 0, "tanh", 3, 8),         # odd channel count (zero partner channel in the packed block), partial cout slice, split activation
+    (16, 24, 3, 96, 96, 15, 0, "sigmoid", 4, 0),      # many small images, multiplicative residual
+]
+
+
+@pytest.mark.parametrize("case", DIRECT_CASES)
+def test_conv_direct_narrow_layers_match_the_mfma_engine_and_torch(case):
+    """conv_direct.hip (narrow layers on large maps: four pixels x <= 16 couts per thread, scalar-loaded weights from the block
+    conv_igemm packs) against an fp64 reference and against the MFMA engine on the same launch (option conv_nodirect)."""
+    from motif_amd import ops
+    from motif_amd.models.modules.layers import Conv2d
+    cin, cout, k, H, W, N, c0, actn, rm, asplit = case
+    acts = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "tanh": ops.ACT_TANH, "sigmoid": ops.ACT_SIGMOID}
+    fact = {"none": lambda v: v, "relu": F.relu, "lrelu": lambda v: F.leaky_relu(v, 0.1), "tanh": torch.tanh, "sigmoid": torch.sigmoid}[actn]
+    m = Conv2d(cin, cout, k, 1, k // 2)
+    with torch.no_grad():
+        m.weight.copy_(rnd(*m.weight.shape, seed=1, scale=1.0 / math.sqrt(cin * k * k)))
+        m.bias.copy_(rnd(cout, seed=2, scale=0.1))
+    x, res = rnd(N, cin, H, W, seed=3), rnd(N, cout, H, W, seed=4)
+    y = F.conv2d(x.double(), m.weight.double(), m.bias.double(), 1, k // 2)
+    r = res.double()
+    if rm == 1: y = y + r
+    y = torch.cat([fact(y[:, :asplit]), F.relu(y[:, asplit:])], 1) if asplit else fact(y)
+    if rm == 2: y = y + r
+    elif rm == 3: y = F.relu(y + r)
+    elif rm == 4: y = y * r
+    m = m.to(dev())
+    xd, rd = x.to(dev()), res.to(dev())
+    args = (xd[:, :c0].contiguous(), xd[:, c0:].contiguous()) if c0 else (xd, None)
+    kw = dict(act=acts[actn], res=rd if rm else None, res_mode=rm)
+    if asplit: kw.update(act2=ops.ACT_RELU, act_split=asplit)
+    scale = float(y.abs().max())
+    try:
+        ops.set_option("conv_nodirect", 1)
+        mf = m(*args, **kw).double().cpu()
+        ops.set_option("conv_nodirect", 0)
+        di = m(*args, **kw).double().cpu()
+    finally:
+        ops.set_option("conv_nodirect", 0)
+    assert float((mf - y).abs().max()) < 2e-6 * scale
+    assert float((di - y).abs().max()) < 2e-6 * scale
+    assert float((di - mf).abs().max()) < 2e-6 * scale
+
+
 def test_conv_split_multi_problem_and_views(keep_mma):
     from motif_amd import ops
     from motif_amd.models.modules.layers import Conv2d
