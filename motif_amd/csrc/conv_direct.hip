@@ -136,6 +136,122 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
     }
 }
 
+// Deep-K, tiny-Cout form (RAFT's flow head: 128 -> 2 channels, 3x3): the matrix engine spends a 32-row tile on 2 couts and is bound
+// by its k-loop (52 us for 0.27 GFLOP).  Here the input channels are cut into NS slices, one per wave of the workgroup: a thread owns
+// four pixels x NCO couts over its slice's channels, the NS partial sums meet in LDS and wave 0 adds them in slice order (fixed order:
+// deterministic), then bias / activation / residual / store as above.
+template <int NCO, int K, int NS>
+__global__ __launch_bounds__(64 * NS) void conv_direct_deep_kernel(ConvArgs a) {
+    __shared__ f32x4 red[NS][NCO][64];
+    const int pz = blockIdx.z / a.N, n = blockIdx.z - pz * a.N;
+    const int W4 = a.W >> 2, nquads = W4 * a.H;
+    const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = blockIdx.x * 64 + lane;
+    const bool live = q < nquads;
+    const int qc = live ? q : nquads - 1;
+    const int y = qc / W4, x = (qc - y * W4) * 4;
+    const long HW = (long)a.H * a.W;
+    const float* in0n = a.in0[pz] + (long)n * a.in0_bs[pz];
+    const float* in1n = a.in1[pz] ? a.in1[pz] + (long)n * a.in1_bs[pz] : nullptr;
+    typedef const __attribute__((address_space(4))) float* cptr;
+    cptr wp = (cptr)a.wp[pz];
+    constexpr int T = K * K;
+    const int Cin = a.Cin_g;
+    const int per = ((Cin + NS - 1) / NS + 1) & ~1;                  // channels per slice, even
+    const int cbeg = slice * per, cend = min(Cin, cbeg + per);
+
+    f32x4 acc[NCO];
+#pragma unroll
+    for (int o = 0; o < NCO; ++o) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto plane_of = [&](int c) { return c < a.C0 ? in0n + (long)c * HW : in1n + (long)(c - a.C0) * HW; };
+    auto wrow_of = [&](int c) { return wp + (long)(((c >> 1) * T) * 2 + (c & 1)) * 32; };
+    constexpr int CG = K == 1 ? 8 : 2;
+    auto group = [&](int c0, auto n_tag) {
+        constexpr int NG = decltype(n_tag)::value;
+        if constexpr (K == 1) {
+            f32x4 v[NG];
+#pragma unroll
+            for (int i = 0; i < NG; ++i) v[i] = *(const f32x4*)(plane_of(c0 + i) + (long)y * a.W + x);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                cptr wrow = wrow_of(c0 + i);
+#pragma unroll
+                for (int o = 0; o < NCO; ++o) acc[o] += v[i] * wrow[o];
+            }
+        } else {
+            f32x4 m[NG][3];
+            float l[NG][3], rr[NG][3];
+#pragma unroll
+            for (int i = 0; i < NG; ++i)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int yy = y + dy - 1;
+                    const bool rowok = yy >= 0 && yy < a.H;
+                    const float* rp = plane_of(c0 + i) + (long)(rowok ? yy : y) * a.W + x;
+                    m[i][dy] = *(const f32x4*)rp;
+                    l[i][dy] = rp[x > 0 ? -1 : 0];
+                    rr[i][dy] = rp[x + 4 < a.W ? 4 : 3];
+                }
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                cptr wrow = wrow_of(c0 + i);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int yy = y + dy - 1;
+                    const bool rowok = yy >= 0 && yy < a.H;
+                    float r[6];
+                    r[0] = (rowok && x > 0) ? l[i][dy] : 0.f; r[5] = (rowok && x + 4 < a.W) ? rr[i][dy] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[1 + e] = rowok ? m[i][dy][e] : 0.f;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        cptr wt = wrow + (dy * 3 + dx) * 64;
+#pragma unroll
+                        for (int o = 0; o < NCO; ++o) {
+                            const float w = wt[o];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(r[dx + e], w, acc[o][e]);
+                        }
+                    }
+                }
+            }
+        }
+    };
+    int c = cbeg;
+    for (; c + CG <= cend; c += CG) group(c, std::integral_constant<int, CG>{});
+    for (; c < cend; ++c) group(c, std::integral_constant<int, 1>{});
+#pragma unroll
+    for (int o = 0; o < NCO; ++o) red[slice][o][lane] = acc[o];
+    __syncthreads();
+    if (slice != 0 || !live) return;
+    const float* bias = a.bias[pz];
+    const float* resn = a.res_mode ? a.res[pz] + (long)n * a.res_bs[pz] : nullptr;
+    float* outn = a.out[pz] + (long)n * a.out_bs[pz];
+    const int rm = a.res_mode;
+    const long pix = (long)y * a.W + x;
+#pragma unroll
+    for (int o = 0; o < NCO; ++o) {
+        if (o >= a.Cout) break;
+        f32x4 v = red[0][o][lane];
+#pragma unroll
+        for (int sidx = 1; sidx < NS; ++sidx) v += red[sidx][o][lane];
+        const int ac = (a.act_split > 0 && o >= a.act_split) ? a.act2 : a.act;
+        v = v + (bias ? bias[o] : 0.f);
+        f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rm) rv = *(const f32x4*)(resn + (long)o * HW + pix);
+        if (rm == 1) v += rv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_any(v[e], ac);
+        if (rm == 2) v += rv;
+        else if (rm == 3) {
+            v += rv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        } else if (rm == 4) v *= rv;
+        *(f32x4*)(outn + (long)o * HW + pix) = v;
+    }
+}
+
 // ---- host side (called from conv_igemm.hip's forward entry; the packed weights are conv_igemm's) -------------------------
 // Decided per launch (map size and alignment matter), never at pack time: both kernels read the same packed block.
 bool motif_conv_direct_eligible(const MotifConvDesc* d, const ConvArgs& a, int P) {
@@ -143,10 +259,13 @@ bool motif_conv_direct_eligible(const MotifConvDesc* d, const ConvArgs& a, int P
     if (d->groups != 1 || d->stride != 1 || d->dil != 1 || d->KH != d->KW || (d->KH != 1 && d->KH != 3) || d->pad != d->KH / 2) return false;
     if (d->KH == 3 && d->pad_mode != 0) return false;
     const int Cin = d->C0 + d->C1;
-    if (d->Cout > 16 || Cin > 64 || (d->W & 3)) return false;               // measured on the 360x640 layers: 32->8 38 -> 22 us, 8->8 3x3 33 -> 24,
+    const bool deep = d->Cout <= 4 && Cin >= 32 && (long)Cin * d->Cout * d->KH * d->KW <= 16384 && (long)d->N * P * d->H * d->W >= 16384 &&
+                      (d->C1 == 0 || (d->C0 & 1) == 0);                      // tiny-Cout / deep-K form (flow heads): any map size that fills the chip
+    if (!deep && (d->Cout > 16 || Cin > 64)) return false;
+    if (d->W & 3) return false;               // measured on the 360x640 layers: 32->8 38 -> 22 us, 8->8 3x3 33 -> 24,
                                                                              // 32->16 40 -> 29; 8->32 (store bound, two cout slices) 27 -> 31: not taken
-    if ((long)Cin * d->Cout * d->KH * d->KW > 4096) return false;            // MACs per pixel: beyond this the matrix engine wins
-    if ((long)d->N * P * d->H * d->W < 131072) return false;                 // small maps: the MFMA engine's blocks fill the chip anyway
+    if (!deep && (long)Cin * d->Cout * d->KH * d->KW > 4096) return false;   // MACs per pixel: beyond this the matrix engine wins
+    if (!deep && (long)d->N * P * d->H * d->W < 131072) return false;        // small maps: the MFMA engine's blocks fill the chip anyway
     for (int i = 0; i < P; ++i) {
         unsigned long long bits = (unsigned long long)a.in0[i] | (unsigned long long)a.out[i] | (unsigned long long)a.in1[i] | (unsigned long long)a.res[i];
         if (bits & 15) return false;
@@ -158,6 +277,12 @@ bool motif_conv_direct_eligible(const MotifConvDesc* d, const ConvArgs& a, int P
 int motif_conv_direct_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s) {
     a.Ho = d->H; a.Wo = d->W; a.Cin_g = d->C0 + d->C1; a.Cout_g = d->Cout;
     const long quads = (long)(d->W >> 2) * d->H;
+    if (d->Cout <= 4 && a.Cin_g >= 32) {                 // deep form: 8 channel slices (waves) per 64 pixel quads
+        dim3 grid((unsigned)((quads + 63) / 64), 1, d->N * P);
+        if (d->KH == 1) conv_direct_deep_kernel<4, 1, 8><<<grid, 512, 0, s>>>(a); else conv_direct_deep_kernel<4, 3, 8><<<grid, 512, 0, s>>>(a);
+        MOTIF_LAUNCH_CHECK();
+        return MOTIF_OK;
+    }
     const int nco = d->Cout <= 16 ? 8 : 16;
     dim3 grid((unsigned)((quads + 255) / 256), (d->Cout + nco - 1) / nco, d->N * P);
     if (d->KH == 1) {

@@ -204,7 +204,10 @@ DIRECT_CASES = [  # cin, cout, k, H, W, N, two-source split, act, res_mode, act_
     (8, 16, 1, 360, 640, 2, 0, "none", 2, 0),         # two cout slices of 8, residual after
     (32, 16, 1, 200, 332, 2, 16, "lrelu", 1, 0),      # two-source input, residual before the activation
     (5, 12, 3, 190, 364, 2, 0, "tanh", 3, 8),         # odd channel count (zero partner channel in the packed block), partial cout slice, split activation
-    (16, 24, 3, 96, 96, 15, 0, "sigmoid", 4, 0),      # many small images, multiplicative residual
+    (16, 24, 3, 96, 96, 15, 0, "sigmoid", 4, 0),      # many small images, multiplicative residual (24 couts: stays on the MFMA engine)
+    (128, 2, 3, 90, 160, 2, 0, "none", 0, 0),         # RAFT flow head: deep-K form (8 channel slices per workgroup, LDS reduction)
+    (200, 3, 3, 46, 76, 2, 104, "lrelu", 2, 0),       # deep form: two sources, slice ends inside a source, ragged quads, 3 couts
+    (96, 4, 1, 128, 132, 1, 0, "relu", 1, 0),         # deep form, 1x1
 ]
 
 
