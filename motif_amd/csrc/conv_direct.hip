@@ -114,15 +114,23 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
     float* outn = a.out[pz] + (long)n * a.out_bs[pz];
     const int rm = a.res_mode;
     const long pix = (long)y * a.W + x;
+    // bias and residual values of all couts first: a load inside the store loop waits for every store issued before it (loads and
+    // stores share the vmcnt counter, so the compiler can only wait for zero)
+    float bvv[NCO];
+    f32x4 rvv[NCO];
+#pragma unroll
+    for (int o = 0; o < NCO; ++o) {
+        const int co = min(co0 + o, a.Cout - 1);
+        bvv[o] = bias ? bias[co] : 0.f;
+        rvv[o] = rm ? *(const f32x4*)(resn + (long)co * HW + pix) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int o = 0; o < NCO; ++o) {
         const int co = co0 + o;
         if (co >= a.Cout) break;
         const int ac = (a.act_split > 0 && co >= a.act_split) ? a.act2 : a.act;
-        const float b = bias ? bias[co] : 0.f;
-        f32x4 v = acc[o] + b;
-        f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (rm) rv = *(const f32x4*)(resn + (long)co * HW + pix);
+        f32x4 v = acc[o] + bvv[o];
+        const f32x4 rv = rvv[o];
         if (rm == 1) v += rv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_any(v[e], ac);
@@ -229,6 +237,14 @@ __global__ __launch_bounds__(64 * NS) void conv_direct_deep_kernel(ConvArgs a) {
     float* outn = a.out[pz] + (long)n * a.out_bs[pz];
     const int rm = a.res_mode;
     const long pix = (long)y * a.W + x;
+    float bvv[NCO];
+    f32x4 rvv[NCO];
+#pragma unroll
+    for (int o = 0; o < NCO; ++o) {
+        const int co = min(o, a.Cout - 1);
+        bvv[o] = bias ? bias[co] : 0.f;
+        rvv[o] = rm ? *(const f32x4*)(resn + (long)co * HW + pix) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int o = 0; o < NCO; ++o) {
         if (o >= a.Cout) break;
@@ -236,9 +252,8 @@ __global__ __launch_bounds__(64 * NS) void conv_direct_deep_kernel(ConvArgs a) {
 #pragma unroll
         for (int sidx = 1; sidx < NS; ++sidx) v += red[sidx][o][lane];
         const int ac = (a.act_split > 0 && o >= a.act_split) ? a.act2 : a.act;
-        v = v + (bias ? bias[o] : 0.f);
-        f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (rm) rv = *(const f32x4*)(resn + (long)o * HW + pix);
+        v = v + bvv[o];
+        const f32x4 rv = rvv[o];
         if (rm == 1) v += rv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_any(v[e], ac);
