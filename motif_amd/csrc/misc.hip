@@ -347,12 +347,25 @@ __global__ void in_reduce_kernel(const double* __restrict__ part, double* __rest
     stats[plane * 2 + pass] = t;
 }
 
+// stats: [NC][2] = (sum, centred second moment) of every plane -- or, with part != nullptr, the S partial (sum, sum of squares) pairs the
+// moments kernel wrote: thread 0 adds them in slice order (the order the former reduce kernel used: same bits) -- one launch less.
 __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                      const double* __restrict__ stats, float* __restrict__ out, int HW, int mode) {
+                                                      const double* __restrict__ stats, float* __restrict__ out, int HW, int mode,
+                                                      const double* __restrict__ part, int S) {
     const int plane = blockIdx.y;
     const long base = (long)plane * HW;
-    const float mean = (float)(stats[plane * 2] / (double)HW);
-    const float var = (float)(stats[plane * 2 + 1] / (double)HW);
+    __shared__ double st[2];
+    if (part) {
+        if (threadIdx.x == 0) {
+            double s_ = 0.0, q_ = 0.0;
+            for (int i = 0; i < S; ++i) { s_ += part[((long)plane * S + i) * 2]; q_ += part[((long)plane * S + i) * 2 + 1]; }
+            const double m2 = q_ - s_ * s_ / (double)HW;
+            st[0] = s_; st[1] = m2 > 0.0 ? m2 : 0.0;
+        }
+        __syncthreads();
+    }
+    const float mean = (float)((part ? st[0] : stats[plane * 2]) / (double)HW);
+    const float var = (float)((part ? st[1] : stats[plane * 2 + 1]) / (double)HW);
     const float inv = 1.0f / sqrtf(var + 1e-5f);
     // 16 bytes per lane where the plane allows it (4-byte accesses cost the same vector-memory instruction for a quarter of the bytes)
     const bool v4 = (HW & 3) == 0 && ((((unsigned long long)(x + base)) | ((unsigned long long)(out + base)) | (mode == 2 ? (unsigned long long)(res + base) : 0ull)) & 15) == 0;
@@ -428,16 +441,6 @@ __global__ __launch_bounds__(256) void in_moments_kernel(const float* __restrict
     if (threadIdx.x == 0) { part[((long)plane * S + sb) * 2] = ts; part[((long)plane * S + sb) * 2 + 1] = tq; }
 }
 
-__global__ void in_moments_reduce_kernel(const double* __restrict__ part, double* __restrict__ stats, int NC, int S, int HW) {
-    const int plane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (plane >= NC) return;
-    double s = 0.0, q = 0.0;
-    for (int i = 0; i < S; ++i) { s += part[((long)plane * S + i) * 2]; q += part[((long)plane * S + i) * 2 + 1]; }
-    const double m2 = q - s * s / (double)HW;
-    stats[plane * 2] = s;                      // in_apply_kernel: mean = stats[0] / HW, var = stats[1] / HW
-    stats[plane * 2 + 1] = m2 > 0.0 ? m2 : 0.0;
-}
-
 extern "C" int motif_instance_norm_ws(const float* x, const float* res, float* out, double* workspace, int NC, int HW, int mode, void* stream) {
     if (!x || !out || NC < 1 || HW < 1 || (mode == 2 && !res)) return MOTIF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -448,8 +451,7 @@ extern "C" int motif_instance_norm_ws(const float* x, const float* res, float* o
     double* stats = workspace;               // [NC][2]
     double* part = workspace + 2L * NC;      // [NC][S][2]
     in_moments_kernel<<<dim3(S, NC), 256, 0, s>>>(x, part, HW, S);
-    in_moments_reduce_kernel<<<cdiv(NC, 64), 64, 0, s>>>(part, stats, NC, S, HW);
-    in_apply_kernel<<<dim3(S, NC), 256, 0, s>>>(x, res, stats, out, HW, mode);
+    in_apply_kernel<<<dim3(S, NC), 256, 0, s>>>(x, res, stats, out, HW, mode, part, S);      // every block adds the S partials itself
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }
