@@ -276,10 +276,13 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
     signed char* texp = (signed char*)(abl + 128);                   // [OT_TP] per-cell scale exponent E
     __shared__ unsigned count;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bn = blockIdx.z, b = bn / a.N, n = bn % a.N;
-    // 1-D tile grid in XCD-aware order: an XCD gets a contiguous run of tiles (several tile rows), so the +-16-pixel scan regions
-    // of neighbouring tiles share its L2
-    const int tiles_x = (a.WW + OT_W - 1) / OT_W, tile_id = xcd_tile_id();
+    // 1-D grid over (tile, frame) with the FRAME fastest, in XCD-aware order: an XCD gets a contiguous run of ids, i.e. all B*N frames
+    // of a tile and then the next tiles (several tile rows).  The frames of a tile read the same source values U (only their flows
+    // differ), so the second and third frame find them in that XCD's L2 instead of streaming the 472 MB tensor from HBM once per
+    // frame; the +-16-pixel scan regions of neighbouring tiles share the L2 as before.
+    const int BN = a.B * a.N, gid = xcd_tile_id();
+    const int bn = gid % BN, b = bn / a.N, n = bn % a.N;
+    const int tiles_x = (a.WW + OT_W - 1) / OT_W, tile_id = gid / BN;
     const int tx0 = (tile_id % tiles_x) * OT_W, ty0 = (tile_id / tiles_x) * OT_H;
     const long Q = (long)a.HH * a.WW, HWl = (long)a.H * a.W;
     if (tid == 0) count = 0;
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
     if (single) planes(std::true_type{});
     else planes(std::false_type{});
 #ifdef MOTIF_TRACE
-    const int blk = blockIdx.z * gridDim.x + blockIdx.x;
+    const int blk = blockIdx.x;
     if (tid == 0 && blk < 2048) {
         ph[6] = cnt;
         ph[10] = __builtin_amdgcn_s_memtime() - tstart;
@@ -713,7 +716,7 @@ static int launch_motif_splat(MotifSplatArgs a, void* stream) {
                        + 128 * 4 + ((OT_TP + 3) & ~3);
     hipError_t e = hipFuncSetAttribute((const void*)splat_owner_kernel<PRE, GLR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    dim3 grid(((a.WW + OT_W - 1) / OT_W) * ((a.HH + OT_H - 1) / OT_H), 1, a.B * a.N);
+    dim3 grid(((a.WW + OT_W - 1) / OT_W) * ((a.HH + OT_H - 1) / OT_H) * a.B * a.N, 1, 1);
     splat_owner_kernel<PRE, GLR><<<grid, OT_THREADS, lds, (hipStream_t)stream>>>(a, cap);
     MOTIF_LAUNCH_CHECK();
     const int tiles_x = (a.WW + 63) / 64, tiles_y = (a.HH + 3) / 4;
