@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), "libmotif_hip.so")
-SOURCES = ["api.hip", "conv_igemm.hip", "conv_split.hip", "conv_split2.hip", "conv_direct.hip", "siren.hip", "siren_split.hip", "splat.hip", "misc.hip", "corr.hip", "dcn.hip"]
+SOURCES = ["api.hip", "conv_igemm.hip", "conv_split.hip", "conv_split2.hip", "conv_wino.hip", "conv_direct.hip", "siren.hip", "siren_split.hip", "splat.hip", "misc.hip", "corr.hip", "dcn.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value",
          "-Wno-pass-failed"]
 
@@ -34,7 +34,7 @@ def build(force=False, verbose=False):
 
 
 def _build_locked(objdir, force, verbose):
-    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "conv_common.h"), os.path.join(HERE, "conv_split_common.h"), os.path.join(HERE, "siren_common.h"), os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "motif_hip.h")]
+    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "conv_common.h"), os.path.join(HERE, "conv_split_common.h"), os.path.join(HERE, "conv_wave_epilogue.h"), os.path.join(HERE, "siren_common.h"), os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "motif_hip.h")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(HERE, s)

@@ -231,10 +231,15 @@ bool motif_conv_split_eligible(const MotifConvDesc* d) {
     return Cin / d->groups >= 16 && d->Cout / d->groups > 32;
 }
 
-long motif_conv_split_packed_floats(const MotifConvDesc* d) {
+long motif_conv_split_packed_floats_direct(const MotifConvDesc* d) {
     const int Cin_g = (d->C0 + d->C1) / d->groups, Cout_g = d->Cout / d->groups;
     const long nks = 9L * ((Cin_g + 15) / 16), ncg = (Cout_g + 63) / 64;
     return (long)d->groups * ncg * nks * split_parts(d->mma) * 2 * 64 * 4;     // 8 bf16 = 4 floats per lane
+}
+
+// blob = [direct fragments | Winograd F(2,3) fragments (mma = 6 only, conv_wino.hip)]: the kernel is chosen per launch
+long motif_conv_split_packed_floats(const MotifConvDesc* d) {
+    return motif_conv_split_packed_floats_direct(d) + motif_conv_wino_packed_floats(d);
 }
 
 int motif_conv_split_pack(const MotifConvDesc* d, const float* weight, float* packed, hipStream_t s) {
@@ -243,10 +248,15 @@ int motif_conv_split_pack(const MotifConvDesc* d, const float* weight, float* pa
     const long total = (long)d->groups * ncg * nks * NP * 2 * 64 * 8;
     conv_split_pack_kernel<<<cdiv(total, 256), 256, 0, s>>>(weight, (unsigned short*)packed, Cout_g, Cin_g, nks, ncg, NP, total);
     MOTIF_LAUNCH_CHECK();
+    if (motif_conv_wino_packed_floats(d) > 0) return motif_conv_wino_pack(d, weight, packed + motif_conv_split_packed_floats_direct(d), s);
     return MOTIF_OK;
 }
 
 int motif_conv_split_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s) {
+    {                                                    // round 4: conv_wino.hip (conv_engine 5 = wherever it applies, 6 = never)
+        const int force = motif_opt(MOTIF_OPT_CONV_ENGINE);
+        if ((force == 0 || force == 5) && motif_conv_wino_eligible(d, a, P)) return motif_conv_wino_launch(d, a, P, s);
+    }
     if (motif_opt(MOTIF_OPT_CONV_ENGINE) != 1 && motif_conv_split2_eligible(d, a, P)) return motif_conv_split2_launch(d, a, P, s);   // round 3: conv_split2.hip
     const int Cin_g = (d->C0 + d->C1) / d->groups, Cout_g = d->Cout / d->groups;
     if (d->C1 > 0 && (d->groups != 1 || d->C0 % 16)) return MOTIF_ELIMIT;   // a 16-channel chunk must not straddle the sources

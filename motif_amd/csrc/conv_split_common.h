@@ -46,3 +46,9 @@ static inline int split_parts(int mma) { return mma == 6 ? 3 : mma == 3 ? 2 : mm
 // round-3 kernel (conv_split2.hip): same packed weights, same ConvArgs as conv_split.hip
 bool motif_conv_split2_eligible(const MotifConvDesc* d, const ConvArgs& a, int P);
 int motif_conv_split2_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s);
+// round-4 kernel (conv_wino.hip): Winograd F(2,3) along the rows, its own fragment block behind the direct one in the packed blob
+long motif_conv_split_packed_floats_direct(const MotifConvDesc* d);
+long motif_conv_wino_packed_floats(const MotifConvDesc* d);
+int motif_conv_wino_pack(const MotifConvDesc* d, const float* weight, float* packed, hipStream_t s);
+bool motif_conv_wino_eligible(const MotifConvDesc* d, const ConvArgs& a, int P);
+int motif_conv_wino_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s);

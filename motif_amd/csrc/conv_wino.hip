@@ -1,0 +1,490 @@
+// 3x3 / stride 1 convolution with 1.5x fewer matrix instructions: Winograd F(2,3) along the image ROWS, direct along the
+// columns, fp32-equivalent 3-way bf16 split arithmetic (see conv_split.hip), on the bf16 matrix cores.  Round-4 kernel.
+//
+// For an output row pair (2T, 2T+1), input rows d0..d3 = 2T-1 .. 2T+2 and the kernel rows g0, g1, g2 (per column tap kx):
+//     V0 = d0 - d2     U0 = g0                    M_p = sum over (cin, kx) of U_p[kx] * V_p[x + kx]
+//     V1 = d1 + d2     U1 = (g0 + g1 + g2) / 2    out(2T)   = M0 + M1 + M2
+//     V2 = d2 - d1     U2 = (g0 - g1 + g2) / 2    out(2T+1) = M1 - M2 - M3
+//     V3 = d1 - d3     U3 = g2
+// i.e. 4 x 3 = 12 k-steps per 16-channel chunk and row PAIR instead of 2 x 9 = 18.  The transform is along y only: along x the
+// kernel stays a direct convolution, so a B fragment is still one ds_read_b128 at an immediate column offset, the C/D layout of an
+// output row is the one of the direct kernels (shared epilogue), and the 2-D form's operand traffic (no fragment reuse at all: one
+// 1 KB fragment per MFMA) and 256-register accumulator set are avoided.  U is formed in fp64 from the fp32
+// weights and split into three bf16 parts at pack time; V is one fp32 addition per value, then the same exact 3-way split as the
+// direct kernels.  Rounding differs from the direct form by that one addition per operand and by the three-term output sums
+// (tests/test_kernels_gpu.py: error against fp64 <= 3x the fp32-MFMA engine's).
+//
+// Shape: workgroup = 4 waves, ONE WAVE PER SIMD (512 registers per lane: 128 accumulators + operands two k-steps ahead + a whole
+// chunk's staging in flight), tile = 8 rows x 32 columns x 64 couts.  MFMA role of wave (ct, tp): cout tile ct x row pairs 2tp,
+// 2tp+1 (8 accumulators = [pair][position]).  Staging role of wave w: row pair T = w -- it fetches the pair's 4 input rows of the
+// next 16-channel chunk as 16-byte row pieces (range-checked buffer loads: zeros outside the image and past Cin), parks them in its
+// private landing area, reads them back pixel-major, forms V (one lane = one pixel x 8 channels x 4 positions), splits and writes
+// the staging buffer [part][octet][pair][position][34 px] x 8 bf16.  The two halo columns of the pair (4 items of 32 values) are
+// done channel-parallel, one (position, channel pair) per lane.  Every wave runs the same statically scheduled stream: after each
+// MFMA at most one operand request and one staging piece of <= 4 instructions (WSched), pinned with sched_barrier(0).
+// Persistent workgroups (tile = b' + i * G, XCD-aware b'), the next tile's first chunk staged under the current tile's last one.
+#include "conv_wave_epilogue.h"
+#include <utility>
+
+#ifdef MOTIF_TRACE
+__device__ long long g_wn_trace[1024 * 4 * 32];
+#define WNTRACE(slot) do { if (lane == 0 && blockIdx.x < 1024) g_wn_trace[(blockIdx.x * 4 + wave) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int motif_debug_wino_trace(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wn_trace), sizeof(long long) * n); }
+// per-super-step stamps of the first 8 staged chunks of a workgroup: [block][wave][chunk][7]
+__device__ long long g_wn_trace2[256 * 4 * 8 * 8];
+extern "C" int motif_debug_wino_trace2(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wn_trace2), sizeof(long long) * n); }
+#else
+#define WNTRACE(slot)
+#endif
+
+#ifndef WINO_ABL
+#define WINO_ABL 0        // ablation builds (tools/wino_ablate.sh): bit 0 no loads, 1 no parks, 2 no read-back, 3 no transform/split,
+#endif                    // 4 no staging stores, 5 no halo item, 6 no B fragments, 7 no weight fragments, 8 no epilogue
+
+namespace {
+// Products ordered by ACTIVATION part, smallest part first (w = weight part, x = activation part).
+struct WOrder {
+    static constexpr int n = 6;
+    static constexpr int w[6] = {0, 1, 0, 2, 1, 0};
+    static constexpr int x[6] = {2, 1, 1, 0, 0, 0};
+};
+
+enum { WP_LOAD = 1, WP_PARK = 2, WP_READ = 3, WP_X = 4, WP_W = 5, WP_HREAD = 6, WP_HX = 7, WP_HW = 8 };
+
+// Static schedule of a chunk: 6 super-steps (position pair, kx) of M = 24 MFMAs = product x (position of the pair, row pair): FOUR
+// accumulators in rotation -- a dependent v_mfma_f32_32x32x16_bf16 issues ~86 cycles after its producer, so with the two accumulators
+// of one position an MFMA-only stream runs at 42.8 cycles per MFMA instead of 32-36 (measured).
+// Slot s = ss * M + m follows MFMA m of super-step ss.
+//   slots 0..11:  B fragments of the NEXT super-step (a second register set), smallest activation part first;
+//   slots 12..17: weight fragments of the super-step after next (a third set);
+//   ext[s]: staging piece of the NEXT chunk, kind << 8 | index -- loads first, parks one super-step later, then the read-back, the
+//           halo reads, per position 13 transform/split stages of <= 4 INDEPENDENT instructions each + 3 stores, the halo item last
+//           (dependent instructions sit in different slots: a lone wave issues a dependent vector instruction only ~8 cycles later).
+struct WSched {
+    static constexpr int SS = 6, M = 24, S = SS * M, NLD = 10;
+    int ext[S], used;
+    constexpr WSched() : ext(), used(0) {
+        for (int s = 0; s < S; ++s) ext[s] = 0;
+        int f = 0;
+        for (int i = 0; i < NLD; ++i) ext[f++] = (WP_LOAD << 8) | i;
+        f = M;
+        for (int i = 0; i < NLD; ++i) ext[f++] = (WP_PARK << 8) | i;
+        for (int r = 0; r < 16; ++r) ext[f++] = (WP_READ << 8) | r;
+        for (int r = 0; r < 2; ++r) ext[f++] = (WP_HREAD << 8) | r;
+        for (int pos = 0; pos < 4; ++pos)
+            for (int i = 0; i < 16; ++i) ext[f++] = (i < 13 ? (WP_X << 8) | (pos * 16 + i) : (WP_W << 8) | (pos * 3 + i - 13));
+        for (int h = 0; h < 4; ++h) ext[f++] = (WP_HX << 8) | h;
+        for (int p = 0; p < 3; ++p) ext[f++] = (WP_HW << 8) | p;
+        used = f;
+    }
+};
+// Scalar fp32 add / subtract the compiler cannot pair into v_pk_add_f32: a packed add costs a lone wave ~12 cycles that do NOT
+// overlap its MFMA stream (tools/ubench_lone.hip: 2 per MFMA -> 55 cycles per MFMA), two plain ones 8 that do.
+__device__ __forceinline__ float fadd1(float a, float b) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float fsub1(float a, float b) { float r; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+constexpr WSched kWSched{};
+static_assert(kWSched.used <= WSched::S, "staging pieces do not fit the slots of a chunk");
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) -- every slot of the schedule is its own
+// instantiation (the loop unroller's size estimate, taken before the dispatch on the slot's piece is folded, refuses 144 slots)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+}  // namespace
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino_kernel(ConvArgs a, int ntiles, int tiles_y) {
+    constexpr int NP = 3, WAVES = 4, TH = 8, PW = 34, OCT = 16 * PW;   // 16 (pair, position) planes of 34 pixels per octet
+    constexpr int SLOTS = 2 * OCT + 4;                   // per part: [2 octets][16 planes][34] 16-byte slots (+ pad)
+    constexpr int STG = NP * SLOTS;                      // one bf16 staging buffer (u32x4)
+    constexpr int NLD = WSched::NLD, LW = NLD * 64;      // a wave's landing area: [4 rows][2 octets][8 channels][40 px] floats
+    constexpr int M = WSched::M, SS = WSched::SS;
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), ct = wave & 1, tp = wave >> 1;
+    float* bias_w = (float*)lds_raw + wave * 64;                       // [WAVES][64] (32 used)
+    u32x4* stg0 = lds_raw + WAVES * 16;                               // [2 buffers][NP][SLOTS]
+    u32x4* land = lds_raw + WAVES * 16 + 2 * STG + wave * LW;         // [WAVES][LW]: fp32 landing area / epilogue scratch
+    const float* landf = (const float*)land;
+
+    const int G = gridDim.x, bq = xcd_block_id(blockIdx.x, G);
+    if (bq >= ntiles) return;
+    const int nch = a.Kpad / 12;
+    const int ncgG = a.CK;                                              // groups * ncg
+    const int HW = a.H * a.W;
+
+    // tile coordinates as mixed-radix digits (cout group | column | row | image), advanced by G's digits: no division per tile
+    struct TileC { int cgg, tx, ty, z; };
+    auto coords_of = [&](int t) __attribute__((always_inline)) {
+        TileC c;
+        c.cgg = t % ncgG; int s = t / ncgG;
+        c.tx = s % a.tiles_x; s /= a.tiles_x;
+        c.ty = s % tiles_y; c.z = s / tiles_y;
+        return c;
+    };
+    const TileC stepc = coords_of(__builtin_amdgcn_readfirstlane(G));
+    auto advance = [&](TileC c) __attribute__((always_inline)) {
+        c.cgg += stepc.cgg; int cy = c.cgg >= ncgG; c.cgg -= cy ? ncgG : 0;
+        c.tx += stepc.tx + cy; cy = c.tx >= a.tiles_x; c.tx -= cy ? a.tiles_x : 0;
+        c.ty += stepc.ty + cy; cy = c.ty >= tiles_y; c.ty -= cy ? tiles_y : 0;
+        c.z += stepc.z + cy;
+        return c;
+    };
+    auto decode = [&](const TileC& c, int& n, int& pz, int& g, int& cg, int& ty, int& tx) __attribute__((always_inline)) {
+        tx = c.tx; ty = c.ty;
+        g = a.ncg == ncgG ? 0 : c.cgg / a.ncg; cg = c.cgg - g * a.ncg;
+        pz = (c.z >= a.N) + (c.z >= 2 * a.N) + (c.z >= 3 * a.N); n = c.z - pz * a.N;
+    };
+
+    // ---- per-lane constants of the staging role (row pair T = wave) ------------------------------------------------------
+    const int mrd = half * 8 * 40 + 4 + l31;                           // main item: octet `half`, pixel 1 + l31 (landing column 4 + l31)
+    const int mslot = half * OCT + (wave * 4) * PW + 1 + l31;          // its staging slot at position 0
+    const int h_side = (lane >> 4) & 1, h_oct = lane >> 5, h_pos = (lane >> 2) & 3, h_pair = lane & 3;   // halo item: one (position, channel pair)
+    const int h_ra = h_pos == 0 ? 0 : h_pos == 2 ? 2 : 1, h_rb = h_pos == 0 ? 2 : h_pos == 2 ? 1 : h_pos == 1 ? 2 : 3;
+    const float h_sgn = h_pos == 1 ? 1.f : -1.f;
+    const int h_rda = ((h_ra * 2 + h_oct) * 8 + 2 * h_pair) * 40 + (h_side ? 36 : 3);
+    const int h_rdb = ((h_rb * 2 + h_oct) * 8 + 2 * h_pair) * 40 + (h_side ? 36 : 3);
+    const int h_wr = (h_oct * OCT + (wave * 4 + h_pos) * PW + (h_side ? 33 : 0)) * 4 + h_pair;   // dword index within a part
+
+    // ---- staging plan of a tile (chunk-invariant) --------------------------------------------------------------------------
+    int doff[NLD];
+    const float* in0n = nullptr; const float* in1n = nullptr;
+    int st_g = 0;
+    float bias_v = 0.f;
+    auto wptr = [&](const TileC& t) __attribute__((always_inline)) {
+        int n, pz, g, cg, ty, tx;
+        decode(t, n, pz, g, cg, ty, tx);
+        const u32x4* base = (const u32x4*)a.wp[pz] + (long)(g * a.ncg + cg) * a.Kpad * (NP * 2 * 64);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    };
+    const int wvoff = (ct * 64 + lane) * 16;
+    auto wfrag = [&](__amdgpu_buffer_rsrc_t wb, int ks, int p) __attribute__((always_inline)) {
+        return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wb, wvoff, (ks * NP + p) * (2 * 64 * 16), 0));
+    };
+    auto setup_stage = [&](const TileC& t) __attribute__((always_inline)) {
+        int n, pz, g, cg, ty, tx;
+        decode(t, n, pz, g, cg, ty, tx);
+        st_g = g;
+        in0n = a.in0[pz] + (long)n * a.in0_bs[pz];
+        in1n = a.in1[pz] ? a.in1[pz] + (long)n * a.in1_bs[pz] : nullptr;
+        const float* bp = a.bias[pz];
+        bias_v = (bp && lane < 32 && cg * 64 + ct * 32 + lane < a.Cout_g) ? bp[g * a.Cout_g + cg * 64 + ct * 32 + lane] : 0.f;
+        const int iy0 = ty * TH - 1 + 2 * wave, x0 = tx * 32 - 4;      // pad 1; rows start 4 pixels left of the tile: aligned quads
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int qd = i * 64 + lane;
+            const int xq = qd % 10, r = qd / 10, ch = r & 7, oct = (r >> 3) & 1, row = r >> 4;
+            const int iy = iy0 + row, x = x0 + 4 * xq;
+            // BYTE offset from the chunk's first plane; 2^31 = "outside the image": beyond any descriptor's range, the load returns 0
+            doff[i] = (iy >= 0 && iy < a.H && x >= 0 && x < a.W) ? (iy * a.W + x + (8 * oct + ch) * HW) * 4 : (int)0x80000000;
+        }
+    };
+    // ---- the pieces of staging one 16-channel chunk ------------------------------------------------------------------------
+    f32x4 gq[NLD] = {};
+    auto st_load = [&](int i, int c0) __attribute__((always_inline)) {                  // global -> registers: 4 pixels of one channel of one row
+        const int gch0 = st_g * a.Cin_g + c0;
+        const bool first = gch0 < a.C0;
+        const float* base = first ? in0n + (long)gch0 * HW : in1n + (long)(gch0 - a.C0) * HW;
+        const int nchv = (first && in1n) ? a.C0 - c0 : a.Cin_g - c0;          // channels from c0 to the end of the group / of the first source
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nchv * HW * 4, 0x00020000);
+        gq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, doff[i], 0, 0));
+    };
+    auto st_park = [&](int i) __attribute__((always_inline)) { *(f32x4*)(land + i * 64 + lane) = gq[i]; };
+    float sv[4][8] = {};                                   // [input row of the pair][channel of the octet]
+    auto st_read = [&](int r) __attribute__((always_inline)) {                          // piece r: row r/4, channels 2(r%4), 2(r%4)+1
+        const int row = r >> 2, q = (r & 3) * 2;
+        sv[row][q] = landf[mrd + ((row * 2) * 8 + q) * 40];
+        sv[row][q + 1] = landf[mrd + ((row * 2) * 8 + q + 1) * 40];
+    };
+    float xv[8] = {}, xe[8] = {};
+    unsigned xpk[4] = {};
+    u32x4 sparts[NP] = {};
+    auto st_x = [&](int idx) __attribute__((always_inline)) {     // transform + split of one position, stage idx & 15 (four independent instructions each)
+        const int pos = idx >> 4, st = idx & 15;
+        auto expand = [&](int h) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 2 * h; q < 2 * h + 2; ++q) { xe[2 * q] = bf_lo(xpk[q]); xe[2 * q + 1] = bf_hi(xpk[q]); }
+        };
+        auto sub = [&](int h) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 4 * h; e < 4 * h + 4; ++e) xv[e] = fsub1(xv[e], xe[e]);
+        };
+        auto pack = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { xpk[q] = pk_bf16(xv[2 * q], xv[2 * q + 1]); sparts[p][q] = xpk[q]; }
+        };
+        if (st < 2) {
+            const int ra = pos == 0 ? 0 : pos == 2 ? 2 : 1, rb = pos == 0 ? 2 : pos == 2 ? 1 : pos == 1 ? 2 : 3;
+#pragma unroll
+            for (int e = 4 * st; e < 4 * st + 4; ++e) xv[e] = pos == 1 ? fadd1(sv[ra][e], sv[rb][e]) : fsub1(sv[ra][e], sv[rb][e]);
+        } else if (st == 2) pack(0);
+        else if (st == 3 || st == 4) expand(st - 3);
+        else if (st == 5 || st == 6) sub(st - 5);
+        else if (st == 7) pack(1);
+        else if (st == 8 || st == 9) expand(st - 8);
+        else if (st == 10 || st == 11) sub(st - 10);
+        else if (st == 12) pack(2);
+    };
+    auto st_w = [&](int idx, u32x4* dstbuf) __attribute__((always_inline)) {            // one part of position idx / 3 -> staging buffer
+        const int pos = idx / 3, p = idx - pos * 3;
+        dstbuf[p * SLOTS + mslot + pos * PW] = sparts[p];
+    };
+    float ha0 = 0.f, ha1 = 0.f, hb0 = 0.f, hb1 = 0.f, hv0 = 0.f, hv1 = 0.f, he0 = 0.f, he1 = 0.f;
+    unsigned hpk = 0, hparts[NP] = {};
+    auto st_hread = [&](int r) __attribute__((always_inline)) {
+        if (r == 0) { ha0 = landf[h_rda]; ha1 = landf[h_rda + 40]; }
+        else { hb0 = landf[h_rdb]; hb1 = landf[h_rdb + 40]; }
+    };
+    auto st_hx = [&](int h) __attribute__((always_inline)) {
+        if (h == 0) {
+            hv0 = __builtin_fmaf(h_sgn, hb0, ha0); hv1 = __builtin_fmaf(h_sgn, hb1, ha1);   // a +- b: the product by +-1 is exact
+            hpk = pk_bf16(hv0, hv1);
+            hparts[0] = hpk;
+        } else if (h == 1) {
+            hv0 -= bf_lo(hpk); hv1 -= bf_hi(hpk);
+        } else if (h == 2) {
+            hpk = pk_bf16(hv0, hv1);
+            hparts[1] = hpk;
+            he0 = bf_lo(hpk); he1 = bf_hi(hpk);
+        } else {
+            hparts[2] = pk_bf16(hv0 - he0, hv1 - he1);
+        }
+    };
+    auto st_hw = [&](int p, u32x4* dstbuf) __attribute__((always_inline)) { ((unsigned*)(dstbuf + p * SLOTS))[h_wr] = hparts[p]; };
+    auto piece = [&](auto ec, int c0, u32x4* dstbuf) __attribute__((always_inline)) {
+        constexpr int e = decltype(ec)::value, kind = e >> 8, idx = e & 255;
+        if constexpr (kind == WP_LOAD) { if constexpr (!(WINO_ABL & 1)) st_load(idx, c0); }
+        else if constexpr (kind == WP_PARK) { if constexpr (!(WINO_ABL & 2)) st_park(idx); }
+        else if constexpr (kind == WP_READ) { if constexpr (!(WINO_ABL & 4)) st_read(idx); }
+        else if constexpr (kind == WP_X) { if constexpr (!(WINO_ABL & 8)) st_x(idx); }
+        else if constexpr (kind == WP_W) { if constexpr (!(WINO_ABL & 16)) st_w(idx, dstbuf); }
+        else if constexpr (kind == WP_HREAD) { if constexpr (!(WINO_ABL & 32)) st_hread(idx); }
+        else if constexpr (kind == WP_HX) { if constexpr (!(WINO_ABL & 32)) st_hx(idx); }
+        else if constexpr (kind == WP_HW) { if constexpr (!(WINO_ABL & 32)) st_hw(idx, dstbuf); }
+    };
+
+#ifdef MOTIF_TRACE
+    int trace_chunk = 0;
+#endif
+    f32x16 acc[2][4];                                    // [row pair of this wave][position]
+    constexpr int WB = 3;                                // weight fragments two super-steps ahead
+    u32x4 wf[WB][2][NP];                                 // [set][position of the pair][weight part]
+    __amdgpu_buffer_rsrc_t wbase, wnext;
+    auto wks = [](int ss, int pi) __attribute__((always_inline)) { return (2 * (ss / 3) + pi) * 3 + ss % 3; };   // packed k-step (position, kx) within a chunk
+    auto loadw = [&](__amdgpu_buffer_rsrc_t wb, int ss, u32x4 (&dst)[2][NP]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) dst[pi][p] = wfrag(wb, wks(ss, pi), p);
+    };
+
+    // 6 super-steps of chunk c on staging buffer `buf`; STAGE: the pieces of chunk `sc` (source plan as set up) go to the other buffer,
+    // and the first two super-steps' weight fragments of that chunk (from `wn`) are requested during super-steps 4 and 5.
+    auto chunk_body = [&](int c, int buf, auto stage_tag, int sc, __amdgpu_buffer_rsrc_t wn) __attribute__((always_inline)) {
+        constexpr bool STAGE = decltype(stage_tag)::value;
+        const u32x4* pb = stg0 + buf * STG + half * OCT + (tp * 8) * PW + l31;
+        u32x4* dstbuf = stg0 + (buf ^ 1) * STG;
+        u32x4 bfr[2][NP][4];                             // [set][activation part][position of the pair * 2 + row pair]
+        auto loadb = [&](int ss, int p, int j) __attribute__((always_inline)) {
+            bfr[ss & 1][p][j] = pb[p * SLOTS + ((j & 1) * 4 + 2 * (ss / 3) + (j >> 1)) * PW + (ss % 3)];
+        };
+#pragma unroll
+        for (int p = NP - 1; p >= 0; --p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) loadb(0, p, j);
+#ifdef MOTIF_TRACE
+        long long ts[7];
+#endif
+        static_for<SS * M>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int s = decltype(ic)::value, ss = s / M, m = s % M, k = m >> 2, j = m & 3, pi = j >> 1, tl = j & 1, pos = 2 * (ss / 3) + pi;
+#ifdef MOTIF_TRACE
+            if constexpr (m == 0 && STAGE) ts[ss] = __builtin_amdgcn_s_memtime();
+#endif
+            acc[tl][pos] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ss % WB][pi][WOrder::w[k]]),
+                                                                   __builtin_bit_cast(bf16x8, bfr[ss & 1][WOrder::x[k]][j]), acc[tl][pos], 0, 0, 0);
+            if constexpr (m < 12 && ss + 1 < SS && !(WINO_ABL & 64)) loadb(ss + 1, 2 - m / 4, m & 3);
+            if constexpr (m >= 12 && m < 18 && !(WINO_ABL & 128)) {
+                constexpr int p = (m - 12) >> 1, qi = (m - 12) & 1;      // part-major: the leading weight parts of both positions first
+                if constexpr (ss + 2 < SS) wf[(ss + 2) % WB][qi][p] = wfrag(wbase, c * 12 + wks(ss + 2, qi), p);
+                else if constexpr (STAGE) wf[(ss + 2) % WB][qi][p] = wfrag(wn, sc * 12 + wks(ss + 2 - SS, qi), p);
+            }
+            if constexpr (STAGE) piece(std::integral_constant<int, kWSched.ext[s]>{}, sc * 16, dstbuf);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#ifdef MOTIF_TRACE
+        if constexpr (STAGE) {
+            ts[6] = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && blockIdx.x < 256 && trace_chunk < 8) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) g_wn_trace2[((blockIdx.x * 4 + wave) * 8 + trace_chunk) * 8 + i] = ts[i];
+            }
+            ++trace_chunk;
+        }
+#endif
+    };
+    auto epilogue = [&](const TileC& t) __attribute__((always_inline)) {
+        int n, pz, g, cg, ty, tx;
+        decode(t, n, pz, g, cg, ty, tx);
+        const int cbase = g * a.Cout_g + cg * 64 + ct * 32, climit = a.Cout_g - cg * 64 - ct * 32;
+        if (climit <= 0 || (WINO_ABL & 256)) return;
+        f32x16 o[4];                                     // output rows 4 tp .. 4 tp + 3 of the tile: the inverse transform
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            o[2 * tl] = (acc[tl][0] + acc[tl][1]) + acc[tl][2];
+            o[2 * tl + 1] = (acc[tl][1] - acc[tl][2]) - acc[tl][3];
+        }
+        const long HWo = (long)a.Ho * a.Wo;
+        float* ob = a.out[pz] + (long)n * a.out_bs[pz] + (long)cbase * HWo;
+        const float* rb = a.res_mode ? a.res[pz] + (long)n * a.res_bs[pz] + (long)cbase * HWo : nullptr;
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        if (a.res_mode) conv_epilogue_wave<4, 2, true>(a, o, bias_w, (float*)land, lane_e, cbase, climit, ty * TH + 4 * tp, tx * 32, rb, ob);
+        else conv_epilogue_wave<4, 2, false>(a, o, bias_w, (float*)land, lane_e, cbase, climit, ty * TH + 4 * tp, tx * 32, rb, ob);
+    };
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tl][p][r] = 0.f;
+    };
+
+    // ---- prologue: first chunk of the first tile (nothing to hide it under) ------------------------------------------------
+    int t = bq;
+    TileC tc = coords_of(__builtin_amdgcn_readfirstlane(t)), tn = tc;
+    WNTRACE(0);
+    setup_stage(tc);
+    wbase = wnext = wptr(tc);
+    loadw(wbase, 0, wf[0]);
+    loadw(wbase, 1, wf[1]);
+    static_for<WSched::S>([&](auto ic) __attribute__((always_inline)) { piece(std::integral_constant<int, kWSched.ext[decltype(ic)::value]>{}, 0, stg0); });
+    if (lane < 32) bias_w[lane] = bias_v;
+    zero_acc();
+    __syncthreads();
+    WNTRACE(1);
+
+    // ---- persistent tile loop ----------------------------------------------------------------------------------------------
+    int buf = 0, slot = 2;
+    for (;;) {
+        const int t_next = t + G;
+        const bool has_next = t_next < ntiles;
+        for (int c = 0; c < nch; ++c) {
+            const bool last = c + 1 == nch;
+            if (last && has_next) { tn = advance(tc); setup_stage(tn); wnext = wptr(tn); }
+            if (!last || has_next) chunk_body(c, buf, std::true_type{}, last ? 0 : c + 1, last ? wnext : wbase);
+            else chunk_body(c, buf, std::false_type{}, 0, wbase);
+            __syncthreads();
+            buf ^= 1;
+            if (slot < 30) { WNTRACE(slot); ++slot; }
+        }
+        epilogue(tc);
+        if (slot < 30) { WNTRACE(slot); ++slot; }
+        if (!has_next) break;
+        t = t_next; tc = tn; wbase = wnext;
+        if (lane < 32) bias_w[lane] = bias_v;
+        zero_acc();
+    }
+    WNTRACE(31);
+}
+
+// weight [Cout, Cin_g, 3, 3] fp32 -> A fragments [group][cout group of 64][k-step][part][cout tile][lane][8] bf16,
+// k-step = (channel group of 16, position, kx); value = U_position[kx] of the file header, formed in fp64 and split from there
+__global__ void conv_wino_pack_kernel(const float* w, unsigned short* wp, int Cout_g, int Cin_g, int nks, int ncg, long total) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), ct = (int)((i >> 9) & 1);
+    long tt = i >> 10;
+    const int part = (int)(tt % 3); tt /= 3;
+    const int ks = (int)(tt % nks); tt /= nks;
+    const int cgi = (int)(tt % ncg);
+    const int g = (int)(tt / ncg);
+    const int col = cgi * 64 + ct * 32 + (lane & 31);
+    const int c = (ks / 12) * 16 + 8 * (lane >> 5) + e, s = ks % 12, pos = s / 3, kx = s % 3;
+    double v = 0.0;
+    if (col < Cout_g && c < Cin_g) {
+        const float* wk = w + ((long)(g * Cout_g + col) * Cin_g + c) * 9 + kx;
+        const double g0 = wk[0], g1 = wk[3], g2 = wk[6];
+        v = pos == 0 ? g0 : pos == 1 ? 0.5 * (g0 + g1 + g2) : pos == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+    }
+    unsigned short out = 0;
+    for (int p = 0; p <= part; ++p) {
+        const unsigned pk = pk_bf16((float)v, 0.f);
+        out = (unsigned short)(pk & 0xffffu);
+        v -= (double)bf_lo(pk);
+    }
+    wp[i] = out;
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------
+namespace {
+int wn_cu_count() {
+    static int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return cus;
+}
+}  // namespace
+
+// The Winograd block follows the direct block in the packed blob of every split-eligible layer with mma = 6 (pack and forward
+// agree from the desc alone); WHICH kernel runs is decided per launch.
+long motif_conv_wino_packed_floats(const MotifConvDesc* d) {
+    if (split_parts(d->mma) != 3) return 0;
+    const int Cin_g = (d->C0 + d->C1) / d->groups, Cout_g = d->Cout / d->groups;
+    const long nks = 12L * ((Cin_g + 15) / 16), ncg = (Cout_g + 63) / 64;
+    return (long)d->groups * ncg * nks * 3 * 2 * 64 * 4;
+}
+
+int motif_conv_wino_pack(const MotifConvDesc* d, const float* weight, float* packed, hipStream_t s) {
+    const int Cin_g = (d->C0 + d->C1) / d->groups, Cout_g = d->Cout / d->groups;
+    const int nks = 12 * ((Cin_g + 15) / 16), ncg = (Cout_g + 63) / 64;
+    const long total = (long)d->groups * ncg * nks * 3 * 2 * 64 * 8;
+    conv_wino_pack_kernel<<<cdiv(total, 256), 256, 0, s>>>(weight, (unsigned short*)packed, Cout_g, Cin_g, nks, ncg, total);
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}
+
+// Same layout conditions as conv_split2 (zero padding 1, rows of whole 16-byte units, aligned tensors, activation split on an
+// 8-cout boundary); 3-part arithmetic only.
+bool motif_conv_wino_eligible(const MotifConvDesc* d, const ConvArgs& a, int P) {
+    if (split_parts(d->mma) != 3 || d->pad != 1 || d->pad_mode != 0 || (d->W & 3)) return false;
+    const long HW = (long)d->H * d->W;
+    if (HW * 64 >= 0x7fffffffL) return false;
+    const int Cout_g = d->Cout / d->groups;
+    if ((long)((d->C0 + d->C1) / d->groups) * HW * 4 >= 0x7fffffffL) return false;
+    if (d->act_split > 0 && ((d->act_split & 7) || (d->groups > 1 && (Cout_g & 7)))) return false;
+    if (d->C1 > 0 && (d->groups != 1 || d->C0 % 16)) return false;
+    for (int i = 0; i < P; ++i) {
+        unsigned long long bits = (unsigned long long)a.in0[i] | (unsigned long long)a.out[i] | (unsigned long long)a.in1[i] | (unsigned long long)a.res[i];
+        if (bits & 15) return false;
+        if ((a.in0_bs[i] | a.out_bs[i] | (a.in1[i] ? a.in1_bs[i] : 0) | (a.res[i] ? a.res_bs[i] : 0)) & 3) return false;
+    }
+    return true;
+}
+
+int motif_conv_wino_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s) {
+    const int Cin_g = (d->C0 + d->C1) / d->groups, Cout_g = d->Cout / d->groups;
+    const int Ho = d->H, Wo = d->W;                      // pad 1
+    a.Ho = Ho; a.Wo = Wo; a.Cin_g = Cin_g; a.Cout_g = Cout_g;
+    a.Kpad = 12 * ((Cin_g + 15) / 16);
+    a.ncg = (Cout_g + 63) / 64;
+    a.tiles_x = (Wo + 31) / 32;
+    const int ncgG = d->groups * a.ncg, cus = wn_cu_count();
+    a.Cout = d->Cout;
+    a.CK = ncgG;
+    const long direct = motif_conv_split_packed_floats_direct(d);      // the Winograd block follows the direct one
+    for (int i = 0; i < MOTIF_MAX_PROBLEMS; ++i) a.wp[i] = a.wp[i] + direct;
+    const int tiles_y = (Ho + 7) / 8;
+    const long T = (long)a.tiles_x * ncgG * d->N * P * tiles_y;
+    if (T >= 0x7fffffffL) return MOTIF_ELIMIT;
+    const int G = (int)(T < cus ? T : cus);
+    const size_t ldsb = ((size_t)4 * 16 + (size_t)2 * 3 * (2 * 16 * 34 + 4) + (size_t)4 * 640) * 16;
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    conv_wino_kernel<<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of conv_wino_kernel from an instrumented (-DMOTIF_TRACE) build of the library:
+   MOTIF_HIP_LIB=tools/_trace/libmotif_hip.so python tools/trace_s2.py [shape index]
+   slots: 0 start, 1 prologue done (first chunk staged), then one per chunk (after its barrier) and one per tile epilogue, 31 end"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from motif_amd import _lib, ops
+from motif_amd.models.modules.layers import Conv2d
+from tools.conv_bench import SHAPES
+
+n, ci, co, k, s, h, w = SHAPES[int(sys.argv[1]) if len(sys.argv) > 1 else 0]
+m = Conv2d(ci, co, k, s, k // 2).cuda()
+x = torch.randn(n, ci, h, w, device="cuda")
+res = torch.randn(n, co, h // s, w // s, device="cuda") if os.environ.get("RES") else None
+kw = dict(act=1, res=res, res_mode=1) if res is not None else dict(act=1)
+for _ in range(3):
+    y = m(x, **kw)
+torch.cuda.synchronize()
+ops.set_option("conv_engine", 5)
+for _ in range(2):
+    y = m(x, **kw)
+torch.cuda.synchronize()
+lib = _lib.load()
+nb = 1024
+buf = (ctypes.c_longlong * (nb * 4 * 32))()
+lib.motif_debug_wino_trace.restype = ctypes.c_int
+rc = lib.motif_debug_wino_trace(buf, nb * 4 * 32)
+t = np.frombuffer(buf, dtype=np.int64).reshape(nb, 4, 32).astype(np.float64)[:256]
+ok = t[:, :, 1] > 0
+nch = (ci + 15) // 16
+print("rc", rc, "shape", (n, ci, co, h, w), "blocks traced", int(ok[:, 0].sum()), "chunks per tile", nch)
+print("prologue %.2f kcyc" % ((t[:, :, 1] - t[:, :, 0])[ok].mean() / 1e3))
+names = []
+while len(names) < 28:
+    names += ["chunk %d" % c for c in range(nch)] + ["epilogue"]
+for sl in range(2, 30):
+    v = ok & (t[:, :, sl] > 0)
+    if not v.any():
+        break
+    d = (t[:, :, sl] - t[:, :, sl - 1])[v]
+    print("  %-9s %6.2f kcyc  (p10 %6.2f  p90 %6.2f)  blocks %d" % (names[sl - 2], d.mean() / 1e3, np.percentile(d, 10) / 1e3, np.percentile(d, 90) / 1e3, int(v[:, 0].sum())))
+print("block duration mean %.2f kcyc, max %.2f" % ((t[:, :, 31] - t[:, :, 0])[ok].mean() / 1e3, (t[:, :, 31] - t[:, :, 0])[ok].max() / 1e3))
+
+buf2 = (ctypes.c_longlong * (256 * 4 * 8 * 8))()
+lib.motif_debug_wino_trace2.restype = ctypes.c_int
+rc = lib.motif_debug_wino_trace2(buf2, 256 * 4 * 8 * 8)
+t2 = np.frombuffer(buf2, dtype=np.int64).reshape(256, 4, 8, 8).astype(np.float64)
+print("per super-step (cycles): chunk | ss0 .. ss5 | total   [mean over blocks and waves]")
+for c in range(8):
+    d = t2[:, :, c, 1:7] - t2[:, :, c, 0:6]
+    okc = (t2[:, :, c, 0] > 0) & (t2[:, :, c, 6] > 0)
+    if okc.any():
+        print("  staged chunk %d: %s | %6.0f" % (c, " ".join("%6.0f" % d[..., i][okc].mean() for i in range(6)), (t2[:, :, c, 6] - t2[:, :, c, 0])[okc].mean()))
+for wv in range(4):
+    d = t2[:, wv, 1, 1:7] - t2[:, wv, 1, 0:6]
+    print("  wave %d chunk 1: %s" % (wv, " ".join("%6.0f" % d[:, i].mean() for i in range(6))))
