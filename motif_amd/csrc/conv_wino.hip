@@ -8,21 +8,31 @@
 //     V3 = d1 - d3     U3 = g2
 // i.e. 4 x 3 = 12 k-steps per 16-channel chunk and row PAIR instead of 2 x 9 = 18.  The transform is along y only: along x the
 // kernel stays a direct convolution, so a B fragment is still one ds_read_b128 at an immediate column offset, the C/D layout of an
-// output row is the one of the direct kernels (shared epilogue), and the 2-D form's operand traffic (no fragment reuse at all: one
-// 1 KB fragment per MFMA) and 256-register accumulator set are avoided.  U is formed in fp64 from the fp32
-// weights and split into three bf16 parts at pack time; V is one fp32 addition per value, then the same exact 3-way split as the
-// direct kernels.  Rounding differs from the direct form by that one addition per operand and by the three-term output sums
-// (tests/test_kernels_gpu.py: error against fp64 <= 3x the fp32-MFMA engine's).
+// output row is the one of the direct kernels, and the 2-D form's operand traffic (no fragment reuse at all: one 1 KB fragment per
+// MFMA) and 256-register accumulator set are avoided.  U is formed in fp64 from the fp32 weights and split
+// into three bf16 parts at pack time; V is one fp32 addition per value, then the same exact 3-way split as the direct kernels.
+// Rounding differs from the direct form by that one addition per operand and by the three-term output sums.
 //
-// Shape: workgroup = 4 waves, ONE WAVE PER SIMD (512 registers per lane: 128 accumulators + operands two k-steps ahead + a whole
-// chunk's staging in flight), tile = 8 rows x 32 columns x 64 couts.  MFMA role of wave (ct, tp): cout tile ct x row pairs 2tp,
-// 2tp+1 (8 accumulators = [pair][position]).  Staging role of wave w: row pair T = w -- it fetches the pair's 4 input rows of the
-// next 16-channel chunk as 16-byte row pieces (range-checked buffer loads: zeros outside the image and past Cin), parks them in its
-// private landing area, reads them back pixel-major, forms V (one lane = one pixel x 8 channels x 4 positions), splits and writes
-// the staging buffer [part][octet][pair][position][34 px] x 8 bf16.  The two halo columns of the pair (4 items of 32 values) are
-// done channel-parallel, one (position, channel pair) per lane.  Every wave runs the same statically scheduled stream: after each
-// MFMA at most one operand request and one staging piece of <= 4 instructions (WSched), pinned with sched_barrier(0).
-// Persistent workgroups (tile = b' + i * G, XCD-aware b'), the next tile's first chunk staged under the current tile's last one.
+// Shape: workgroup = 4 waves, ONE WAVE PER SIMD (512 registers per lane), tile = 8 rows x 32 columns x 64 couts.  MFMA role of wave
+// (ct, tp): cout tile ct x row pairs 2tp, 2tp+1 (8 accumulators = [pair][position]).  Staging role of wave w: row pair T = w -- it
+// fetches the pair's 4 input rows of a 16-channel chunk as 16-byte row pieces (range-checked buffer loads: zeros outside the image
+// and past Cin), parks them in its private landing area, reads them back pixel-major, forms V (one lane = one pixel x 8 channels x
+// 4 positions), splits and writes the staging buffer [part][octet][pair][position][34 px] x 8 bf16; the two halo columns of the pair
+// are done channel-parallel, one (position, channel pair) per lane.
+//
+// A lone wave hides nothing behind another wave, so EVERYTHING is a statically scheduled filler of the MFMA stream (what the
+// stream tolerates was measured with tools/ubench_lone*.hip: <= 4 independent vector instructions per MFMA are free, a dependent
+// one costs ~8 cycles, v_pk_add_f32 ~12 that do NOT overlap, a 1 KB load 64 cycles of the CU's L1 path (16 per wave), LDS stores 13):
+//   * the (tile, chunk) pairs of a persistent workgroup form one flat stream of steps; during step s the wave multiplies step s,
+//     parks / transforms / splits step s+1 (loaded during step s-1) and requests the raw rows of step s+2;
+//   * a chunk is 6 super-steps (position pair, kx) of 24 MFMAs; B fragments have ONE register copy (a part's registers take the
+//     next super-step's fragment as soon as its last product is issued), weight fragments are two super-steps ahead, vector-memory
+//     requests are never in adjacent slots;
+//   * the epilogue of a tile is exposed (carrying it under the next tile's chunks needs 64 holding registers on top of the 128
+//     accumulators and ~300 operand / staging registers: hipcc spilled 400 of them) but short: inverse transform + bias in the C/D
+//     layout, four 8-cout passes through the wave's landing area (two 4 KB halves: pass p+1 is written before pass p is read back),
+//     residual quads requested two passes ahead, 16-byte stores as inline assembly the wait-count pass does not see (a pending
+//     store would turn every counted wait for a load -- the next step's row pieces and weights are in flight -- into vmcnt(0)).
 #include "conv_wave_epilogue.h"
 #include <utility>
 
@@ -30,7 +40,7 @@
 __device__ long long g_wn_trace[1024 * 4 * 32];
 #define WNTRACE(slot) do { if (lane == 0 && blockIdx.x < 1024) g_wn_trace[(blockIdx.x * 4 + wave) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int motif_debug_wino_trace(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wn_trace), sizeof(long long) * n); }
-// per-super-step stamps of the first 8 staged chunks of a workgroup: [block][wave][chunk][7]
+// per-super-step stamps of the first 8 chunks of a workgroup: [block][wave][chunk][7]
 __device__ long long g_wn_trace2[256 * 4 * 8 * 8];
 extern "C" int motif_debug_wino_trace2(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wn_trace2), sizeof(long long) * n); }
 #else
@@ -39,7 +49,7 @@ extern "C" int motif_debug_wino_trace2(long long* host, int n) { return (int)hip
 
 #ifndef WINO_ABL
 #define WINO_ABL 0        // ablation builds (tools/wino_ablate.sh): bit 0 no loads, 1 no parks, 2 no read-back, 3 no transform/split,
-#endif                    // 4 no staging stores, 5 no halo item, 6 no B fragments, 7 no weight fragments, 8 no epilogue
+#endif                    // 4 no staging stores, 5 no halo item, 6 no B fragments, 7 no weight fragments, 8 no epilogue pieces
 
 namespace {
 // Products ordered by ACTIVATION part, smallest part first (w = weight part, x = activation part).
@@ -49,26 +59,47 @@ struct WOrder {
     static constexpr int x[6] = {2, 1, 1, 0, 0, 0};
 };
 
-enum { WP_LOAD = 1, WP_PARK = 2, WP_READ = 3, WP_X = 4, WP_W = 5, WP_HREAD = 6, WP_HX = 7, WP_HW = 8 };
+enum { WP_PARK = 2, WP_READ = 3, WP_X = 4, WP_W = 5, WP_HREAD = 6, WP_HX = 7, WP_HW = 8 };
 
-// Static schedule of a chunk: 6 super-steps (position pair, kx) of M = 24 MFMAs = product x (position of the pair, row pair): FOUR
-// accumulators in rotation -- a dependent v_mfma_f32_32x32x16_bf16 issues ~86 cycles after its producer, so with the two accumulators
-// of one position an MFMA-only stream runs at 42.8 cycles per MFMA instead of 32-36 (measured).
-// Slot s = ss * M + m follows MFMA m of super-step ss.
-//   slots 0..11:  B fragments of the NEXT super-step (a second register set), smallest activation part first;
-//   slots 12..17: weight fragments of the super-step after next (a third set);
-//   ext[s]: staging piece of the NEXT chunk, kind << 8 | index -- loads first, parks one super-step later, then the read-back, the
-//           halo reads, per position 13 transform/split stages of <= 4 INDEPENDENT instructions each + 3 stores, the halo item last
-//           (dependent instructions sit in different slots: a lone wave issues a dependent vector instruction only ~8 cycles later).
+// Static schedule of a chunk: 6 super-steps (position pair, kx) of M = 24 MFMAs = product x (position of the pair, row pair), four
+// accumulators in rotation.  Slot s = ss * M + m follows MFMA m of super-step ss and holds at most one request of each kind and one
+// staging piece.  Every operand register has ONE copy per prefetch depth and is re-requested right after the last product that
+// reads it:
+//   rb[s]:  B fragment (part * 4 + j) of the NEXT super-step (part 2 after MFMAs 0..3, part 1 after 8..11, part 0 after 20..23);
+//   ra[s]:  weight fragment (position of the pair * 3 + part) of the super-step THREE ahead, into the set in use (three sets): part 2
+//           after MFMAs 13 / 15, part 1 after 17 / 19, part 0 after 21 / 23 -- ~2.2 super-steps (~2 k cycles) before its first use.
+//           vmcnt retires in order, so a weight fragment can only be consumed once every OLDER load has returned, raw row pieces
+//           included (first touches of another XCD's output: ~2 k cycles); hence
+//   rl[s]:  raw row piece i of the step after next is requested as soon as its landing registers are free (two slots after its
+//           park): it then has >= four super-steps before the next chunk parks it, and the weight fragments requested behind it are
+//           not needed for two.  Parks and requests are spread over super-steps 0 and 1: 14 one-KB requests in one super-step are
+//           900 cycles of the CU's L1 path, 40 ds_write_b128 of four waves 500 of the LDS store path.
+//   ext[s]: staging piece of the NEXT step: parks (every fourth slot of super-steps 0 and 1), read-back, halo reads, per position 13
+//           transform / split stages of <= 4 INDEPENDENT instructions + 3 stores, the halo item last.
 struct WSched {
     static constexpr int SS = 6, M = 24, S = SS * M, NLD = 10;
-    int ext[S], used;
-    constexpr WSched() : ext(), used(0) {
-        for (int s = 0; s < S; ++s) ext[s] = 0;
+    int rb[S], ra[S], rl[S], ext[S], used, clash;
+    constexpr WSched() : rb(), ra(), rl(), ext(), used(0), clash(0) {
+        for (int s = 0; s < S; ++s) { rb[s] = -1; ra[s] = -1; rl[s] = -1; ext[s] = 0; }
+        constexpr int aslot[6] = {13, 15, 17, 19, 21, 23};            // (pi 0, part 2), (pi 1, part 2), (0, 1), (1, 1), (0, 0), (1, 0)
+        for (int ss = 0; ss < SS; ++ss) {
+            if (ss + 1 < SS) {
+                for (int j = 0; j < 4; ++j) {
+                    rb[ss * M + j] = 2 * 4 + j;
+                    rb[ss * M + 8 + j] = 1 * 4 + j;
+                    rb[ss * M + 20 + j] = 0 * 4 + j;
+                }
+            }
+            for (int i = 0; i < 6; ++i) ra[ss * M + aslot[i]] = (i & 1) * 3 + (2 - (i >> 1));
+        }
         int f = 0;
-        for (int i = 0; i < NLD; ++i) ext[f++] = (WP_LOAD << 8) | i;
-        f = M;
-        for (int i = 0; i < NLD; ++i) ext[f++] = (WP_PARK << 8) | i;
+        int pslot[NLD] = {};
+        for (int i = 0; i < NLD; ++i) { ext[f] = (WP_PARK << 8) | i; pslot[i] = f; f += 4; }
+        for (int i = 0; i < NLD; ++i) {
+            const int ls = pslot[i] + 2;                                         // a row piece is requested right after its park
+            if (rl[ls] >= 0 || ra[ls] >= 0) clash = 1;
+            rl[ls] = i;
+        }
         for (int r = 0; r < 16; ++r) ext[f++] = (WP_READ << 8) | r;
         for (int r = 0; r < 2; ++r) ext[f++] = (WP_HREAD << 8) | r;
         for (int pos = 0; pos < 4; ++pos)
@@ -78,13 +109,14 @@ struct WSched {
         used = f;
     }
 };
+
 // Scalar fp32 add / subtract the compiler cannot pair into v_pk_add_f32: a packed add costs a lone wave ~12 cycles that do NOT
 // overlap its MFMA stream (tools/ubench_lone.hip: 2 per MFMA -> 55 cycles per MFMA), two plain ones 8 that do.
 __device__ __forceinline__ float fadd1(float a, float b) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float fsub1(float a, float b) { float r; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 constexpr WSched kWSched{};
-static_assert(kWSched.used <= WSched::S, "staging pieces do not fit the slots of a chunk");
+static_assert(kWSched.used <= WSched::S && kWSched.clash == 0, "pieces do not fit the slots of a chunk");
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) -- every slot of the schedule is its own
 // instantiation (the loop unroller's size estimate, taken before the dispatch on the slot's piece is folded, refuses 144 slots)
@@ -94,6 +126,9 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 }  // namespace
 
+// MULTI: more than one problem in the launch (the per-problem argument selects are ~100 scalar instructions per tile: a lone wave
+// hides none of them).
+template <bool MULTI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino_kernel(ConvArgs a, int ntiles, int tiles_y) {
     constexpr int NP = 3, WAVES = 4, TH = 8, PW = 34, OCT = 16 * PW;   // 16 (pair, position) planes of 34 pixels per octet
     constexpr int SLOTS = 2 * OCT + 4;                   // per part: [2 octets][16 planes][34] 16-byte slots (+ pad)
@@ -110,9 +145,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     const int G = gridDim.x, bq = xcd_block_id(blockIdx.x, G);
     if (bq >= ntiles) return;
-    const int nch = a.Kpad / 12;
+    const int nch = a.Kpad / 12;                                        // >= 2 (host)
     const int ncgG = a.CK;                                              // groups * ncg
     const int HW = a.H * a.W;
+    const unsigned HWo = (unsigned)(a.Ho * a.Wo);
 
     // tile coordinates as mixed-radix digits (cout group | column | row | image), advanced by G's digits: no division per tile
     struct TileC { int cgg, tx, ty, z; };
@@ -134,7 +170,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto decode = [&](const TileC& c, int& n, int& pz, int& g, int& cg, int& ty, int& tx) __attribute__((always_inline)) {
         tx = c.tx; ty = c.ty;
         g = a.ncg == ncgG ? 0 : c.cgg / a.ncg; cg = c.cgg - g * a.ncg;
-        pz = (c.z >= a.N) + (c.z >= 2 * a.N) + (c.z >= 3 * a.N); n = c.z - pz * a.N;
+        if constexpr (MULTI) { pz = (c.z >= a.N) + (c.z >= 2 * a.N) + (c.z >= 3 * a.N); n = c.z - pz * a.N; }
+        else { pz = 0; n = c.z; }
+    };
+
+    // Per-problem launch arguments by CONSTANT index + scalar selects: a dynamic index into the kernel-argument arrays becomes a
+    // VECTOR load whose result every later use waits for with vmcnt(0) -- i.e. for all the row pieces and weight fragments in flight.
+    auto pick = [](const auto (&arr)[MOTIF_MAX_PROBLEMS], int pz) __attribute__((always_inline)) {
+        if constexpr (!MULTI) return arr[0];
+        else return pz == 0 ? arr[0] : pz == 1 ? arr[1] : pz == 2 ? arr[2] : arr[3];
     };
 
     // ---- per-lane constants of the staging role (row pair T = wave) ------------------------------------------------------
@@ -146,41 +190,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int h_rda = ((h_ra * 2 + h_oct) * 8 + 2 * h_pair) * 40 + (h_side ? 36 : 3);
     const int h_rdb = ((h_rb * 2 + h_oct) * 8 + 2 * h_pair) * 40 + (h_side ? 36 : 3);
     const int h_wr = (h_oct * OCT + (wave * 4 + h_pos) * PW + (h_side ? 33 : 0)) * 4 + h_pair;   // dword index within a part
+    // row piece i of a step: quad qd = i * 64 + lane = ((row * 2 + octet) * 8 + channel) * 10 + column quad.  pl = its byte offset from
+    // the tile's first staged pixel of the chunk's first plane, rx = (row | quad << 2) of the ten pieces packed six bits each.
+    int pl[NLD];
+    unsigned rx0 = 0, rx1 = 0;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int qd = i * 64 + lane;
+        const int xq = qd % 10, r = qd / 10, ch = r & 7, oct = (r >> 3) & 1, row = r >> 4;
+        pl[i] = ((8 * oct + ch) * HW + row * a.W + 4 * xq) * 4;
+        const unsigned f6 = (unsigned)(row | (xq << 2));
+        if (i < 5) rx0 |= f6 << (6 * i); else rx1 |= f6 << (6 * (i - 5));
+    }
 
-    // ---- staging plan of a tile (chunk-invariant) --------------------------------------------------------------------------
-    int doff[NLD];
+    // ---- load plan of the tile the row-piece requests currently target -----------------------------------------------------
+    unsigned vmask = 0;                                  // bit i: row piece i lies inside the image
+    int origin = 0;                                      // byte offset of the tile's first staged pixel within a plane (uniform)
     const float* in0n = nullptr; const float* in1n = nullptr;
     int st_g = 0;
-    float bias_v = 0.f;
     auto wptr = [&](const TileC& t) __attribute__((always_inline)) {
         int n, pz, g, cg, ty, tx;
         decode(t, n, pz, g, cg, ty, tx);
-        const u32x4* base = (const u32x4*)a.wp[pz] + (long)(g * a.ncg + cg) * a.Kpad * (NP * 2 * 64);
+        const u32x4* base = (const u32x4*)pick(a.wp, pz) + (long)(g * a.ncg + cg) * a.Kpad * (NP * 2 * 64);
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
     };
     const int wvoff = (ct * 64 + lane) * 16;
     auto wfrag = [&](__amdgpu_buffer_rsrc_t wb, int ks, int p) __attribute__((always_inline)) {
         return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wb, wvoff, (ks * NP + p) * (2 * 64 * 16), 0));
     };
-    auto setup_stage = [&](const TileC& t) __attribute__((always_inline)) {
+    auto bias_of = [&](const TileC& t) __attribute__((always_inline)) {
+        int n, pz, g, cg, ty, tx;
+        decode(t, n, pz, g, cg, ty, tx);
+        const float* bp = pick(a.bias, pz);
+        return (bp && lane < 32 && cg * 64 + ct * 32 + lane < a.Cout_g) ? bp[g * a.Cout_g + cg * 64 + ct * 32 + lane] : 0.f;
+    };
+    auto setup_loads = [&](const TileC& t, bool valid) __attribute__((always_inline)) {
         int n, pz, g, cg, ty, tx;
         decode(t, n, pz, g, cg, ty, tx);
         st_g = g;
-        in0n = a.in0[pz] + (long)n * a.in0_bs[pz];
-        in1n = a.in1[pz] ? a.in1[pz] + (long)n * a.in1_bs[pz] : nullptr;
-        const float* bp = a.bias[pz];
-        bias_v = (bp && lane < 32 && cg * 64 + ct * 32 + lane < a.Cout_g) ? bp[g * a.Cout_g + cg * 64 + ct * 32 + lane] : 0.f;
+        in0n = pick(a.in0, pz) + (long)n * pick(a.in0_bs, pz);
+        in1n = pick(a.in1, pz) ? pick(a.in1, pz) + (long)n * pick(a.in1_bs, pz) : nullptr;
         const int iy0 = ty * TH - 1 + 2 * wave, x0 = tx * 32 - 4;      // pad 1; rows start 4 pixels left of the tile: aligned quads
+        origin = (iy0 * a.W + x0) * 4;
+        if (valid && iy0 >= 0 && iy0 + 4 <= a.H && x0 >= 0 && x0 + 40 <= a.W) { vmask = 0x3ffu; return; }   // interior tile: every piece inside
+        vmask = 0;
+        const int rlo = iy0 < 0 ? -iy0 : 0, rhi = valid ? (a.H - iy0 < 4 ? a.H - iy0 : 4) : 0;
+        const int qlo = x0 < 0 ? 1 : 0, qhi = (a.W - x0) >> 2;         // W % 4 == 0, x0 % 4 == 0
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int qd = i * 64 + lane;
-            const int xq = qd % 10, r = qd / 10, ch = r & 7, oct = (r >> 3) & 1, row = r >> 4;
-            const int iy = iy0 + row, x = x0 + 4 * xq;
-            // BYTE offset from the chunk's first plane; 2^31 = "outside the image": beyond any descriptor's range, the load returns 0
-            doff[i] = (iy >= 0 && iy < a.H && x >= 0 && x < a.W) ? (iy * a.W + x + (8 * oct + ch) * HW) * 4 : (int)0x80000000;
+            const unsigned f6 = ((i < 5 ? rx0 >> (6 * i) : rx1 >> (6 * (i - 5)))) & 63u;
+            const int row = (int)(f6 & 3u), xq = (int)(f6 >> 2);
+            vmask |= (row >= rlo && row < rhi && xq >= qlo && xq < qhi) ? 1u << i : 0u;
         }
     };
-    // ---- the pieces of staging one 16-channel chunk ------------------------------------------------------------------------
+    // ---- the requests and pieces of staging one 16-channel chunk -----------------------------------------------------------
     f32x4 gq[NLD] = {};
     auto st_load = [&](int i, int c0) __attribute__((always_inline)) {                  // global -> registers: 4 pixels of one channel of one row
         const int gch0 = st_g * a.Cin_g + c0;
@@ -188,7 +251,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float* base = first ? in0n + (long)gch0 * HW : in1n + (long)(gch0 - a.C0) * HW;
         const int nchv = (first && in1n) ? a.C0 - c0 : a.Cin_g - c0;          // channels from c0 to the end of the group / of the first source
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nchv * HW * 4, 0x00020000);
-        gq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, doff[i], 0, 0));
+        // BYTE offset from the chunk's first plane; 2^31 = "outside the image": beyond any descriptor's range, the load returns 0
+        const int off = (vmask >> i) & 1u ? pl[i] + origin : (int)0x80000000;
+        gq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     };
     auto st_park = [&](int i) __attribute__((always_inline)) { *(f32x4*)(land + i * 64 + lane) = gq[i]; };
     float sv[4][8] = {};                                   // [input row of the pair][channel of the octet]
@@ -242,20 +307,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             hpk = pk_bf16(hv0, hv1);
             hparts[0] = hpk;
         } else if (h == 1) {
-            hv0 -= bf_lo(hpk); hv1 -= bf_hi(hpk);
+            hv0 = fsub1(hv0, bf_lo(hpk)); hv1 = fsub1(hv1, bf_hi(hpk));
         } else if (h == 2) {
             hpk = pk_bf16(hv0, hv1);
             hparts[1] = hpk;
             he0 = bf_lo(hpk); he1 = bf_hi(hpk);
         } else {
-            hparts[2] = pk_bf16(hv0 - he0, hv1 - he1);
+            hparts[2] = pk_bf16(fsub1(hv0, he0), fsub1(hv1, he1));
         }
     };
     auto st_hw = [&](int p, u32x4* dstbuf) __attribute__((always_inline)) { ((unsigned*)(dstbuf + p * SLOTS))[h_wr] = hparts[p]; };
-    auto piece = [&](auto ec, int c0, u32x4* dstbuf) __attribute__((always_inline)) {
+    auto piece = [&](auto ec, u32x4* dstbuf) __attribute__((always_inline)) {
         constexpr int e = decltype(ec)::value, kind = e >> 8, idx = e & 255;
-        if constexpr (kind == WP_LOAD) { if constexpr (!(WINO_ABL & 1)) st_load(idx, c0); }
-        else if constexpr (kind == WP_PARK) { if constexpr (!(WINO_ABL & 2)) st_park(idx); }
+        if constexpr (kind == WP_PARK) { if constexpr (!(WINO_ABL & 2)) st_park(idx); }
         else if constexpr (kind == WP_READ) { if constexpr (!(WINO_ABL & 4)) st_read(idx); }
         else if constexpr (kind == WP_X) { if constexpr (!(WINO_ABL & 8)) st_x(idx); }
         else if constexpr (kind == WP_W) { if constexpr (!(WINO_ABL & 16)) st_w(idx, dstbuf); }
@@ -264,12 +328,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         else if constexpr (kind == WP_HW) { if constexpr (!(WINO_ABL & 32)) st_hw(idx, dstbuf); }
     };
 
-#ifdef MOTIF_TRACE
-    int trace_chunk = 0;
-#endif
     f32x16 acc[2][4];                                    // [row pair of this wave][position]
-    constexpr int WB = 3;                                // weight fragments two super-steps ahead
+    constexpr int WB = 3;                                // weight fragment sets: a set is refilled for three super-steps ahead while in use
     u32x4 wf[WB][2][NP];                                 // [set][position of the pair][weight part]
+    u32x4 bfr[NP][4];                                    // [activation part][position of the pair * 2 + row pair]: ONE copy
     __amdgpu_buffer_rsrc_t wbase, wnext;
     auto wks = [](int ss, int pi) __attribute__((always_inline)) { return (2 * (ss / 3) + pi) * 3 + ss % 3; };   // packed k-step (position, kx) within a chunk
     auto loadw = [&](__amdgpu_buffer_rsrc_t wb, int ss, u32x4 (&dst)[2][NP]) __attribute__((always_inline)) {
@@ -278,69 +340,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int p = 0; p < NP; ++p) dst[pi][p] = wfrag(wb, wks(ss, pi), p);
     };
+#ifdef MOTIF_TRACE_SS
+    int trace_chunk = 0;
+#endif
 
-    // 6 super-steps of chunk c on staging buffer `buf`; STAGE: the pieces of chunk `sc` (source plan as set up) go to the other buffer,
-    // and the first two super-steps' weight fragments of that chunk (from `wn`) are requested during super-steps 4 and 5.
-    auto chunk_body = [&](int c, int buf, auto stage_tag, int sc, __amdgpu_buffer_rsrc_t wn) __attribute__((always_inline)) {
-        constexpr bool STAGE = decltype(stage_tag)::value;
+    // Chunk c of the current tile on staging buffer `buf` (ONE instantiation: a second body -- say with the constant 0 as C of each
+    // accumulator's first product -- gets its own accumulator registers, and 128 of them are copied at every transition).
+    // sc / wn: chunk index and weights of the NEXT step (staged into the other buffer; its first three super-steps' weight fragments
+    // are requested during super-steps 3 .. 5); lc0: first channel of the step after next (row pieces, per the load plan).
+    auto chunk_body = [&](int c, int buf, int sc, __amdgpu_buffer_rsrc_t wn, int lc0) __attribute__((always_inline)) {
         const u32x4* pb = stg0 + buf * STG + half * OCT + (tp * 8) * PW + l31;
         u32x4* dstbuf = stg0 + (buf ^ 1) * STG;
-        u32x4 bfr[2][NP][4];                             // [set][activation part][position of the pair * 2 + row pair]
         auto loadb = [&](int ss, int p, int j) __attribute__((always_inline)) {
-            bfr[ss & 1][p][j] = pb[p * SLOTS + ((j & 1) * 4 + 2 * (ss / 3) + (j >> 1)) * PW + (ss % 3)];
+            bfr[p][j] = pb[p * SLOTS + ((j & 1) * 4 + 2 * (ss / 3) + (j >> 1)) * PW + (ss % 3)];
         };
+        if constexpr (!(WINO_ABL & 64)) {
 #pragma unroll
-        for (int p = NP - 1; p >= 0; --p)
+            for (int p = NP - 1; p >= 0; --p)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) loadb(0, p, j);
-#ifdef MOTIF_TRACE
+                for (int j = 0; j < 4; ++j) loadb(0, p, j);
+        }
+#ifdef MOTIF_TRACE_SS
         long long ts[7];
 #endif
         static_for<SS * M>([&](auto ic) __attribute__((always_inline)) {
             constexpr int s = decltype(ic)::value, ss = s / M, m = s % M, k = m >> 2, j = m & 3, pi = j >> 1, tl = j & 1, pos = 2 * (ss / 3) + pi;
-#ifdef MOTIF_TRACE
-            if constexpr (m == 0 && STAGE) ts[ss] = __builtin_amdgcn_s_memtime();
+#ifdef MOTIF_TRACE_SS
+            if constexpr (m == 0) ts[ss] = __builtin_amdgcn_s_memtime();
 #endif
             acc[tl][pos] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ss % WB][pi][WOrder::w[k]]),
-                                                                   __builtin_bit_cast(bf16x8, bfr[ss & 1][WOrder::x[k]][j]), acc[tl][pos], 0, 0, 0);
-            if constexpr (m < 12 && ss + 1 < SS && !(WINO_ABL & 64)) loadb(ss + 1, 2 - m / 4, m & 3);
-            if constexpr (m >= 12 && m < 18 && !(WINO_ABL & 128)) {
-                constexpr int p = (m - 12) >> 1, qi = (m - 12) & 1;      // part-major: the leading weight parts of both positions first
-                if constexpr (ss + 2 < SS) wf[(ss + 2) % WB][qi][p] = wfrag(wbase, c * 12 + wks(ss + 2, qi), p);
-                else if constexpr (STAGE) wf[(ss + 2) % WB][qi][p] = wfrag(wn, sc * 12 + wks(ss + 2 - SS, qi), p);
+                                                                   __builtin_bit_cast(bf16x8, bfr[WOrder::x[k]][j]), acc[tl][pos], 0, 0, 0);
+            if constexpr (kWSched.rb[s] >= 0 && !(WINO_ABL & 64)) loadb(ss + 1, kWSched.rb[s] >> 2, kWSched.rb[s] & 3);
+            if constexpr (kWSched.ra[s] >= 0 && !(WINO_ABL & 128)) {
+                constexpr int qi = kWSched.ra[s] / 3, p = kWSched.ra[s] % 3;
+                if constexpr (ss + 3 < SS) wf[ss % WB][qi][p] = wfrag(wbase, c * 12 + wks(ss + 3, qi), p);
+                else wf[ss % WB][qi][p] = wfrag(wn, sc * 12 + wks(ss + 3 - SS, qi), p);
             }
-            if constexpr (STAGE) piece(std::integral_constant<int, kWSched.ext[s]>{}, sc * 16, dstbuf);
+            if constexpr (kWSched.rl[s] >= 0 && !(WINO_ABL & 1)) st_load(kWSched.rl[s], lc0);
+            piece(std::integral_constant<int, kWSched.ext[s]>{}, dstbuf);
             __builtin_amdgcn_sched_barrier(0);
         });
-#ifdef MOTIF_TRACE
-        if constexpr (STAGE) {
-            ts[6] = __builtin_amdgcn_s_memtime();
-            if (lane == 0 && blockIdx.x < 256 && trace_chunk < 8) {
+#ifdef MOTIF_TRACE_SS
+        ts[6] = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && blockIdx.x < 256 && trace_chunk < 8) {
 #pragma unroll
-                for (int i = 0; i < 7; ++i) g_wn_trace2[((blockIdx.x * 4 + wave) * 8 + trace_chunk) * 8 + i] = ts[i];
-            }
-            ++trace_chunk;
+            for (int i = 0; i < 7; ++i) g_wn_trace2[((blockIdx.x * 4 + wave) * 8 + trace_chunk) * 8 + i] = ts[i];
         }
+        ++trace_chunk;
 #endif
-    };
-    auto epilogue = [&](const TileC& t) __attribute__((always_inline)) {
-        int n, pz, g, cg, ty, tx;
-        decode(t, n, pz, g, cg, ty, tx);
-        const int cbase = g * a.Cout_g + cg * 64 + ct * 32, climit = a.Cout_g - cg * 64 - ct * 32;
-        if (climit <= 0 || (WINO_ABL & 256)) return;
-        f32x16 o[4];                                     // output rows 4 tp .. 4 tp + 3 of the tile: the inverse transform
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-            o[2 * tl] = (acc[tl][0] + acc[tl][1]) + acc[tl][2];
-            o[2 * tl + 1] = (acc[tl][1] - acc[tl][2]) - acc[tl][3];
-        }
-        const long HWo = (long)a.Ho * a.Wo;
-        float* ob = a.out[pz] + (long)n * a.out_bs[pz] + (long)cbase * HWo;
-        const float* rb = a.res_mode ? a.res[pz] + (long)n * a.res_bs[pz] + (long)cbase * HWo : nullptr;
-        int lane_e = lane;
-        asm volatile("" : "+v"(lane_e));
-        if (a.res_mode) conv_epilogue_wave<4, 2, true>(a, o, bias_w, (float*)land, lane_e, cbase, climit, ty * TH + 4 * tp, tx * 32, rb, ob);
-        else conv_epilogue_wave<4, 2, false>(a, o, bias_w, (float*)land, lane_e, cbase, climit, ty * TH + 4 * tp, tx * 32, rb, ob);
     };
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -350,41 +397,158 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[tl][p][r] = 0.f;
     };
+    // After a tile's last chunk: inverse transform + bias in the C/D layout, then four passes of 8 couts x 4 rows x 32 pixels through
+    // the landing area (free between the last read-back and the next chunk's parks): lane item it of a pass = cout half + 2 it, row
+    // l31 / 8, columns 4 (l31 % 8) .. + 3 -- residual, activation, one 16-byte store.
+    auto finish_tile = [&](const TileC& t) __attribute__((always_inline)) {
+        int n, pz, g, cg, ty, tx;
+        decode(t, n, pz, g, cg, ty, tx);
+        const int cb = g * a.Cout_g + cg * 64 + ct * 32, cl = a.Cout_g - cg * 64 - ct * 32;
+        if (cl <= 0 || (WINO_ABL & 256)) { zero_acc(); return; }        // the upper cout tile of a partial group has nothing to store
+        const long HWol = (long)a.Ho * a.Wo;
+        const unsigned long long obv = (unsigned long long)(pick(a.out, pz) + (long)n * pick(a.out_bs, pz) + (long)cb * HWol);
+        const unsigned ob_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(obv >> 32)), ob_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)obv);
+        const unsigned long long obp = ((unsigned long long)ob_hi << 32) | (unsigned long long)ob_lo;      // uniform: the stores take it in SGPRs
+        const float* rb = a.res_mode ? pick(a.res, pz) + (long)n * pick(a.res_bs, pz) + (long)cb * HWol : nullptr;
+        const int rm = a.res_mode;
+        int lane_e = lane;                               // opaque copy: keeps the per-lane geometry inside the tile loop
+        asm volatile("" : "+v"(lane_e));
+        const int hf = lane_e >> 5, l5 = lane_e & 31;
+        const int oy = ty * TH + 4 * tp + (l5 >> 3), ox = tx * 32 + (l5 & 7) * 4;
+        const bool okl = oy < a.Ho && ox < a.Wo;
+        const unsigned lb = (unsigned)hf * HWo + (unsigned)(oy * a.Wo + ox);
+        auto okv = [&](int pass, int it) __attribute__((always_inline)) { return okl && 8 * pass + 2 * it + hf < cl; };
+        auto offv = [&](int pass, int it) __attribute__((always_inline)) { return lb + (unsigned)(8 * pass + 2 * it) * HWo; };
+        // all 16 residual quads are requested before the inverse transform (first touches of another XCD's output: ~2 k cycles; the
+        // operand registers of the main loop are free here)
+        f32x4 rv[4][4];
+        auto load_res = [&](int pass) __attribute__((always_inline)) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) rv[pass][it] = *(const f32x4*)(rb + (okv(pass, it) ? offv(pass, it) : 0u));   // masked lanes read element 0
+        };
+        if (rm) { load_res(0); load_res(1); load_res(2); load_res(3); }
+        float bv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b4 = *(const f32x4*)(bias_w + 8 * q + 4 * hf);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bv[4 * q + u] = b4[u];
+        }
+        f32x16 o[4];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o[2 * tl][r] = ((acc[tl][0][r] + acc[tl][1][r]) + acc[tl][2][r]) + bv[r];
+                o[2 * tl + 1][r] = ((acc[tl][1][r] - acc[tl][2][r]) - acc[tl][3][r]) + bv[r];
+            }
+        zero_acc();
+        float* scr = (float*)land;                       // two halves of [8 couts][4 rows x 32 px]
+        const int ew = hf * 512 + l5, er = hf * 128 + (l5 >> 3) * 32 + (l5 & 7) * 4;
+        auto write_pass = [&](int pass) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r3 = 0; r3 < 4; ++r3) scr[(pass & 1) * 1024 + ew + r3 * 128 + j * 32] = o[j][4 * pass + r3];
+        };
+        // AC / RM >= 0: activation / residual mode known at compile time (the common layers: one straight-line body, no per-item
+        // scalar branches -- 16 items x the generic chain of wave-uniform tests cost a lone wave ~2 k cycles); -1: run-time switches.
+        auto passes = [&](auto ac_tag, auto rm_tag) __attribute__((always_inline)) {
+            constexpr int AC = decltype(ac_tag)::value, RM = decltype(rm_tag)::value;
+            const int rmv = RM >= 0 ? RM : rm;
+            const unsigned long long obq = obp;
+            write_pass(0);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                if (pass + 1 < 4) write_pass(pass + 1);
+                const int ac = AC >= 0 ? AC : ((a.act_split > 0 && cb + 8 * pass >= a.act_split) ? a.act2 : a.act);      // uniform per pass
+                f32x4 v[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) v[it] = *(const f32x4*)(scr + (pass & 1) * 1024 + er + it * 256);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    if (rmv == 1) v[it] += rv[pass][it];
+                    if constexpr (AC == MOTIF_ACT_RELU) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[it][q] = v[it][q] > 0.f ? v[it][q] : 0.f;
+                    } else if constexpr (AC == MOTIF_ACT_LRELU) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[it][q] = v[it][q] > 0.f ? v[it][q] : 0.1f * v[it][q];
+                    } else if constexpr (AC < 0) v[it] = act_uniform(v[it], ac);
+                    if (rmv == 2) v[it] += rv[pass][it];
+                    else if (rmv == 3) {
+                        v[it] += rv[pass][it];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[it][q] = v[it][q] > 0.f ? v[it][q] : 0.f;
+                    } else if (rmv == 4) v[it] *= rv[pass][it];
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    if (okv(pass, it)) {
+                        const unsigned bo = offv(pass, it) * 4u;
+                        const f32x4 val = v[it];
+                        asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(bo), "v"(val), "s"(obq) : "memory");
+                    }
+            }
+        };
+        using I = std::integral_constant<int, 0>;
+        const int act = a.act;
+        if (a.act_split > 0) passes(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
+        else if (rm == 0 && act == MOTIF_ACT_NONE) passes(std::integral_constant<int, MOTIF_ACT_NONE>{}, I{});
+        else if (rm == 0 && act == MOTIF_ACT_RELU) passes(std::integral_constant<int, MOTIF_ACT_RELU>{}, I{});
+        else if (rm == 0 && act == MOTIF_ACT_LRELU) passes(std::integral_constant<int, MOTIF_ACT_LRELU>{}, I{});
+        else if (rm == 1 && act == MOTIF_ACT_NONE) passes(std::integral_constant<int, MOTIF_ACT_NONE>{}, std::integral_constant<int, 1>{});
+        else if (rm == 1 && act == MOTIF_ACT_LRELU) passes(std::integral_constant<int, MOTIF_ACT_LRELU>{}, std::integral_constant<int, 1>{});
+        else if (rm == 2 && act == MOTIF_ACT_RELU) passes(std::integral_constant<int, MOTIF_ACT_RELU>{}, std::integral_constant<int, 2>{});
+        else passes(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
+    };
 
-    // ---- prologue: first chunk of the first tile (nothing to hide it under) ------------------------------------------------
+    // ---- prologue: step 0 staged in full, the row pieces of step 1 requested (nothing to hide them under) --------------------
     int t = bq;
     TileC tc = coords_of(__builtin_amdgcn_readfirstlane(t)), tn = tc;
     WNTRACE(0);
-    setup_stage(tc);
+    zero_acc();
+    setup_loads(tc, true);
     wbase = wnext = wptr(tc);
     loadw(wbase, 0, wf[0]);
     loadw(wbase, 1, wf[1]);
-    static_for<WSched::S>([&](auto ic) __attribute__((always_inline)) { piece(std::integral_constant<int, kWSched.ext[decltype(ic)::value]>{}, 0, stg0); });
+    loadw(wbase, 2, wf[2]);
+    float bias_v = bias_of(tc);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) st_load(i, 0);
+    static_for<WSched::S>([&](auto ic) __attribute__((always_inline)) { piece(std::integral_constant<int, kWSched.ext[decltype(ic)::value]>{}, stg0); });
     if (lane < 32) bias_w[lane] = bias_v;
-    zero_acc();
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) st_load(i, 16);        // nch >= 2: step 1 is chunk 1 of this tile
     __syncthreads();
     WNTRACE(1);
 
-    // ---- persistent tile loop ----------------------------------------------------------------------------------------------
+    // ---- persistent tile loop ------------------------------------------------------------------------------------------------
     int buf = 0, slot = 2;
     for (;;) {
         const int t_next = t + G;
         const bool has_next = t_next < ntiles;
         for (int c = 0; c < nch; ++c) {
+            if (c == nch - 2) {                          // from here on the row-piece requests belong to the next tile
+                if (has_next) { tn = advance(tc); wnext = wptr(tn); bias_v = bias_of(tn); } else wnext = wbase;
+                setup_loads(tn, has_next);
+            }
             const bool last = c + 1 == nch;
-            if (last && has_next) { tn = advance(tc); setup_stage(tn); wnext = wptr(tn); }
-            if (!last || has_next) chunk_body(c, buf, std::true_type{}, last ? 0 : c + 1, last ? wnext : wbase);
-            else chunk_body(c, buf, std::false_type{}, 0, wbase);
+            const int sc = last ? 0 : c + 1, lc0 = (c + 2 < nch ? c + 2 : c + 2 - nch) * 16;
+            const __amdgpu_buffer_rsrc_t wn = last ? wnext : wbase;
+            chunk_body(c, buf, sc, wn, lc0);
+            if (slot < 29) WNTRACE(slot);                // trace: body end | epilogue end | barrier passed, for the first 9 chunks
+            if (last) {
+                finish_tile(tc);
+                if (lane < 32) bias_w[lane] = bias_v;    // the next tile's bias (this tile's has just been read)
+            }
+            if (slot < 29) WNTRACE(slot + 1);
             __syncthreads();
             buf ^= 1;
-            if (slot < 30) { WNTRACE(slot); ++slot; }
+            if (slot < 29) { WNTRACE(slot + 2); slot += 3; }
         }
-        epilogue(tc);
-        if (slot < 30) { WNTRACE(slot); ++slot; }
         if (!has_next) break;
         t = t_next; tc = tn; wbase = wnext;
-        if (lane < 32) bias_w[lane] = bias_v;
-        zero_acc();
     }
     WNTRACE(31);
 }
@@ -457,6 +621,7 @@ bool motif_conv_wino_eligible(const MotifConvDesc* d, const ConvArgs& a, int P) 
     if ((long)((d->C0 + d->C1) / d->groups) * HW * 4 >= 0x7fffffffL) return false;
     if (d->act_split > 0 && ((d->act_split & 7) || (d->groups > 1 && (Cout_g & 7)))) return false;
     if (d->C1 > 0 && (d->groups != 1 || d->C0 % 16)) return false;
+    if ((d->C0 + d->C1) / d->groups <= 16) return false;               // the kernel's step pipeline looks two chunks ahead within a tile
     for (int i = 0; i < P; ++i) {
         unsigned long long bits = (unsigned long long)a.in0[i] | (unsigned long long)a.out[i] | (unsigned long long)a.in1[i] | (unsigned long long)a.res[i];
         if (bits & 15) return false;
@@ -482,9 +647,10 @@ int motif_conv_wino_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream
     if (T >= 0x7fffffffL) return MOTIF_ELIMIT;
     const int G = (int)(T < cus ? T : cus);
     const size_t ldsb = ((size_t)4 * 16 + (size_t)2 * 3 * (2 * 16 * 34 + 4) + (size_t)4 * 640) * 16;
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(P > 1 ? (const void*)conv_wino_kernel<true> : (const void*)conv_wino_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    conv_wino_kernel<<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+    if (P > 1) conv_wino_kernel<true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+    else conv_wino_kernel<false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

@@ -32,15 +32,14 @@ ok = t[:, :, 1] > 0
 nch = (ci + 15) // 16
 print("rc", rc, "shape", (n, ci, co, h, w), "blocks traced", int(ok[:, 0].sum()), "chunks per tile", nch)
 print("prologue %.2f kcyc" % ((t[:, :, 1] - t[:, :, 0])[ok].mean() / 1e3))
-names = []
-while len(names) < 28:
-    names += ["chunk %d" % c for c in range(nch)] + ["epilogue"]
-for sl in range(2, 30):
-    v = ok & (t[:, :, sl] > 0)
-    if not v.any():
-        break
-    d = (t[:, :, sl] - t[:, :, sl - 1])[v]
-    print("  %-9s %6.2f kcyc  (p10 %6.2f  p90 %6.2f)  blocks %d" % (names[sl - 2], d.mean() / 1e3, np.percentile(d, 10) / 1e3, np.percentile(d, 90) / 1e3, int(v[:, 0].sum())))
+lab = ["body->end", "epilogue", "barrier"]
+for i in range(9):
+    row = []
+    for k3 in range(3):
+        sl = 2 + 3 * i + k3
+        v = ok & (t[:, :, sl] > 0) & (t[:, :, sl - 1] > 0)
+        row.append("%s %6.2f" % (lab[k3] if k3 else "chunk(from prev stamp)", ((t[:, :, sl] - t[:, :, sl - 1])[v].mean() / 1e3) if v.any() else float("nan")))
+    print("  iteration %d (chunk %d): %s" % (i, i % nch, " | ".join(row)))
 print("block duration mean %.2f kcyc, max %.2f" % ((t[:, :, 31] - t[:, :, 0])[ok].mean() / 1e3, (t[:, :, 31] - t[:, :, 0])[ok].max() / 1e3))
 
 buf2 = (ctypes.c_longlong * (256 * 4 * 8 * 8))()
