@@ -136,8 +136,17 @@ def pack(store, key, t, limit=300_000):
 
 
 def run_case(net, name, h, w, scale, n_times, batch=1, seed=0, n_frames=4, pad_to=None, oracle_cls=MotifRef, time_idx=None,
-             numeric_scale=False):
-    sample = synthetic_sample(h, w, scale, n_times, n_frames=n_frames, batch=batch, seed=seed)
+             numeric_scale=False, out_hw=None, alpha=None):
+    """out_hw: target size given directly (a NON-INTEGER scale per axis: the literal nearbyint gather of Ours.py:525-528, 699-704);
+    alpha: value of the learnable reliability exponent for this run (Ours.py:509, 794: alpha > 0 makes e^z > 1, so the max plane
+    and the `== 1.0 -> 0` patch of Ours.py:827-830 vary); both the reference and the restatement get it, the fixture records it."""
+    sample = synthetic_sample(h, w, scale if out_hw is None else 1, n_times, n_frames=n_frames, batch=batch, seed=seed)
+    if out_hw is not None:
+        sample["scale"] = [[int(out_hw[0])], [int(out_hw[1])]]
+    alpha_before = float(net.alpha.detach())
+    if alpha is not None:
+        with torch.no_grad():
+            net.alpha.fill_(alpha)
     if time_idx is not None:                      # Ours_44 renders one timestamp per call (VideoSR_base_model.py:182-187)
         sample["time"] = [sample["time"][i] for i in time_idx]
         n_times = len(time_idx)
@@ -171,6 +180,10 @@ def run_case(net, name, h, w, scale, n_times, batch=1, seed=0, n_frames=4, pad_t
 
     # the oracle restatement on the same inputs, compared stage by stage
     orc = fill_state_dict(oracle_cls().eval())
+    if alpha is not None:
+        with torch.no_grad():
+            orc.alpha.fill_(alpha)
+            net.alpha.fill_(alpha_before)
     ost = {}
     with torch.no_grad():
         o_out, o_flow, _ = orc(sample["LQs"], None, sample["time"], sample["scale"], use_GT=False, iter=4, stages=ost)
@@ -190,7 +203,8 @@ def run_case(net, name, h, w, scale, n_times, batch=1, seed=0, n_frames=4, pad_t
 
     store = {"LQs": sample["LQs"].numpy(), "times": torch.stack(sample["time"], 0).numpy(),
              "scale": np.array([out.shape[-2], out.shape[-1]], dtype=np.int64),
-             "iters": np.array(4), "torch_version": np.array(torch.__version__)}
+             "iters": np.array(4), "torch_version": np.array(torch.__version__),
+             "alpha": np.array(alpha_before if alpha is None else alpha, dtype=np.float32)}
     pack(store, "out", out)
     pack(store, "flow", flow)
     for k in ("raft_flow", "encoder", "flow_process", "flow_imnet", "imnet", "fwarp", "fwarp_norm", "fwarp_max", "fwarp_count"):
@@ -350,6 +364,14 @@ def variants():
     json.dump(rep, open(os.path.join(HERE, "restatement_vs_reference_4frame.json"), "w"), indent=1)
 
 
+def round4_cases(net, reports):
+    """VERDICT r3 #2: a reference-run golden at a non-integer scale (64x64 -> 160x168: 2.5 x 2.625) and two with alpha > 0."""
+    reports["lr64_to160x168_n3"] = run_case(net, "lr64_to160x168_n3", 64, 64, None, 3, seed=7, out_hw=(160, 168))
+    reports["lr32_s4_n3_alpha05"] = run_case(net, "lr32_s4_n3_alpha05", 32, 32, 4, 3, seed=8, alpha=0.5)
+    # with the synthetic weights relu(pred[2]) is small: at +0.5 only a few hundred cells leave max = 1; +20 (the init mirrored) moves most
+    reports["lr32_s4_n3_alpha20"] = run_case(net, "lr32_s4_n3_alpha20", 32, 32, 4, 3, seed=8, alpha=20.0)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -360,6 +382,7 @@ def main():
     reports["lr32_s4_n3"] = run_case(net, "lr32_s4_n3", 32, 32, 4, 3)
     reports["lr64_s2_n3"] = run_case(net, "lr64_s2_n3", 64, 64, 2, 3, seed=1)        # BASELINE config 1
     reports["lr32x48_s4_n2_b2"] = run_case(net, "lr32x48_s4_n2_b2", 32, 48, 4, 2, batch=2, seed=2)
+    round4_cases(net, reports)
     shell_case(net)
     pwc_case()
     corr_case()
@@ -377,6 +400,13 @@ if __name__ == "__main__":
         torch.set_num_threads(8)
         build_reference()
         corr_case()
+    elif "--round4-only" in sys.argv:
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        net, _ = build_reference()
+        rep = json.load(open(os.path.join(HERE, "restatement_vs_reference.json")))
+        round4_cases(net, rep)
+        json.dump(rep, open(os.path.join(HERE, "restatement_vs_reference.json"), "w"), indent=1)
     elif "--variants-only" in sys.argv:
         torch.manual_seed(0)
         torch.set_num_threads(8)

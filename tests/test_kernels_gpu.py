@@ -299,7 +299,8 @@ def test_conv_split2_persistent_tiles(shape, tile, keep_mma):
     finally:
         ops.set_option("conv_engine", 0)
     close(out, ref, 2e-5, 2e-5, "split2 vs torch")
-    close(out, old, 2e-6, 2e-6, "split2 vs two-block kernel")
+    tol = 4e-6 if tile == 5 else 2e-6                    # Winograd F(2,3): one more fp32 addition per operand and a three-term output sum
+    close(out, old, tol, tol, "split2 / wino vs two-block kernel")
 
 
 # ------------------------------------------------------------------------------------------- DCNv2

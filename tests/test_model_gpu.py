@@ -64,25 +64,39 @@ def net():
 
 
 @pytest.mark.parametrize("precontract", [True, False], ids=["splat67", "splat133"])
-@pytest.mark.parametrize("case", ["lr32_s4_n3", "lr64_s2_n3", "lr32x48_s4_n2_b2"])
+@pytest.mark.parametrize("case", ["lr32_s4_n3", "lr64_s2_n3", "lr32x48_s4_n2_b2", "lr64_to160x168_n3", "lr32_s4_n3_alpha05", "lr32_s4_n3_alpha20"])
 def test_lunatokis_matches_reference_goldens(net, case, precontract):
     """precontract=True: the default product path (synth_net's first layer contracted into the splat sources, 67-plane
     accumulator; the imnet stage then carries the composed head and is not comparable).  False: the literal 130-plane
-    splat with every stage compared."""
+    splat with every stage compared.  Round 4 goldens (all produced by running the reference): a non-integer scale per axis
+    (64x64 -> 160x168, the nearbyint gather of Ours.py:525-528, 699-704) and alpha = +0.5 / +20 (Ours.py:509, 794, 827-830)."""
     g = load(case)
     x = torch.from_numpy(g["LQs"]).cuda()
     times = [t.cuda() for t in torch.from_numpy(g["times"])]
     scale = [[int(g["scale"][0])], [int(g["scale"][1])]]
+    alpha = float(g["alpha"]) if "alpha" in g else -20.0
     st = {}
     net.clear_cache()
     net.precontract = precontract
     try:
         with torch.no_grad():
+            net.alpha.fill_(alpha)
             out, flow, _ = net(x, None, times, scale, use_GT=False, iter=4, stages=st)
         pc = net._pc()
     finally:
+        with torch.no_grad():
+            net.alpha.fill_(-20.0)
         net.precontract = True
         net.clear_cache()
+    if alpha > 0:
+        # the max plane (accumulator plane 65 / 131) against the reference's fwarp_max: continuous in the flow except where a source
+        # crosses a pixel boundary -- compared on all cells at 1e-3, at most 0.5 % of them further off
+        mxp = st["acc"][:, 65 if pc else 131].reshape(-1).cpu()
+        ref_mx = torch.from_numpy(g["fwarp_max"]).reshape(2, -1).max(0).values      # the two directions share the accumulator's max plane
+        assert float(ref_mx.max()) > 1.0
+        bad = ((mxp - ref_mx).abs() > 1e-3).float().mean()
+        print("%s: max plane differs at %.3f %% of cells (reference max %.3f)" % (case, 100 * float(bad), float(ref_mx.max())))
+        assert float(bad) < 5e-3
     B, N = x.shape[0], len(times)
     HH, WW = out.shape[-2:]
     # t-independent stages

@@ -41,16 +41,27 @@ def test_state_dict_keys_match_reference(oracle_net):
     assert all(list(sd[k].shape) == keys[k] for k in keys)
 
 
-@pytest.mark.parametrize("case", ["lr32_s4_n3", "lr32x48_s4_n2_b2"])
+@pytest.mark.parametrize("case", ["lr32_s4_n3", "lr32x48_s4_n2_b2", "lr64_to160x168_n3", "lr32_s4_n3_alpha05", "lr32_s4_n3_alpha20"])
 def test_restatement_reproduces_reference_outputs(oracle_net, case):
     """Same torch build => bit-identical (make_golden.py reported max|diff| = 0 for every stage);
-    a small tolerance is allowed for a different CPU's conv kernels."""
+    a small tolerance is allowed for a different CPU's conv kernels.  Round 4: a NON-INTEGER scale (64x64 -> 160x168: the literal
+    nearbyint gather of Ours.py:525-528, 699-704) and alpha > 0 (Ours.py:509, 794: the max plane leaves 1 and the `== 1.0 -> 0`
+    patch of Ours.py:827-830 acts on some cells only)."""
     g = load(case)
     times = list(torch.from_numpy(g["times"]))
     scale = [[int(g["scale"][0])], [int(g["scale"][1])]]
     st = {}
+    alpha = float(g["alpha"]) if "alpha" in g else -20.0
     with torch.no_grad():
-        out, flow, _ = oracle_net(torch.from_numpy(g["LQs"]), None, times, scale, use_GT=False, iter=4, stages=st)
+        oracle_net.alpha.fill_(alpha)
+        try:
+            out, flow, _ = oracle_net(torch.from_numpy(g["LQs"]), None, times, scale, use_GT=False, iter=4, stages=st)
+        finally:
+            oracle_net.alpha.fill_(-20.0)
+    if alpha > 0:
+        mx = torch.from_numpy(g["fwarp_max"])
+        assert float(mx.max()) > 1.0 and float(mx.min()) == 1.0          # the fixture really exercises both branches
+        check(g, "fwarp_max", st["fwarp_max"], 2e-5)
     tol = 0.0 if str(g["torch_version"]) == torch.__version__ else 1e-4
     tol = max(tol, 2e-5)
     check(g, "out", out, tol)
