@@ -255,7 +255,10 @@ int motif_conv_split_pack(const MotifConvDesc* d, const float* weight, float* pa
 int motif_conv_split_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s) {
     {                                                    // round 4: conv_wino.hip (conv_engine 5 = wherever it applies, 6 = never)
         const int force = motif_opt(MOTIF_OPT_CONV_ENGINE);
-        if ((force == 0 || force == 5) && motif_conv_wino_eligible(d, a, P)) return motif_conv_wino_launch(d, a, P, s);
+        // by measurement inside the clip (gpurun_out/r4/shapes_*.txt): faster on every 3x3 layer except those with a transcendental
+        // epilogue (the offset | sigmoid(mask) layers of the DCNs: a lone wave hides none of the exp / rcp chains of its exposed epilogue)
+        const bool plain_act = d->act_split <= 0 && (d->act == MOTIF_ACT_NONE || d->act == MOTIF_ACT_RELU || d->act == MOTIF_ACT_LRELU);
+        if ((force == 5 || (force == 0 && plain_act)) && motif_conv_wino_eligible(d, a, P)) return motif_conv_wino_launch(d, a, P, s);
     }
     if (motif_opt(MOTIF_OPT_CONV_ENGINE) != 1 && motif_conv_split2_eligible(d, a, P)) return motif_conv_split2_launch(d, a, P, s);   // round 3: conv_split2.hip
     const int Cin_g = (d->C0 + d->C1) / d->groups, Cout_g = d->Cout / d->groups;

@@ -427,29 +427,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int it = 0; it < 4; ++it) rv[pass][it] = *(const f32x4*)(rb + (okv(pass, it) ? offv(pass, it) : 0u));   // masked lanes read element 0
         };
         if (rm) { load_res(0); load_res(1); load_res(2); load_res(3); }
-        float bv[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b4 = *(const f32x4*)(bias_w + 8 * q + 4 * hf);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) bv[4 * q + u] = b4[u];
-        }
-        f32x16 o[4];
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                o[2 * tl][r] = ((acc[tl][0][r] + acc[tl][1][r]) + acc[tl][2][r]) + bv[r];
-                o[2 * tl + 1][r] = ((acc[tl][1][r] - acc[tl][2][r]) - acc[tl][3][r]) + bv[r];
-            }
-        zero_acc();
         float* scr = (float*)land;                       // two halves of [8 couts][4 rows x 32 px]
         const int ew = hf * 512 + l5, er = hf * 128 + (l5 >> 3) * 32 + (l5 & 7) * 4;
+        // pass p = couts 8p .. 8p+7 = registers 4p .. 4p+3 of every accumulator: inverse transform + bias of those 16 values, transpose
+        // through the scratch half p & 1, and a quarter of the accumulators zeroed for the next tile -- written per pass so that the
+        // compiler overlaps pass p+1's register work with pass p's LDS round trip
         auto write_pass = [&](int pass) __attribute__((always_inline)) {
+            const f32x4 b4 = *(const f32x4*)(bias_w + 8 * pass + 4 * hf);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-                for (int r3 = 0; r3 < 4; ++r3) scr[(pass & 1) * 1024 + ew + r3 * 128 + j * 32] = o[j][4 * pass + r3];
+                for (int r3 = 0; r3 < 4; ++r3) {
+                    const int r = 4 * pass + r3;
+                    const float o0 = ((acc[tl][0][r] + acc[tl][1][r]) + acc[tl][2][r]) + b4[r3];
+                    const float o1 = ((acc[tl][1][r] - acc[tl][2][r]) - acc[tl][3][r]) + b4[r3];
+                    scr[(pass & 1) * 1024 + ew + r3 * 128 + (2 * tl) * 32] = o0;
+                    scr[(pass & 1) * 1024 + ew + r3 * 128 + (2 * tl + 1) * 32] = o1;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) acc[tl][p][r] = 0.f;
+                }
         };
         // AC / RM >= 0: activation / residual mode known at compile time (the common layers: one straight-line body, no per-item
         // scalar branches -- 16 items x the generic chain of wave-uniform tests cost a lone wave ~2 k cycles); -1: run-time switches.
@@ -458,6 +454,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int rmv = RM >= 0 ? RM : rm;
             const unsigned long long obq = obp;
             write_pass(0);
+            // every residual quad is waited for BEFORE the first (uncounted) store: behind a store the counted wait of a later quad
+            // could only end when that store has completed too
+            if (rmv) asm volatile("" :: "v"(rv[3][0]), "v"(rv[3][1]), "v"(rv[3][2]), "v"(rv[3][3]));
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 if (pass + 1 < 4) write_pass(pass + 1);
