@@ -23,8 +23,11 @@ Extra objects on the JSON line:
   stages       the same measurement for every stage of the path (event pairs around each C-ABI call of the
                instrumented clip): ms per clip, algorithmic work, achieved rate, the bound and the fraction of it.
   parity       PSNR / L-inf of the HIP path against the CPU oracle on the cpu_baseline clip (both engines).
-  cpu_baseline the CPU oracle (oracle/, "port" of the reference) on a bounded crop of the same workload, plus the
-               reference's own CPU-runnable case c1.
+  cpu_baseline the CPU oracle (oracle/, "port" of the reference): one 3-timestamp forward call at the c2 shape (after a warm-up
+               call), plus a cropped clip and the reference's own CPU-runnable case c1.
+  streams1     the same job with one clip in flight; fp32_mfma: the same job on the fp32 MFMA.
+  stages.pwc   PWC-Net forward on one 720x1280 pair + the 81-way cost volume against HBM.
+  c5           (multi-GPU runs, or --mode tiled) one 540x960 clip in row bands: exact and cropped modes, PSNR of the latter.
 """
 import argparse
 import json
@@ -65,8 +68,16 @@ def parse():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend: nccl = RCCL over xGMI (the product); gloo = plumbing runs where there are fewer GPUs "
                          "than ranks (ranks then share GPUs, the uint8 gather is staged through the host)")
-    ap.add_argument("--verify-gather", action="store_true",
-                    help="multi-GPU runs: rank 0 re-renders every rank's first clip and checks the gathered uint8 frames byte for byte")
+    ap.add_argument("--verify-gather", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--no-verify-gather", action="store_true",
+                    help="multi-GPU runs verify by default that rank 0's gathered uint8 frames of every rank's first clip equal rank 0's own "
+                         "render of that clip byte for byte (outside the timed region); this switches the check off")
+    ap.add_argument("--no-streams1", action="store_true", help="skip the secondary one-clip-at-a-time measurement (`streams1`)")
+    ap.add_argument("--no-pwc", action="store_true", help="skip the PWC-Net stage (forward on one 720x1280 pair + the 81-way cost volume roofline)")
+    ap.add_argument("--mode", choices=["clips", "tiled"], default="clips",
+                    help="clips = c2 / c4 (independent clips per GPU, the metric); tiled = also run the c5 leg on this world size: ONE 540x960 "
+                         "clip in row bands over the ranks, exact (recomputed halo, bit-identical) and cropped (approximate, PSNR reported) modes")
+    ap.add_argument("--no-c5", action="store_true", help="multi-GPU runs append the c5 row-band leg by default; this skips it")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU/gloo plumbing test of the --gpus launcher: N ranks, barrier, gather, one JSON line; no GPU work")
     return ap.parse_args()
@@ -272,10 +283,11 @@ def _cpu_model():
 
 
 def cpu_baseline_and_parity(times, model, mma, lr=(180, 320), scale=4):
-    """cpu_baseline: the oracle at the metric's own shape (c2: LR 180x320 -> 720x1280), ONE of the clip's timestamps (t = 0.5: one
-    forward call of the reference schedule, ~40 s on the box's host cores -- a bounded sample of the 3-call clip), plus c1, the
+    """cpu_baseline: the oracle at the metric's own shape (c2: LR 180x320 -> 720x1280) on ONE forward call of the reference schedule
+    with its full 3 timestamps (VideoSR_base_model.py:189-193 renders <= 3 per call and recomputes the t-independent stages per
+    call), after a warm-up call on c1 (thread pool, allocator) -- a bounded sample of the 3-call clip -- plus c1 itself, the
     reference's own CPU-runnable configuration (LR 64x64, x2 spatial, 3 timestamps).  parity: the HIP path against the oracle's
-    frames on a cropped c2 clip (LR 48x80, all timestamps), for both arithmetic engines."""
+    frames on a cropped c2 clip (LR 48x80, all timestamps), for both arithmetic engines, with the gated tolerances."""
     import numpy as np
     import torch
     from oracle.motif_ref import MotifRef
@@ -284,28 +296,35 @@ def cpu_baseline_and_parity(times, model, mma, lr=(180, 320), scale=4):
     from motif_amd.utils.synth_weights import fill_state_dict
     cores = torch.get_num_threads()
     H, W = lr
+    _oracle_clip(64, 64, 2, 3)                                        # warm-up, untimed
+    _, _, _, dt1 = _oracle_clip(64, 64, 2, 3)
     full = synthetic_sample(H, W, scale, times, seed=0)
     onet = fill_state_dict(MotifRef().eval())
     mid = times // 2
+    lo = max(0, mid - 1)
+    tsel = full["time"][lo:lo + 3]
     t0 = time.time()
     with torch.no_grad():
-        onet(full["LQs"], None, full["time"][mid:mid + 1], full["scale"], use_GT=False, iter=4)
+        onet(full["LQs"], None, tsel, full["scale"], use_GT=False, iter=4)
     dtf = time.time() - t0
     del onet
     h, w, s = 48, 80, 4
     sample, ref, rflow, dt = _oracle_clip(h, w, s, times)
-    _, _, _, dt1 = _oracle_clip(64, 64, 2, 3)
-    base = {"value": H * scale * W * scale / dtf, "unit": "HR px/s", "cores": cores, "cpu": _cpu_model(), "kind": "port",
+    base = {"value": len(tsel) * H * scale * W * scale / dtf, "unit": "HR px/s", "cores": cores, "cpu": _cpu_model(), "kind": "port",
             "sample": "oracle/motif_ref.py (CPU restatement, bit-identical to the reference on the goldens) at the c2 shape, LR %dx%d -> "
-                      "%dx%d, ONE timestamp (t = %d/%d) = one forward call of the reference schedule, which recomputes the t-independent "
-                      "stages per call: %.1f s on %d torch threads" % (H, W, H * scale, W * scale, mid, times - 1, dtf, cores),
+                      "%dx%d, ONE forward call of the reference schedule with its %d timestamps (t = %d..%d of 0..%d; the t-independent stages "
+                      "are computed once per call, as the reference does): %.1f s on %d torch threads, after a warm-up call.  A 7-timestamp clip "
+                      "is three such calls (3 / 3 / 1 timestamps); the last one amortises the t-independent part over one frame only"
+                      % (H, W, H * scale, W * scale, len(tsel), lo, lo + len(tsel) - 1, times - 1, dtf, cores),
             "crop": {"value": times * h * s * w * s / dt, "unit": "HR px/s",
-                     "sample": "the parity clip: c2 cropped to LR %dx%d, %d timestamps in chunks of 3, %.1f s" % (h, w, times, dt)},
+                     "sample": "the parity clip: c2 cropped to LR %dx%d, %d timestamps in calls of 3 / 3 / 1, %.1f s" % (h, w, times, dt)},
             "c1": {"value": 3 * 128 * 128 / dt1, "unit": "HR px/s",
-                   "sample": "BASELINE configs[0]: LR 64x64 -> 128x128 (x2 spatial, x2 temporal = 3 timestamps), %.1f s" % dt1}}
+                   "sample": "BASELINE configs[0]: LR 64x64 -> 128x128 (x2 spatial, x2 temporal = 3 timestamps), %.1f s (second call)" % dt1}}
     data = {"LQs": sample["LQs"].cuda(), "GT": sample["GT"][:, :1].cuda(), "time": [t.cuda() for t in sample["time"]], "scale": sample["scale"]}
-    parity = {"clip": "c2 cropped to LR %dx%d, all %d timestamps" % (h, w, times), "tolerance": "PSNR >= 60 dB, flow L-inf <= 2e-3 (tests/test_model_gpu.py); the frame L-inf is reported, not gated: "
-                                                                                                       "isolated pixels where a splat target coordinate floors to the other side of an integer"}
+    parity = {"clip": "c2 cropped to LR %dx%d, all %d timestamps" % (h, w, times),
+              "tolerance": "gated (here and in tests/test_model_gpu.py): PSNR >= 60 dB, flow L-inf <= 2e-3, frame L-inf <= 1e-2 and at most 1e-5 of the "
+                           "clip's values further than 1e-3 from the oracle (isolated pixels where a splat target coordinate floors to the other "
+                           "side of an integer under 1e-7 of flow noise)"}
     try:
         for mode in ("bf16x3", "fp32"):
             ops.set_mma(mode)
@@ -314,13 +333,125 @@ def cpu_baseline_and_parity(times, model, mma, lr=(180, 320), scale=4):
             out = model.fake_H.float().cpu()
             mse = float(((out.double() - ref.double()) ** 2).mean())
             ad = (out - ref).abs()
-            parity[mode] = {"psnr_vs_oracle": 99.0 if mse == 0 else round(10 * np.log10(1.0 / mse), 2),
-                            "linf_vs_oracle": float(ad.max()),
-                            "values_over_1e-4": int((ad > 1e-4).sum()), "values_over_1e-3": int((ad > 1e-3).sum()), "values": int(ad.numel()),
-                            "linf_flow": float((model.flow.float().cpu() - rflow).abs().max())}
+            row = {"psnr_vs_oracle": 99.0 if mse == 0 else round(10 * np.log10(1.0 / mse), 2),
+                   "linf_vs_oracle": float(ad.max()),
+                   "values_over_1e-4": int((ad > 1e-4).sum()), "values_over_1e-3": int((ad > 1e-3).sum()), "values": int(ad.numel()),
+                   "linf_flow": float((model.flow.float().cpu() - rflow).abs().max())}
+            row["gates"] = {"psnr_ge_60": bool(row["psnr_vs_oracle"] >= 60.0), "flow_linf_le_2e-3": bool(row["linf_flow"] <= 2e-3),
+                            "frame_linf_le_1e-2": bool(row["linf_vs_oracle"] <= 1e-2),
+                            "frac_over_1e-3_le_1e-5": bool(row["values_over_1e-3"] <= 1e-5 * row["values"])}
+            row["pass"] = bool(all(row["gates"].values()))
+            parity[mode] = row
     finally:
         ops.set_mma(mma)
+    parity["pass"] = bool(all(parity[m]["pass"] for m in ("bf16x3", "fp32")))
     return base, parity
+
+
+def pwc_stage():
+    """PWC-Net (north_star names it first; the reference does not wire it into its own path): forward on one
+    720x1280 pair through the same conv engines, and the 81-way cost volume (correlation.py:44-112) on its own: algorithmic
+    bytes (both feature maps read once, 81 planes written) and FLOP of its six launches against HBM and the fp32 vector peak."""
+    import torch
+    from motif_amd import ops
+    from motif_amd.OpticalFlow.PWCNet import PWCNet
+    from motif_amd.utils.synth_weights import fill_state_dict
+    net = fill_state_dict(PWCNet()).cuda().eval()
+    f0, f1 = torch.rand(1, 3, 720, 1280, device="cuda"), torch.rand(1, 3, 720, 1280, device="cuda")
+    rec = []
+    orig = ops.corr81
+
+    def timed_corr(first, second, *args, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(first, second, *args, **kw)
+        e1.record()
+        b, c, hh, ww = first.shape
+        rec.append((e0, e1, 2.0 * b * 81 * c * hh * ww, 4.0 * b * hh * ww * (2 * c + 81)))
+        return out
+    with torch.no_grad():
+        for _ in range(2):
+            net(f0, f1)
+        torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 3
+        c0.record()
+        for _ in range(reps):
+            net(f0, f1)
+        c1.record()
+        torch.cuda.synchronize()
+        ops.corr81 = timed_corr
+        try:
+            net(f0, f1)
+            torch.cuda.synchronize()
+        finally:
+            ops.corr81 = orig
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rec)
+    fl, by = sum(r[2] for r in rec), sum(r[3] for r in rec)
+    row = {"ms_per_pair": round(c0.elapsed_time(c1) / reps, 3), "input": "one 720x1280 frame pair (padded to 768x1280 inside, OpticalFlow/PWCNet.py:266-322)",
+           "corr81": {"ms": round(ms, 4), "calls": len(rec), "gflop": round(fl / 1e9, 3), "gbyte": round(by / 1e9, 4)}}
+    if ms > 0:
+        row["corr81"].update(bound="hbm", achieved=round(by / (ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             tflops=round(fl / (ms * 1e-3) / 1e12, 2), frac_of_fp32_vector_peak=round(fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                             note="coarse pyramid levels are launch / latency bound (16-24 us for a few hundred pixels)")
+    return row
+
+
+def c5_leg(net, world, rank, backend, reps=1):
+    """BASELINE configs[4]: ONE 540x960 LR clip -> 2160x3840, x4t = 5 timestamps, in row bands over the ranks
+    (motif_amd.dist.render_clip_tiled).  exact = every rank recomputes the LR stage and a 64-row halo of the HR stage: bit-identical
+    to the untiled render (tests/test_model_gpu.py::test_c5_row_bands_match_untiled_at_full_size), bounded at ~1.3x on 8 GPUs
+    because the LR stage is 3/4 of the clip; cropped (lr_halo = 16 LR rows) = every rank runs the whole model on its crop:
+    approximate, its PSNR against the exact frames is reported."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from motif_amd import dist as mdist
+    from motif_amd.data.synthetic import synthetic_sample
+    s = synthetic_sample(540, 960, 4, 5, seed=5)
+    x = s["LQs"].cuda()
+    times = [t.cuda() for t in s["time"]]
+    scale = s["scale"]
+
+    def run(**kw):
+        out = None
+        best = None
+        for i in range(reps + 1):                        # first = warm-up (weights packed for this shape, allocator)
+            net.clear_cache()                            # the t-independent stage is cached per clip tensor: every repetition renders from scratch
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            out = mdist.render_clip_tiled(net, x, times, scale, **kw)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            if i > 0:
+                best = dt if best is None else min(best, dt)
+        return out, best
+    was_training = net.training
+    net.eval()
+    net.clear_cache()
+    exact, t_exact = run(halo=64)
+    net.clear_cache()
+    crop, t_crop = run(halo=64, lr_halo=16)
+    net.clear_cache()
+    net.train(was_training)
+    if rank != 0:
+        return None
+    px = 5 * 2160 * 3840
+    mse = float(((exact.double() - crop.double()) ** 2).mean()) / 255.0 ** 2
+    return {"workload": "c5: one 4-frame 540x960 LR clip -> 2160x3840, 5 timestamps, row bands over %d rank(s)" % world,
+            "exact": {"ms_per_clip": round(1000 * t_exact, 2), "value": px / t_exact, "unit": "px/s",
+                      "note": "bit-identical to the untiled render; LR stage replicated (bounded ~1.3x on 8 GPUs)"},
+            "cropped": {"ms_per_clip": round(1000 * t_crop, 2), "value": px / t_crop, "unit": "px/s", "lr_halo": 16,
+                        "psnr_vs_exact_db": 99.0 if mse == 0 else round(10 * np.log10(1.0 / mse), 2),
+                        "note": "approximate: every rank renders its own LR crop (uint8 frames compared)"}}
 
 
 # ------------------------------------------------------------------------------------------------- main
@@ -365,16 +496,19 @@ def main():
         models.append(m)
         streams.append(torch.cuda.Stream())
     HH, WW = h * a.scale, w * a.scale
-    # two distinct clips per rank, resident in HBM before the timed region
+    # two distinct clips per rank, resident in HBM before the timed region.  Global clip j = rank + world * i goes to rank j % world:
+    # the striding of the reference's DistIterSampler (data/data_sampler.py:56, indices[rank::world]); clip j is seeded with j.
     clips = []
     for i in range(2):
-        s = synthetic_sample(h, w, a.scale, a.times, seed=100 * rank + i, batch=a.batch)
+        s = synthetic_sample(h, w, a.scale, a.times, seed=rank + world * i, batch=a.batch)
         s = {"LQs": s["LQs"].cuda(), "GT": s["GT"][:, :1].cuda(), "time": [t.cuda() for t in s["time"]], "scale": s["scale"]}
         clips.append(s)
 
+    nstreams = [len(models)]                              # clips in flight in the loop being timed (streams1 leg: 1)
+
     def step(i):
-        m = models[i % len(models)]
-        with torch.cuda.stream(streams[i % len(models)]):
+        m = models[i % nstreams[0]]
+        with torch.cuda.stream(streams[i % nstreams[0]]):
             m.feed_data(clips[i % 2])
             m.test()
             if world > 1:
@@ -427,7 +561,9 @@ def main():
         "config": {"arithmetic": ("fp32-equivalent on the bf16 matrix cores: every fp32 operand = 3 exact bf16 parts, 6 products, fp32 "
                                   "accumulate (3x3 convolutions, fused DCN and the three MLPs); everything else fp32" if a.mma == "bf16x3"
                                   else "fp32 MFMA (v_mfma_f32_32x32x2_f32) and fp32 VALU"),
-                   "workload": "c2: 4-frame %dx%d LR clip -> %dx%d (x%d spatial), x%dt = %d timestamps, B=%d clip(s) per step per GPU, "
+                   "workload": ("c2" if world == 1 else "c4 (independent c2 clips sharded over %d GPUs as the reference's DistIterSampler strides them: "
+                                "%d clips per GPU in the timed region, %d in total; 8 GPUs x 8 clips = BASELINE configs[3])" % (world, a.steps * a.batch, world * a.steps * a.batch))
+                               + ": 4-frame %dx%d LR clip -> %dx%d (x%d spatial), x%dt = %d timestamps, B=%d clip(s) per step per GPU, "
                                "RAFT-small iters=4, seeded key-hashed weights" % (h, w, HH, WW, a.scale, a.times - 1, a.times, a.batch),
                    "parallelism": "clips sharded per GPU (dp%d), uint8 frame gather to rank 0" % world,
                    "clips_in_flight_per_gpu": a.streams,
@@ -438,22 +574,29 @@ def main():
             ver = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception as e:                       # informational only
             ver = "unknown (%s)" % type(e).__name__
-        line["collective"] = {"backend": dist.get_backend(), "version": ver,
+        line["collective"] = {"backend": dist.get_backend(), "version": ver, "world_size": dist.get_world_size(),
+                              "data_path": "none: clips are independent; the only collective is the asynchronous gather of the uint8 frames to rank 0",
                               "library": "RCCL (torch.distributed 'nccl' on ROCm)" if a.backend == "nccl" else "gloo (plumbing run, host-staged gather)"}
-    if world > 1 and a.verify_gather:
+    if world > 1 and not a.no_verify_gather:
         m = models[0]
         m.feed_data(clips[0]); m.test()
         got = mdist.gather_to_rank0(mdist.frames_to_uint8(m.fake_H.permute(1, 0, 2, 3, 4)), world)
         if rank == 0:
             ok = True
             for r in range(world):
-                sr = synthetic_sample(h, w, a.scale, a.times, seed=100 * r, batch=a.batch)
+                sr = synthetic_sample(h, w, a.scale, a.times, seed=r, batch=a.batch)          # rank r's first clip = global clip r
                 m.feed_data({"LQs": sr["LQs"].cuda(), "GT": sr["GT"][:, :1].cuda(), "time": [t.cuda() for t in sr["time"]], "scale": sr["scale"]})
                 m.test()
                 mine = mdist.frames_to_uint8(m.fake_H.permute(1, 0, 2, 3, 4))
                 ok = ok and bool(torch.equal(got[r * a.batch:(r + 1) * a.batch].to(mine.device), mine))
             line["gather_verified"] = ok                 # every rank's gathered frames == rank 0's own render of that rank's clip
         fence()
+    if a.streams > 1 and not a.no_streams1:
+        nstreams[0] = 1                                  # strictly one clip at a time on the first stream / model instance
+        dt1 = timed(1, a.steps)
+        nstreams[0] = len(models)
+        line["streams1"] = {"value": world * a.steps * px / dt1, "unit": "px/s", "ms_per_step": 1000.0 * dt1 / a.steps,
+                            "note": "the same job with ONE clip in flight per GPU (--streams 1); the headline keeps %d in flight" % a.streams}
     if a.mma == "bf16x3" and not a.no_fp32_leg:
         # the same job on the fp32 MFMA (all ranks, same barriers), reported next to the headline value
         from motif_amd import ops
@@ -490,14 +633,24 @@ def main():
                                                     "the timed wall time per clip, against the same peak"},
                                 "peak_basis": ("bf16 dense MFMA 2500 TFLOP/s / 6 bf16 products per fp32 MAC" if split
                                                else "fp32 MFMA 157.3 TFLOP/s"),
-                                "kernel": "3x3 engine: conv_split2_kernel where its 12-row tiles fill >= 0.9 of the rounds, else conv_split_kernel<3,4>" if split else "conv_igemm_kernel<2>",
+                                "kernel": ("3x3 engine: conv_wino_kernel (Winograd F(2,3) along the rows, one wave per SIMD: 2/3 of the direct form's MFMAs for the "
+                                           "algorithmic FLOP counted here) wherever it applies, the direct conv_split2 / conv_split kernels for the layers with a "
+                                           "transcendental epilogue or a single 16-channel chunk") if split else "conv_igemm_kernel<2>",
+                                "flop_basis": "algorithmic (direct-form) FLOP of the launches; the Winograd kernel executes 2/3 of them on the matrix cores",
                                 "launches_per_clip": r["launches"],
                                 "avg_launch_us": 1000.0 * r["ms"] / max(r["launches"], 1),
                                 "avg_launch_gflop": r["flops"] / max(r["launches"], 1) / 1e9,
                                 "all_conv_ms_per_clip": r["all_conv_ms"], "all_conv_tflop_per_clip": r["all_conv_flops"] / 1e12}
             line["stages"] = r["table"]
+            if not a.no_pwc:
+                line["stages"]["pwc"] = pwc_stage()
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(a.times, model, a.mma, tuple(a.lr), a.scale)
+    if (world > 1 and not a.no_c5) or a.mode == "tiled":
+        c5 = c5_leg(model.netG, world, rank, a.backend)     # all ranks take part
+        if rank == 0:
+            line["c5"] = c5
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
