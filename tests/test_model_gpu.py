@@ -439,6 +439,9 @@ class _Keep(dict):
 
 
 _ORACLE_C2 = {}
+# measured at c2 full size (t = 0.5): TODO-MEASURED of the 921 600 cells (a source within 1e-7 px of a pixel boundary lands in the
+# neighbouring cell); the gate is 10x that, not the 2 % of rounds 1-3
+COUNT_MISMATCH_GATE = 2e-3
 
 
 def _oracle_c2():
@@ -473,14 +476,20 @@ def test_c2_full_size_parity_vs_oracle(mma_mode):
     p = psnr(out, o["ref"])
     linf = float((out - o["ref"]).abs().max())
     fl = float((flow - o["rflow"]).abs().max())
-    print("c2 full size [%s]: PSNR(build, oracle) = %.1f dB, Linf = %.2e, flow Linf = %.2e" % (mma_mode, p, linf, fl))
+    over = int(((out - o["ref"]).abs() > 1e-3).sum())
+    print("c2 full size [%s]: PSNR(build, oracle) = %.1f dB, Linf = %.2e, %d of %d values beyond 1e-3, flow Linf = %.2e" % (mma_mode, p, linf, over, out.numel(), fl))
     assert p >= 60.0 and fl <= 2e-3, (p, fl)
+    # frame deviations are GATED: isolated pixels next to a splat target coordinate that floors to the other side of an
+    # integer under 1e-7 of flow noise -- at most 1e-5 of the frame's values further than 1e-3 from the oracle, none further than 1e-2
+    assert linf <= 1e-2, linf
+    assert over <= 1e-5 * out.numel(), (over, out.numel())
     assert float((st["flow"].cpu() - o["stages"]["flow_lr"]).abs().max()) <= 2e-3
     enc = (st["feat"].cpu() - o["stages"]["encoder"]).abs()
     assert float(enc.max()) <= 2e-3 + 1e-3 * float(o["stages"]["encoder"].abs().max()), float(enc.max())
     cnt_ref = o["stages"]["fwarp_count"].reshape(2, 1, 1, 720, 1280).sum(0)
     mism = float((st["acc"][:, -1:].cpu() != cnt_ref).float().mean())                 # last accumulator plane = hit count
-    assert mism < 0.02, "hit-count plane differs at %.2f%% of cells" % (100 * mism)
+    print("c2 full size [%s]: hit-count plane differs at %.2e of the cells" % (mma_mode, mism))
+    assert mism < COUNT_MISMATCH_GATE, "hit-count plane differs at %.4f%% of cells" % (100 * mism)
     gt = s["GT"][0, 4:5]
     assert np.abs(util.y_psnr_per_frame(gt, out[:, 0]) - util.y_psnr_per_frame(gt, o["ref"][:, 0])).max() < 0.05
 

@@ -224,3 +224,117 @@ def test_frame_codec_restatement_known_answers():
     assert t[0, 0, :, 0].tolist() == [0, 1, 2, 0, 255, 254]                                  # truncation
     g = np.random.default_rng(0).random((2, 3, 5, 7), dtype=np.float32)
     assert np.array_equal(frames_ref.decode(frames_ref.encode_tensor2img(g)).round(6), frames_ref.decode(frames_ref.encode_tensor2img(frames_ref.decode(frames_ref.encode_tensor2img(g)))).round(6))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Second opinion on oracle/native_ref.c.  The three CUDA kernel texts it restates (soft-splat, PWC correlation,
+# DCNv2 im2col) cannot be built or run here, so the C file is pinned by READING only.  The formulations below are written from the
+# published formulas with torch index / sampling primitives -- not from the C file -- and must agree with it; the analytic known
+# answers pin both.
+
+def _splat_torch(inp, flow, mode):
+    """Forward soft-splat from its definition (softsplat_cp.py:12-52): every source pixel adds inp * bilinear weight to the four
+    cells around (x + fx, y + fy); cells outside the image are skipped.  index_put_(accumulate=True) on the flattened image."""
+    n, c, h, w = inp.shape
+    X = torch.arange(w, dtype=torch.float32).view(1, 1, w) + flow[:, 0]
+    Y = torch.arange(h, dtype=torch.float32).view(1, h, 1) + flow[:, 1]
+    x0, y0 = torch.floor(X), torch.floor(Y)
+    out = torch.ones(n, c, h * w, dtype=torch.float64) if mode == "max" else torch.zeros(n, c, h * w, dtype=torch.float64)
+    ni = torch.arange(n).view(n, 1, 1).expand(n, h, w)
+    for dx in (0, 1):
+        for dy in (0, 1):
+            xi, yi = x0 + dx, y0 + dy
+            wgt = (1.0 - (X - xi).abs()) * (1.0 - (Y - yi).abs())                  # (x0+1-X)(y0+1-Y), (X-x0)(y0+1-Y), ...
+            ok = (xi >= 0) & (xi < w) & (yi >= 0) & (yi < h)
+            cell = (yi.clamp(0, h - 1) * w + xi.clamp(0, w - 1)).long()
+            for ch in range(c):
+                v = inp[:, ch].double() * (wgt.double() if mode != "count" else 1.0)
+                chi = torch.full_like(cell, ch)
+                if mode == "max":
+                    out.view(-1).scatter_reduce_(0, ((ni * c + ch) * (h * w) + cell)[ok], v[ok], reduce="amax", include_self=True)
+                else:
+                    out.index_put_((ni[ok], chi[ok], cell[ok]), v[ok], accumulate=True)
+    return out.view(n, c, h, w)
+
+
+def test_splat_restatement_equals_an_index_put_formulation_and_analytic_answers():
+    from oracle import native
+    g = torch.Generator().manual_seed(5)
+    n, c, h, w = 2, 3, 14, 19
+    src = torch.randn(n, c, h, w, generator=g)
+    flow = (torch.rand(n, 2, h, w, generator=g) - 0.5) * 9.0               # some targets leave the image
+    assert float((native.splat(src, flow, "sum").double() - _splat_torch(src, flow, "sum")).abs().max()) < 1e-5
+    ones = torch.ones(n, 1, h, w)
+    assert torch.equal(native.splat(ones, flow, "count").double(), _splat_torch(ones, flow, "count"))
+    ez = torch.rand(n, 1, h, w, generator=g) * 3.0                          # values on both sides of the init-1 clamp
+    assert float((native.splat(ez, flow, "max").double() - _splat_torch(ez, flow, "max")).abs().max()) < 1e-6
+    # analytic: a half-pixel flow in both directions spreads every source over four cells with weight 1/4 each
+    half = torch.full((n, 2, h, w), 0.5)
+    want = torch.zeros(n, c, h + 1, w + 1)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            want[:, :, dy:dy + h, dx:dx + w] += 0.25 * src
+    assert float((native.splat(src, half, "sum") - want[:, :, :h, :w]).abs().max()) < 1e-6
+    cnt = native.splat(ones, half, "count")
+    assert cnt[0, 0, 0, 0] == 1 and cnt[0, 0, 0, 5] == 2 and cnt[0, 0, 5, 5] == 4
+    # analytic: an integer shift is a translation (both directions at once), mass pushed outside disappears
+    sh = torch.zeros(n, 2, h, w)
+    sh[:, 0], sh[:, 1] = -3.0, 2.0
+    out = native.splat(src, sh, "sum")
+    assert torch.equal(out[:, :, 2:, :w - 3], src[:, :, :h - 2, 3:]) and float(out[:, :, :2].abs().max()) == 0 and float(out[:, :, :, w - 3:].abs().max()) == 0
+
+
+def _dcn_torch(x, weight, bias, offset, mask, pad, dg):
+    """DCNv2 forward (dcn_v2_im2col_cuda.cu:125-194 semantics) from its definition: tap k of output pixel p samples the input
+    bilinearly at p - pad + k + offset_k(p) (zero outside the image), times mask_k(p); then a dense contraction with the weight.
+    Sampling by F.grid_sample(align_corners=True, padding_mode="zeros") on absolute coordinates."""
+    B, C, H, W = x.shape
+    co, _, kh, kw = weight.shape
+    K = kh * kw
+    ys = torch.arange(H, dtype=torch.float32).view(1, H, 1)
+    xs = torch.arange(W, dtype=torch.float32).view(1, 1, W)
+    out = bias.view(1, co, 1, 1).expand(B, co, H, W).clone().double()
+    cg = C // dg
+    for g in range(dg):
+        xg = x[:, g * cg:(g + 1) * cg]
+        for i in range(kh):
+            for j in range(kw):
+                k = i * kw + j
+                py = ys - pad + i + offset[:, g * 2 * K + 2 * k]
+                px = xs - pad + j + offset[:, g * 2 * K + 2 * k + 1]
+                grid = torch.stack((2.0 * px / (W - 1) - 1.0, 2.0 * py / (H - 1) - 1.0), -1)
+                smp = F.grid_sample(xg, grid, mode="bilinear", padding_mode="zeros", align_corners=True) * mask[:, g * K + k].unsqueeze(1)
+                out += torch.einsum("oc,bchw->bohw", weight[:, g * cg:(g + 1) * cg, i, j].double(), smp.double())
+    return out
+
+
+def test_dcn_restatement_equals_a_grid_sample_formulation_and_a_shifted_convolution():
+    from oracle import native
+    g = torch.Generator().manual_seed(6)
+    B, C, H, W, co, dg = 2, 8, 11, 13, 6, 2
+    x = torch.randn(B, C, H, W, generator=g)
+    wgt = torch.randn(co, C, 3, 3, generator=g) * 0.2
+    bias = torch.randn(co, generator=g) * 0.1
+    off = (torch.rand(B, dg * 18, H, W, generator=g) - 0.5) * 5.0           # up to 2.5 pixels: samples leave the image at the border
+    msk = torch.rand(B, dg * 9, H, W, generator=g)
+    got = native.dcn_v2_forward(x, wgt, bias, off, msk, 3, 3, 1, 1, 1, 1, 1, 1, dg)
+    assert float((got.double() - _dcn_torch(x, wgt, bias, off, msk, 1, dg)).abs().max()) < 2e-5
+    # analytic: constant integer offsets (dy, dx) = (1, -2) with mask 1 = the plain convolution of the translated input
+    off2 = torch.zeros(B, dg * 18, H, W)
+    off2[:, 0::2], off2[:, 1::2] = 1.0, -2.0
+    # out[y, x] = sum w[i, j] X(y + i, x + j - 3), X = x extended by zeros: the valid convolution of the 3-padded input, cropped
+    want = F.conv2d(F.pad(x, (3, 3, 3, 3)), wgt, bias)[:, :, 3:3 + H, 0:W]
+    got2 = native.dcn_v2_forward(x, wgt, bias, off2, torch.ones(B, dg * 9, H, W), 3, 3, 1, 1, 1, 1, 1, 1, dg)
+    assert float((got2 - want).abs().max()) < 2e-5
+
+
+def test_corr81_restatement_equals_an_unfold_formulation():
+    """PWC-Net's cost volume (correlation.py:44-112): channel (dy + 4) * 9 + (dx + 4) = mean over channels of first[y, x] *
+    second[y + dy, x + dx], zero outside.  F.unfold of the zero-padded second map gives all 81 shifted copies at once."""
+    from oracle import native
+    g = torch.Generator().manual_seed(7)
+    b, c, h, w = 2, 5, 9, 12
+    f1, f2 = torch.randn(b, c, h, w, generator=g), torch.randn(b, c, h, w, generator=g)
+    patches = F.unfold(f2, kernel_size=9, padding=4).view(b, c, 81, h, w)
+    want = (f1.unsqueeze(2) * patches).mean(1)
+    assert float((native.corr81(f1, f2) - want).abs().max()) < 1e-5
