@@ -23,6 +23,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("-opt", type=str, default=None, help="YAML options file (test.yml format)")
     ap.add_argument("--launcher", choices=["none", "pytorch"], default="none")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend of --launcher pytorch: nccl = RCCL (one GPU per rank, as the reference's init_dist); gloo = "
+                         "plumbing runs with fewer GPUs than ranks (ranks share GPUs, the PSNR gather is staged through the host)")
     ap.add_argument("--local_rank", type=int, default=0)
     ap.add_argument("--clips", type=int, default=2)
     ap.add_argument("--lr", type=int, nargs=2, default=[180, 320])
@@ -46,8 +49,10 @@ def main():
     if opt["dist"]:
         import torch.distributed as dist
         local = int(os.environ.get("LOCAL_RANK", args.local_rank))
+        if args.backend == "gloo":
+            local %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl")
+        dist.init_process_group(backend=args.backend)
     rank, world = mdist.world()
     logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format="%(asctime)s %(message)s")
     logger = logging.getLogger("base")

@@ -877,6 +877,66 @@ def test_splat_motif_sinks_and_overfull_tiles():
     assert float(cnt[..., 48:64, 64:128].sum()) > 4 * 7000
 
 
+def test_splat_motif_value_clamp_and_non_finite_inputs():
+    """Defined behaviour of the fused splat at the edges of its fixed-point accumulation (splat.hip, include/motif_hip.h):
+      * plane values are clamped to +-2^17 when they are staged (the exact integer sums need |addend * 2^(32-E)| < 2^51): a source
+        value of 1e6 contributes as 131072, +-Inf as +-131072; the result equals the kernel-text splat of the CLAMPED sources;
+      * a NaN plane value does not propagate either -- the accumulator stays finite (the reference's float atomicAdd would leave a
+        NaN in the touched cells; its driver never produces one: the sources are SIREN outputs);
+      * a source whose flow is not finite is DROPPED: it touches no cell, the hit count included (the reference asserts finite
+        flows up front, softsplat_cp.py:25-26; a kernel cannot raise, and floor(NaN) names no cell)."""
+    from oracle import native
+    from motif_amd import ops
+    B, N, H, W, s = 1, 1, 16, 24, 4
+    HH, WW = H * s, W * s
+    iy, ix, _, _ = _tables(H, W, HH, WW)
+    iyc, ixc = iy.cpu().long(), ix.cpu().long()
+    imnet_out = rnd(2 * B, 64, HH, WW, seed=1)
+    feat_lr = rnd(2 * B, 64, H, W, seed=2)
+    alpha = torch.tensor([-20.0])
+    pred = rnd(2, 3, HH, WW, seed=3, scale=0.01)
+    pred[:, 2] = 0.0
+    M = 131072.0
+
+    def run(im, pr):
+        return ops.splat_motif(im.to(dev()), pr.to(dev()), feat_lr.to(dev()), iy, ix, alpha.to(dev()), HH / H, B, N, HH, WW).cpu()
+
+    def ref(im, pr):
+        flow = pr[:, :2] * 20.0 * (HH / H)
+        ez = (F.relu(pr[:, 2:3]) * alpha).exp()
+        feat_all = torch.cat([im, pr[:, :2], feat_lr[:, :, iyc][:, :, :, ixc]], 1)
+        ssum = native.splat(torch.cat([feat_all * ez, ez], 1), flow, "sum").reshape(2, B * N, 131, HH, WW).sum(0)
+        scnt = native.splat(torch.ones_like(ez), flow, "count").reshape(2, B * N, 1, HH, WW).sum(0)
+        return ssum, scnt
+
+    def rel(a, b):
+        return float(((a - b).abs() / (1 + b.abs())).max())
+
+    im = imnet_out.clone()
+    im[0, 5, 20, 30], im[1, 7, 40, 50], im[0, 9, 10, 10], im[0, 11, 12, 12] = 1e6, -3e5, M, 200000.0
+    im[1, 3, 30, 40], im[0, 2, 44, 70] = float("inf"), float("-inf")
+    acc = run(im, pred)
+    ssum, scnt = ref(im.clamp(-M, M), pred)
+    assert torch.isfinite(acc).all()
+    assert torch.equal(acc[:, 132:133], scnt)
+    assert rel(acc[:, :131], ssum) < 1e-6, "values beyond +-2^17 must contribute as +-2^17"
+    assert float((acc[:, :131] - ref(im.nan_to_num(posinf=3e38, neginf=-3e38), pred)[0]).abs().max()) > 1e5       # i.e. NOT the unclamped sum
+    im2 = imnet_out.clone()
+    im2[0, 5, 20, 30] = float("nan")
+    assert torch.isfinite(run(im2, pred)).all()
+    ssum0, scnt0 = ref(imnet_out, pred)
+    for bad in (float("nan"), float("inf"), float("-inf")):
+        pr2 = pred.clone()
+        pr2[0, 0, 20, 30], pr2[1, 1, 33, 44] = bad, bad
+        a3 = run(imnet_out, pr2)
+        pr3 = pred.clone()
+        pr3[0, 0, 20, 30], pr3[1, 1, 33, 44] = 1e3, 1e3                     # the same two sources sent far outside: no contribution
+        ssum3, scnt3 = ref(imnet_out, pr3)
+        assert torch.isfinite(a3).all()
+        assert torch.equal(a3[:, 132:133], scnt3) and not torch.equal(scnt3, scnt0)
+        assert rel(a3[:, :131], ssum3) < 1e-6
+
+
 def test_precontracted_splat_and_synth_equal_the_literal_path():
     """motif_splat_motif_pre_fwd + motif_siren_synth_pre_fwd (synth_net's first layer contracted into the splat sources:
     Ours.py:811-814 and 839-856 are linear) against the literal composition on the CPU: kernel-text splat of the 130

@@ -439,9 +439,9 @@ class _Keep(dict):
 
 
 _ORACLE_C2 = {}
-# measured at c2 full size (t = 0.5): TODO-MEASURED of the 921 600 cells (a source within 1e-7 px of a pixel boundary lands in the
-# neighbouring cell); the gate is 10x that, not the 2 % of rounds 1-3
-COUNT_MISMATCH_GATE = 2e-3
+# measured at c2 full size (t = 0.5): 1.3e-5 (bf16x3 engines) / 2.6e-5 (fp32 MFMA) of the 921 600 cells differ from the oracle's hit
+# count (a source within 1e-7 px of a pixel boundary lands in the neighbouring cell); the gate is 10x that, not the 2 % of rounds 1-3
+COUNT_MISMATCH_GATE = 2.6e-4
 
 
 def _oracle_c2():
@@ -463,7 +463,8 @@ def test_c2_full_size_parity_vs_oracle(mma_mode):
     """BASELINE config 2 (LR 180x320 -> 720x1280) at full size, timestamp t = 0.5, HIP path vs the CPU oracle (the
     restatement pinned bit-exact to the reference on the goldens).  Bars: PSNR(build, oracle) >= 60 dB, returned flow
     L-inf <= 2e-3 (LR-pixel units), LR RAFT flow L-inf <= 2e-3, encoder features within 2e-3, the integer hit-count plane
-    equal except where a source crosses a pixel boundary (< 2 % of cells), Y-PSNR vs the seeded GT within 0.05 dB."""
+    equal except where a source crosses a pixel boundary (gate 2.6e-4 of the cells = 10x the measured fraction), frame L-inf <= 1e-2
+    with at most 1e-5 of the values beyond 1e-3 (measured: 12 / 26 of 2 764 800), Y-PSNR vs the seeded GT within 0.05 dB."""
     from motif_amd.utils import util
     o = _oracle_c2()
     s = o["sample"]
