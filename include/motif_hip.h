@@ -40,7 +40,7 @@ int motif_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
  * environment ONCE, at its first call (MOTIF_<NAME> in upper case, e.g. MOTIF_CONV_ENGINE=1), never per launch; after that
  * the values change only through motif_set_option.  Every option defaults to 0 = "let the library choose"; none of them
  * changes a result beyond kernel-selection rounding.  Names: conv_dbg, conv_ck, conv_nospec, conv_engine (1 = always the
- * round-2 two-block 3x3 kernel, 2 / 3 / 4 = the round-3 kernel with 12- / 8-row tiles (one workgroup per CU) / 6-row tiles (two per CU) wherever it applies, 0 = by tile count), pp_rp (unused), lds_pad, corr81 (1 tiled / 2 small),
+ * round-2 two-block 3x3 kernel, 2 / 3 / 4 = the round-3 kernel with 12- / 8-row tiles (one workgroup per CU) / 6-row tiles (two per CU) wherever it applies, 5 = the round-4 Winograd F(2,3) kernel (conv_wino.hip) wherever it applies, 6 = never that one, 0 = the library's choice: the Winograd kernel for every eligible 3x3 layer with a plain epilogue, else by tile count), lds_pad, corr81 (1 tiled / 2 small),
  * dcn_nowin, dcn_waves (4 / 8), dcn_front_pad, dcn_back_pad, siren_stagger, conv_novec (1 = 4-byte staging in the fp32 engine), conv_nodirect (1 = the narrow layers on large maps stay on the MFMA engine instead of conv_direct.hip).  Returns MOTIF_EINVAL for an unknown name.
  * Not thread-safe against concurrent launches -- a test / tuning aid, not part of the data path. */
 int motif_set_option(const char* name, int value);
@@ -162,7 +162,13 @@ typedef struct MotifConvDesc {
                                  accumulate); 3 = 2-way split, 3 products (16-bit mantissa); 1 = plain bf16.
                                  Non-zero values apply to 3x3/stride-1 layers with > 32 couts and >= 16 input
                                  channels per group, every other layer runs mode 0.  The packed weight format
-                                 depends on it: pack and forward must be given the same value. */
+                                 depends on it: pack and forward must be given the same value.  With mode 6 the blob of
+                                 such a layer holds two fragment blocks, direct and Winograd F(2,3)-along-the-rows
+                                 (U = G g, formed in fp64 and split from there); which kernel runs is decided per launch
+                                 (layout, alignment, epilogue: option conv_engine).  The Winograd form has the same
+                                 6-product arithmetic with 2/3 of the matrix instructions; its rounding differs from the
+                                 direct form by one fp32 addition per operand and a three-term output sum (measured
+                                 against fp64: not larger than the direct form's error). */
 } MotifConvDesc;
 
 long motif_conv2d_packed_size(const MotifConvDesc* d);

@@ -2,7 +2,7 @@
 #include "common.h"
 #include <string.h>
 
-extern "C" int motif_abi_version(void) { return 4; }   // 4: motif_siren_imnet_add_fwd, g_lr = NULL in motif_splat_motif_pre_fwd, siren split blobs in turns; 3: motif_set_option / motif_get_option (2: MotifConvDesc.mma, motif_siren_pack_split + pre=2, splat row0)
+extern "C" int motif_abi_version(void) { return 5; }   // 5: option pp_rp removed, conv_engine 5 / 6 (conv_wino.hip), packed 3x3 blobs carry a Winograd block; 4: motif_siren_imnet_add_fwd, g_lr = NULL in motif_splat_motif_pre_fwd, siren split blobs in turns; 3: motif_set_option / motif_get_option (2: MotifConvDesc.mma, motif_siren_pack_split + pre=2, splat row0)
 
 extern "C" int motif_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len) {
     int dev = 0;
@@ -21,7 +21,7 @@ extern "C" int motif_device_info(int* cu_count, int* lds_bytes, char* arch, int 
 #include <stdlib.h>
 #include <ctype.h>
 namespace {
-const char* const kOptNames[MOTIF_OPT_COUNT] = {"conv_dbg", "conv_ck", "conv_nospec", "conv_engine", "pp_rp", "lds_pad", "corr81",
+const char* const kOptNames[MOTIF_OPT_COUNT] = {"conv_dbg", "conv_ck", "conv_nospec", "conv_engine", "lds_pad", "corr81",
                                                 "dcn_nowin", "dcn_waves", "dcn_front_pad", "dcn_back_pad", "siren_stagger", "conv_novec", "conv_nodirect"};
 struct OptTable {
     int v[MOTIF_OPT_COUNT];

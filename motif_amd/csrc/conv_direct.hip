@@ -269,13 +269,19 @@ __global__ __launch_bounds__(64 * NS) void conv_direct_deep_kernel(ConvArgs a) {
 
 // ---- host side (called from conv_igemm.hip's forward entry; the packed weights are conv_igemm's) -------------------------
 // Decided per launch (map size and alignment matter), never at pack time: both kernels read the same packed block.
+// tiny-Cout / deep-K form (flow heads): any map size that fills the chip.  ONE predicate for eligibility and launch.
+static bool direct_is_deep(const MotifConvDesc* d, int P) {
+    const int Cin = d->C0 + d->C1;
+    return d->Cout <= 4 && Cin >= 32 && (long)Cin * d->Cout * d->KH * d->KW <= 16384 && (long)d->N * P * d->H * d->W >= 16384 &&
+           (d->C1 == 0 || (d->C0 & 1) == 0);
+}
+
 bool motif_conv_direct_eligible(const MotifConvDesc* d, const ConvArgs& a, int P) {
     if (motif_opt(MOTIF_OPT_CONV_NODIRECT)) return false;
     if (d->groups != 1 || d->stride != 1 || d->dil != 1 || d->KH != d->KW || (d->KH != 1 && d->KH != 3) || d->pad != d->KH / 2) return false;
     if (d->KH == 3 && d->pad_mode != 0) return false;
     const int Cin = d->C0 + d->C1;
-    const bool deep = d->Cout <= 4 && Cin >= 32 && (long)Cin * d->Cout * d->KH * d->KW <= 16384 && (long)d->N * P * d->H * d->W >= 16384 &&
-                      (d->C1 == 0 || (d->C0 & 1) == 0);                      // tiny-Cout / deep-K form (flow heads): any map size that fills the chip
+    const bool deep = direct_is_deep(d, P);
     if (!deep && (d->Cout > 16 || Cin > 64)) return false;
     if (d->W & 3) return false;               // measured on the 360x640 layers: 32->8 38 -> 22 us, 8->8 3x3 33 -> 24,
                                                                              // 32->16 40 -> 29; 8->32 (store bound, two cout slices) 27 -> 31: not taken
@@ -292,19 +298,15 @@ bool motif_conv_direct_eligible(const MotifConvDesc* d, const ConvArgs& a, int P
 int motif_conv_direct_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s) {
     a.Ho = d->H; a.Wo = d->W; a.Cin_g = d->C0 + d->C1; a.Cout_g = d->Cout;
     const long quads = (long)(d->W >> 2) * d->H;
-    if (d->Cout <= 4 && a.Cin_g >= 32) {                 // deep form: 8 channel slices (waves) per 64 pixel quads
+    if (direct_is_deep(d, P)) {                          // deep form: 8 channel slices (waves) per 64 pixel quads
         dim3 grid((unsigned)((quads + 63) / 64), 1, d->N * P);
         if (d->KH == 1) conv_direct_deep_kernel<4, 1, 8><<<grid, 512, 0, s>>>(a); else conv_direct_deep_kernel<4, 3, 8><<<grid, 512, 0, s>>>(a);
         MOTIF_LAUNCH_CHECK();
         return MOTIF_OK;
     }
-    const int nco = d->Cout <= 16 ? 8 : 16;
+    constexpr int nco = 8;                               // eligibility caps Cout at 16: cout slices of 8 (a 16-wide slice was never reachable)
     dim3 grid((unsigned)((quads + 255) / 256), (d->Cout + nco - 1) / nco, d->N * P);
-    if (d->KH == 1) {
-        if (nco == 8) conv_direct_kernel<8, 1><<<grid, 256, 0, s>>>(a); else conv_direct_kernel<16, 1><<<grid, 256, 0, s>>>(a);
-    } else {
-        if (nco == 8) conv_direct_kernel<8, 3><<<grid, 256, 0, s>>>(a); else conv_direct_kernel<16, 3><<<grid, 256, 0, s>>>(a);
-    }
+    if (d->KH == 1) conv_direct_kernel<8, 1><<<grid, 256, 0, s>>>(a); else conv_direct_kernel<8, 3><<<grid, 256, 0, s>>>(a);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

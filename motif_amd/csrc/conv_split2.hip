@@ -417,19 +417,17 @@ int motif_conv_split2_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStre
     const long rounds12 = (T12 + cus - 1) / cus;
     const int force = motif_opt(MOTIF_OPT_CONV_ENGINE);
     const bool big = force == 2 || (force != 3 && (double)T12 / (double)(rounds12 * cus) >= 0.9);      // else: 8-row tiles (T8 <= CUs, or forced)
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_split2_kernel<8, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_split2_kernel<8, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    // per launch, like the other kernels: a process-wide "done once" flag is neither per device nor thread-safe
+    {
+        const void* kfn = (force == 4) ? (const void*)conv_split2_kernel<4, 3, 1> : big ? (const void*)conv_split2_kernel<8, 3, 1> : (const void*)conv_split2_kernel<8, 2, 1>;
+        const hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, force == 4 ? 80 * 1024 : 160 * 1024);
+        if (e != hipSuccess) return (int)e;
     }
     if (force == 4) {                                    // 6-row tiles, two 4-wave workgroups per CU: best on the smallest maps in isolation
                                                          // (+10 ... +35 % on 45x80 / 90x160 single launches), a draw or worse inside the model; opt-in
         const long T6 = per_row_tile * ((Ho + 5) / 6);
         const int G = (int)(T6 < 2 * cus ? T6 : 2 * cus);
         const size_t ldsb = ((size_t)4 * 16 + (size_t)2 * 3 * (2 * 8 * 34 + 4) + (size_t)4 * 320) * 16;
-        static bool attr4 = false;
-        if (!attr4) { (void)hipFuncSetAttribute((const void*)conv_split2_kernel<4, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr4 = true; }
         conv_split2_kernel<4, 3, 1><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T6, (Ho + 5) / 6);
     } else if (big) {
         const int G = (int)(T12 < cus ? T12 : cus);

@@ -1,10 +1,16 @@
 // Fused reliability-aware soft-splat (forward warping) for gfx950.
 //
-// One thread per SOURCE pixel: the target corner indices and bilinear weights are computed once
-// (the reference recomputes flow+floor for every one of its 131 channels), then the channel loop
-// scatters with global_atomic_add_f32 (built with -munsafe-fp-atomics).  A wave's 64 lanes are 64
-// consecutive x of one source row, so for smooth flow every per-channel atomic instruction lands on
-// 1-2 contiguous cache lines of the accumulator plane.  Sum, max and count share the index math.
+// Two forms.  The OPERATOR form (motif_splat_fwd, the reference's module surface) and the fall-back for far sources: one thread
+// per SOURCE pixel, the target corner indices and bilinear weights computed once (the reference recomputes flow+floor for every one
+// of its 131 channels), then a channel loop of global_atomic_add_f32 (built with -munsafe-fp-atomics).  The fused MoTIF form
+// (motif_splat_motif_*_fwd, the product path) is OWNER-COMPUTES: a workgroup owns a 16 x 64 tile of the accumulator, lists the
+// sources of both directions that touch it, buckets the (source, corner) pairs by cell and GATHERS them, one thread per cell, into
+// exact integer sums in registers -- no global atomics, no zero fill, bit-reproducible (see the block comment further down).
+//
+// Edges of the fused form (tests/test_kernels_gpu.py::test_splat_motif_value_clamp_and_non_finite_inputs): plane values are clamped
+// to +-2^17 when they are staged (so +-Inf contribute as +-2^17 and a NaN leaves the accumulator finite -- the reference's float
+// atomicAdd would propagate both); a source whose flow is not finite touches no cell, the hit count included (the reference
+// asserts finite flows up front, softsplat_cp.py:25-26).  Far sources (fall-back kernel) are not clamped.
 //
 // Bit-level contract with the kernel text (softsplat_cp.py:27-38 etc.): floor -> int corners, weights
 // as (SE - o) products, bounds test >=0 & <size, addend = (value*e^z) rounded, then * weight rounded.
@@ -123,10 +129,10 @@ extern "C" int motif_splat_fwd(const float* src, const float* flow, const float*
 //      softsplat_max_cp.py:12-58, before its init-1 clamp), its binary exponent E, and the hit count (LDS integer atomics,
 //      once per tile, not per plane);
 //   2. the (source, corner) pairs are bucketed by cell (prefix sum of the counts, one returning atomic per pair);
-//   3. per chunk of 8 planes: every listed source stages value*e^z (fp32, rounded as softsplat_cp.py:35-40 rounds it) in LDS,
+//   3. per chunk of OT_CC = 4 planes: every listed source stages value*e^z (fp32, rounded as softsplat_cp.py:35-40 rounds it) in LDS,
 //      then every cell walks its bucket: addend = staged value * corner weight (fp32, the reference's addend bit for bit),
-//      scaled by 2^(32-E) and rounded to an integer in double precision (one fma against 1.5*2^52) and summed in a double
-//      REGISTER accumulator -- sums of integers below 2^53 are exact, so the result does not depend on the order of the
+//      scaled by 2^(32-E) and rounded to an integer in double precision (one fma against 1.5*2^52); the RAW BITS of those doubles are
+//      summed as 64-bit integers in registers (see FIX_MAGIC below) -- integer sums are exact, so the result does not depend on the order of the
 //      bucket (which the atomics of step 2 do not fix) and is bit-identical run to run and across tilings;
 //   4. the sum is scaled back by 2^(E-32) and rounded to fp32 ONCE, and stored with plain coalesced stores.
 // The per-cell scale E exists because the reliability weight e^z = exp(-20 relu(p2)) (Ours.py:794) spans the whole fp32
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(OT_THREADS) void splat_owner_kernel(MotifSplatArgs 
     for (int i = tid; i < OT_TP; i += OT_THREADS) texp[i] = (signed char)min(cell_exponent(tmaxb[i]), 127);
     __syncthreads();
 
-    constexpr int NPL = PRE ? 64 : 130, NCH = NPL / OT_CC, NREM = NPL - NCH * OT_CC;    // 130 = 16*8 + 2, 64 = 8*8 + 0
+    constexpr int NPL = PRE ? 64 : 130, NCH = NPL / OT_CC, NREM = NPL - NCH * OT_CC;    // OT_CC = 4 planes per chunk: 130 = 32*4 + 2, 64 = 16*4 + 0
     float* abase = a.acc + (long)bn * (NPL + 3) * Q;
     // c is uniform (chunk index * 8 + unrolled plane)
     auto plane_value = [&](int c, const Ent& t) -> float {

@@ -31,10 +31,8 @@ def main():
     only = os.environ.get("ONLY")
     from motif_amd import ops
     if os.environ.get("ENGINE"):
-        ops.set_option("conv_engine", int(os.environ["ENGINE"]))      # 1 = round-2 two-block kernel, 2 = round-3 kernel, 0 = by tile count
-    if os.environ.get("RP"):
-        ops.set_option("pp_rp", int(os.environ["RP"]))
-    print("conv mma mode", ops.get_conv_mma(), "engine", ops.get_option("conv_engine"), "pp_rp", ops.get_option("pp_rp"))
+        ops.set_option("conv_engine", int(os.environ["ENGINE"]))      # 1 = round-2 two-block kernel, 2 / 3 = round-3 kernel, 5 = round-4 Winograd kernel, 6 = never it, 0 = the library's choice
+    print("conv mma mode", ops.get_conv_mma(), "engine", ops.get_option("conv_engine"))
     for i, (n, ci, co, k, s, h, w) in enumerate(SHAPES):
         if only is not None and int(only) != i:
             continue
