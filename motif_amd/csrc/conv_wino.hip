@@ -95,11 +95,21 @@ struct WSched {
         int f = 0;
         int pslot[NLD] = {};
         for (int i = 0; i < NLD; ++i) { ext[f] = (WP_PARK << 8) | i; pslot[i] = f; f += 4; }
+#ifndef WINO_LATE_LOADS
         for (int i = 0; i < NLD; ++i) {
             const int ls = pslot[i] + 2;                                         // a row piece is requested right after its park
             if (rl[ls] >= 0 || ra[ls] >= 0) clash = 1;
             rl[ls] = i;
         }
+#else
+        {   // experiment: requests spread over super-steps 2..5 (the L1 path of super-steps 0 / 1 carries the parks' neighbours only)
+            constexpr int lslot[NLD] = {2 * M + 6, 2 * M + 12, 3 * M + 2, 3 * M + 6, 3 * M + 12, 4 * M + 2, 4 * M + 6, 4 * M + 12, 5 * M + 2, 5 * M + 6};
+            for (int i = 0; i < NLD; ++i) {
+                if (rl[lslot[i]] >= 0 || ra[lslot[i]] >= 0) clash = 1;
+                rl[lslot[i]] = i;
+            }
+        }
+#endif
         for (int r = 0; r < 16; ++r) ext[f++] = (WP_READ << 8) | r;
         for (int r = 0; r < 2; ++r) ext[f++] = (WP_HREAD << 8) | r;
         for (int pos = 0; pos < 4; ++pos)
