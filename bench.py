@@ -235,7 +235,7 @@ def instrumented_clip(model, sample):
     in_stages = sum(s["ms"] for s in stages.values())
     table["_clip"] = {"ms_instrumented": round(c0.elapsed_time(c1), 3), "ms_in_stages": round(in_stages, 3), "calls_in_stages": len(rec),
                       "ms_outside_stages": round(c0.elapsed_time(c1) - in_stages, 3),
-                      "note": "outside = torch glue kernels (cat / copy / index_select / fill: ~100 launches, profiles/r03_bench_kernel_stats.txt) plus the "
+                      "note": "outside = torch glue kernels (cat / copy / index_select / fill: ~100 launches, profiles/r04_bench_kernel_stats.txt) plus the "
                               "idle time between an event pair's end and the next launch of this serialised, event-instrumented run; the timed "
                               "bench loop has neither the events nor the serialisation"}
     big = [(e0.elapsed_time(e1), d) for stage, e0, e1, _, d in rec if stage == "conv3x3"]
@@ -613,7 +613,7 @@ def main():
             ach = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
             split = a.mma == "bf16x3"
             traffic, traffic_src = None, None
-            for name in ("r03_conv_traffic.json", "r02_conv_split_traffic.json") if split else ("r01_conv_traffic.json",):
+            for name in ("r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_split_traffic.json") if split else ("r01_conv_traffic.json",):
                 tj = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tj):          # rocprofv3 PMC passes of this kernel (FETCH_SIZE / WRITE_SIZE), not collected in this run
                     tdoc = json.load(open(tj))
