@@ -152,6 +152,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     u32x4* stg0 = lds_raw + WAVES * 16;                               // [2 buffers][NP][SLOTS]
     u32x4* land = lds_raw + WAVES * 16 + 2 * STG + wave * LW;         // [WAVES][LW]: fp32 landing area / epilogue scratch
     const float* landf = (const float*)land;
+    constexpr int TT = 128;                              // tile-parameter table: [TT][4] x 16 bytes, entry = ordinal of the tile in this workgroup
+    u32x4* ttab = lds_raw + WAVES * 16 + 2 * STG + WAVES * LW;
 
     const int G = gridDim.x, bq = xcd_block_id(blockIdx.x, G);
     if (bq >= ntiles) return;
@@ -160,35 +162,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int HW = a.H * a.W;
     const unsigned HWo = (unsigned)(a.Ho * a.Wo);
 
-    // tile coordinates as mixed-radix digits (cout group | column | row | image), advanced by G's digits: no division per tile
-    struct TileC { int cgg, tx, ty, z; };
-    auto coords_of = [&](int t) __attribute__((always_inline)) {
-        TileC c;
-        c.cgg = t % ncgG; int s = t / ncgG;
-        c.tx = s % a.tiles_x; s /= a.tiles_x;
-        c.ty = s % tiles_y; c.z = s / tiles_y;
-        return c;
-    };
-    const TileC stepc = coords_of(__builtin_amdgcn_readfirstlane(G));
-    auto advance = [&](TileC c) __attribute__((always_inline)) {
-        c.cgg += stepc.cgg; int cy = c.cgg >= ncgG; c.cgg -= cy ? ncgG : 0;
-        c.tx += stepc.tx + cy; cy = c.tx >= a.tiles_x; c.tx -= cy ? a.tiles_x : 0;
-        c.ty += stepc.ty + cy; cy = c.ty >= tiles_y; c.ty -= cy ? tiles_y : 0;
-        c.z += stepc.z + cy;
-        return c;
-    };
-    auto decode = [&](const TileC& c, int& n, int& pz, int& g, int& cg, int& ty, int& tx) __attribute__((always_inline)) {
-        tx = c.tx; ty = c.ty;
-        g = a.ncg == ncgG ? 0 : c.cgg / a.ncg; cg = c.cgg - g * a.ncg;
-        if constexpr (MULTI) { pz = (c.z >= a.N) + (c.z >= 2 * a.N) + (c.z >= 3 * a.N); n = c.z - pz * a.N; }
-        else { pz = 0; n = c.z; }
-    };
-
     // Per-problem launch arguments by CONSTANT index + scalar selects: a dynamic index into the kernel-argument arrays becomes a
     // VECTOR load whose result every later use waits for with vmcnt(0) -- i.e. for all the row pieces and weight fragments in flight.
     auto pick = [](const auto (&arr)[MOTIF_MAX_PROBLEMS], int pz) __attribute__((always_inline)) {
         if constexpr (!MULTI) return arr[0];
         else return pz == 0 ? arr[0] : pz == 1 ? arr[1] : pz == 2 ? arr[2] : arr[3];
+    };
+
+    // ---- tile parameters.  Tile e of this workgroup = bq + e * G; its coordinates (three integer divisions), source / weight / output /
+    // residual / bias addresses (64-bit multiply-adds, per-problem selects) are computed by ONE LANE EACH of wave 0 -- 64 tiles at a
+    // time on the vector ALU -- and parked in LDS; a tile change then costs four broadcast ds_read_b128 and sixteen readfirstlanes
+    // instead of ~150 dependent scalar instructions (a lone wave hides none of them: they were 1-1.5 k of a tile's 34 k cycles).
+    struct TileP { const float* in0n; const float* in1n; const u32x4* wb; float* ob; const float* rb; const float* bp; int ty, tx, g, clg, cbg; };
+    auto fill_table = [&](int e0) __attribute__((always_inline)) {       // entries e0 .. e0 + 63, by the 64 lanes of the calling wave
+        const int e = e0 + lane;
+        const long tl = (long)bq + (long)e * G;
+        if (tl < ntiles) {
+            const int tt = (int)tl;
+            const int cgg = tt % ncgG; int s2 = tt / ncgG;
+            const int tx = s2 % a.tiles_x; s2 /= a.tiles_x;
+            const int ty = s2 % tiles_y, z = s2 / tiles_y;
+            const int g = a.ncg == ncgG ? 0 : cgg / a.ncg, cg = cgg - g * a.ncg;
+            int pz = 0, n = z;
+            if constexpr (MULTI) { pz = (z >= a.N) + (z >= 2 * a.N) + (z >= 3 * a.N); n = z - pz * a.N; }
+            const long HWol = (long)a.Ho * a.Wo;
+            const int cbg = g * a.Cout_g + cg * 64;
+            const unsigned long long i0 = (unsigned long long)(pick(a.in0, pz) + (long)n * pick(a.in0_bs, pz));
+            const float* i1p = pick(a.in1, pz);
+            const unsigned long long i1 = i1p ? (unsigned long long)(i1p + (long)n * pick(a.in1_bs, pz)) : 0ull;
+            const unsigned long long wb = (unsigned long long)((const u32x4*)pick(a.wp, pz) + (long)(g * a.ncg + cg) * a.Kpad * (NP * 2 * 64));
+            const unsigned long long ob = (unsigned long long)(pick(a.out, pz) + (long)n * pick(a.out_bs, pz) + (long)cbg * HWol);
+            const float* rp = pick(a.res, pz);
+            const unsigned long long rb = (a.res_mode && rp) ? (unsigned long long)(rp + (long)n * pick(a.res_bs, pz) + (long)cbg * HWol) : 0ull;
+            const float* bpp = pick(a.bias, pz);
+            const unsigned long long bp = bpp ? (unsigned long long)(bpp + cbg) : 0ull;
+            u32x4* r = ttab + (e & (TT - 1)) * 4;
+            r[0] = u32x4{(unsigned)i0, (unsigned)(i0 >> 32), (unsigned)i1, (unsigned)(i1 >> 32)};
+            r[1] = u32x4{(unsigned)wb, (unsigned)(wb >> 32), (unsigned)ob, (unsigned)(ob >> 32)};
+            r[2] = u32x4{(unsigned)rb, (unsigned)(rb >> 32), (unsigned)bp, (unsigned)(bp >> 32)};
+            r[3] = u32x4{(unsigned)ty | ((unsigned)tx << 16), (unsigned)g, (unsigned)(a.Cout_g - cg * 64), (unsigned)cbg};
+        }
+    };
+    auto load_tile = [&](int e) __attribute__((always_inline)) {         // uniform: every lane reads the same entry
+        const u32x4* r = ttab + (e & (TT - 1)) * 4;
+        const u32x4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+        auto sg = [](unsigned v) __attribute__((always_inline)) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+        auto p64 = [&](unsigned lo, unsigned hi) __attribute__((always_inline)) { return ((unsigned long long)sg(hi) << 32) | (unsigned long long)sg(lo); };
+        TileP t;
+        t.in0n = (const float*)p64(r0[0], r0[1]); t.in1n = (const float*)p64(r0[2], r0[3]);
+        t.wb = (const u32x4*)p64(r1[0], r1[1]); t.ob = (float*)p64(r1[2], r1[3]);
+        t.rb = (const float*)p64(r2[0], r2[1]); t.bp = (const float*)p64(r2[2], r2[3]);
+        const unsigned yx = sg(r3[0]);
+        t.ty = (int)(yx & 0xffffu); t.tx = (int)(yx >> 16); t.g = (int)sg(r3[1]); t.clg = (int)sg(r3[2]); t.cbg = (int)sg(r3[3]);
+        return t;
     };
 
     // ---- per-lane constants of the staging role (row pair T = wave) ------------------------------------------------------
@@ -218,34 +244,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int origin = 0;                                      // byte offset of the tile's first staged pixel within a plane (uniform)
     const float* in0n = nullptr; const float* in1n = nullptr;
     int st_g = 0;
-    auto wptr = [&](const TileC& t) __attribute__((always_inline)) {
-        int n, pz, g, cg, ty, tx;
-        decode(t, n, pz, g, cg, ty, tx);
-        const u32x4* base = (const u32x4*)pick(a.wp, pz) + (long)(g * a.ncg + cg) * a.Kpad * (NP * 2 * 64);
-        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    auto wptr = [&](const TileP& t) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)t.wb, 0, 0x7fffffff, 0x00020000);
     };
     const int wvoff = (ct * 64 + lane) * 16;
     auto wfrag = [&](__amdgpu_buffer_rsrc_t wb, int ks, int p) __attribute__((always_inline)) {
         return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wb, wvoff, (ks * NP + p) * (2 * 64 * 16), 0));
     };
-    auto bias_of = [&](const TileC& t) __attribute__((always_inline)) {
-        int n, pz, g, cg, ty, tx;
-        decode(t, n, pz, g, cg, ty, tx);
-        const float* bp = pick(a.bias, pz);
-        return (bp && lane < 32 && cg * 64 + ct * 32 + lane < a.Cout_g) ? bp[g * a.Cout_g + cg * 64 + ct * 32 + lane] : 0.f;
+    auto bias_of = [&](const TileP& t) __attribute__((always_inline)) {
+        return (t.bp && lane < 32 && ct * 32 + lane < t.clg) ? t.bp[ct * 32 + lane] : 0.f;
     };
-    auto setup_loads = [&](const TileC& t, bool valid) __attribute__((always_inline)) {
-        int n, pz, g, cg, ty, tx;
-        decode(t, n, pz, g, cg, ty, tx);
-        st_g = g;
-        in0n = pick(a.in0, pz) + (long)n * pick(a.in0_bs, pz);
-        in1n = pick(a.in1, pz) ? pick(a.in1, pz) + (long)n * pick(a.in1_bs, pz) : nullptr;
-        const int iy0 = ty * TH - 1 + 2 * wave, x0 = tx * 32 - 4;      // pad 1; rows start 4 pixels left of the tile: aligned quads
+    auto setup_loads = [&](const TileP& t, bool valid) __attribute__((always_inline)) {
+        st_g = t.g;
+        in0n = t.in0n;
+        in1n = t.in1n;
+        const int iy0 = t.ty * TH - 1 + 2 * wave, x0 = t.tx * 32 - 4;  // pad 1; rows start 4 pixels left of the tile: aligned quads
+        const int rlo = iy0 < 0 ? -iy0 : 0, rhi = valid ? (a.H - iy0 < 4 ? a.H - iy0 : 4) : 0;
+        const int qlo = x0 < 0 ? 1 : 0, qhi = (a.W - x0) >> 2;         // W % 4 == 0, x0 % 4 == 0
         origin = (iy0 * a.W + x0) * 4;
         if (valid && iy0 >= 0 && iy0 + 4 <= a.H && x0 >= 0 && x0 + 40 <= a.W) { vmask = 0x3ffu; return; }   // interior tile: every piece inside
         vmask = 0;
-        const int rlo = iy0 < 0 ? -iy0 : 0, rhi = valid ? (a.H - iy0 < 4 ? a.H - iy0 : 4) : 0;
-        const int qlo = x0 < 0 ? 1 : 0, qhi = (a.W - x0) >> 2;         // W % 4 == 0, x0 % 4 == 0
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const unsigned f6 = ((i < 5 ? rx0 >> (6 * i) : rx1 >> (6 * (i - 5)))) & 63u;
@@ -399,6 +417,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ++trace_chunk;
 #endif
     };
+    int ti = 0;                                          // ordinal of the current tile in this workgroup
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl)
@@ -410,16 +429,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // After a tile's last chunk: inverse transform + bias in the C/D layout, then four passes of 8 couts x 4 rows x 32 pixels through
     // the landing area (free between the last read-back and the next chunk's parks): lane item it of a pass = cout half + 2 it, row
     // l31 / 8, columns 4 (l31 % 8) .. + 3 -- residual, activation, one 16-byte store.
-    auto finish_tile = [&](const TileC& t) __attribute__((always_inline)) {
-        int n, pz, g, cg, ty, tx;
-        decode(t, n, pz, g, cg, ty, tx);
-        const int cb = g * a.Cout_g + cg * 64 + ct * 32, cl = a.Cout_g - cg * 64 - ct * 32;
+    auto finish_tile = [&](const TileP& t) __attribute__((always_inline)) {
+        const int ty = t.ty, tx = t.tx;
+        const int cb = t.cbg + ct * 32, cl = t.clg - ct * 32;
         if (cl <= 0 || (WINO_ABL & 256)) { zero_acc(); return; }        // the upper cout tile of a partial group has nothing to store
-        const long HWol = (long)a.Ho * a.Wo;
-        const unsigned long long obv = (unsigned long long)(pick(a.out, pz) + (long)n * pick(a.out_bs, pz) + (long)cb * HWol);
-        const unsigned ob_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(obv >> 32)), ob_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)obv);
-        const unsigned long long obp = ((unsigned long long)ob_hi << 32) | (unsigned long long)ob_lo;      // uniform: the stores take it in SGPRs
-        const float* rb = a.res_mode ? pick(a.res, pz) + (long)n * pick(a.res_bs, pz) + (long)cb * HWol : nullptr;
+#ifdef MOTIF_TRACE
+        long long es[8];
+        int esn = 0;
+        es[esn++] = __builtin_amdgcn_s_memtime();
+#define EPSTAMP() do { if (esn < 8) es[esn++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define EPSTAMP()
+#endif
+        const unsigned long long obp = (unsigned long long)(t.ob + (long)(ct * 32) * (long)HWo);            // uniform: the stores take it in SGPRs
+        const float* rb = t.rb ? t.rb + (long)(ct * 32) * (long)HWo : nullptr;
         const int rm = a.res_mode;
         int lane_e = lane;                               // opaque copy: keeps the per-lane geometry inside the tile loop
         asm volatile("" : "+v"(lane_e));
@@ -437,6 +460,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int it = 0; it < 4; ++it) rv[pass][it] = *(const f32x4*)(rb + (okv(pass, it) ? offv(pass, it) : 0u));   // masked lanes read element 0
         };
         if (rm) { load_res(0); load_res(1); load_res(2); load_res(3); }
+        EPSTAMP();
         float* scr = (float*)land;                       // two halves of [8 couts][4 rows x 32 px]
         const int ew = hf * 512 + l5, er = hf * 128 + (l5 >> 3) * 32 + (l5 & 7) * 4;
         // pass p = couts 8p .. 8p+7 = registers 4p .. 4p+3 of every accumulator: inverse transform + bias of those 16 values, transpose
@@ -464,6 +488,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int rmv = RM >= 0 ? RM : rm;
             const unsigned long long obq = obp;
             write_pass(0);
+            EPSTAMP();
             // every residual quad is waited for BEFORE the first (uncounted) store: behind a store the counted wait of a later quad
             // could only end when that store has completed too
             if (rmv) asm volatile("" :: "v"(rv[3][0]), "v"(rv[3][1]), "v"(rv[3][2]), "v"(rv[3][3]));
@@ -498,6 +523,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         const f32x4 val = v[it];
                         asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(bo), "v"(val), "s"(obq) : "memory");
                     }
+                EPSTAMP();
             }
         };
         using I = std::integral_constant<int, 0>;
@@ -508,21 +534,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         else if (rm == 0 && act == MOTIF_ACT_LRELU) passes(std::integral_constant<int, MOTIF_ACT_LRELU>{}, I{});
         else if (rm == 1 && act == MOTIF_ACT_NONE) passes(std::integral_constant<int, MOTIF_ACT_NONE>{}, std::integral_constant<int, 1>{});
         else if (rm == 1 && act == MOTIF_ACT_LRELU) passes(std::integral_constant<int, MOTIF_ACT_LRELU>{}, std::integral_constant<int, 1>{});
+        else if (rm == 1 && act == MOTIF_ACT_RELU) passes(std::integral_constant<int, MOTIF_ACT_RELU>{}, std::integral_constant<int, 1>{});
         else if (rm == 2 && act == MOTIF_ACT_RELU) passes(std::integral_constant<int, MOTIF_ACT_RELU>{}, std::integral_constant<int, 2>{});
         else passes(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
+#ifdef MOTIF_TRACE
+        if (lane == 0 && blockIdx.x < 256 && ti < 8) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) g_wn_trace2[((blockIdx.x * 4 + wave) * 8 + ti) * 8 + i] = i < esn ? es[i] : 0;
+        }
+#endif
+#undef EPSTAMP
     };
 
     // ---- prologue: step 0 staged in full, the row pieces of step 1 requested (nothing to hide them under) --------------------
     int t = bq;
-    TileC tc = coords_of(__builtin_amdgcn_readfirstlane(t)), tn = tc;
     WNTRACE(0);
     zero_acc();
-    setup_loads(tc, true);
-    wbase = wnext = wptr(tc);
+    if (wave == 0) {
+        fill_table(0);
+        if ((long)bq + 64L * G < ntiles) fill_table(64);
+    }
+    __syncthreads();
+    {
+        const TileP t0 = load_tile(0);
+        setup_loads(t0, true);
+        wbase = wnext = wptr(t0);
+    }
     loadw(wbase, 0, wf[0]);
     loadw(wbase, 1, wf[1]);
     loadw(wbase, 2, wf[2]);
-    float bias_v = bias_of(tc);
+    float bias_v = bias_of(load_tile(0));
 #pragma unroll
     for (int i = 0; i < NLD; ++i) st_load(i, 0);
     static_for<WSched::S>([&](auto ic) __attribute__((always_inline)) { piece(std::integral_constant<int, kWSched.ext[decltype(ic)::value]>{}, stg0); });
@@ -539,8 +580,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const bool has_next = t_next < ntiles;
         for (int c = 0; c < nch; ++c) {
             if (c == nch - 2) {                          // from here on the row-piece requests belong to the next tile
-                if (has_next) { tn = advance(tc); wnext = wptr(tn); bias_v = bias_of(tn); } else wnext = wbase;
-                setup_loads(tn, has_next);
+                const TileP tq = load_tile(has_next ? ti + 1 : ti);
+                if (has_next) { wnext = wptr(tq); bias_v = bias_of(tq); } else wnext = wbase;
+                setup_loads(tq, has_next);
             }
             const bool last = c + 1 == nch;
             const int sc = last ? 0 : c + 1, lc0 = (c + 2 < nch ? c + 2 : c + 2 - nch) * 16;
@@ -548,7 +590,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             chunk_body(c, buf, sc, wn, lc0);
             if (slot < 29) WNTRACE(slot);                // trace: body end | epilogue end | barrier passed, for the first 9 chunks
             if (last) {
-                finish_tile(tc);
+                finish_tile(load_tile(ti));
                 if (lane < 32) bias_w[lane] = bias_v;    // the next tile's bias (this tile's has just been read)
             }
             if (slot < 29) WNTRACE(slot + 1);
@@ -557,7 +599,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (slot < 29) { WNTRACE(slot + 2); slot += 3; }
         }
         if (!has_next) break;
-        t = t_next; tc = tn; wbase = wnext;
+        t = t_next; ++ti; wbase = wnext;
+        // the table is a ring of 128 entries: when the first half of an epoch of 64 tiles begins, the entries of the epoch after next go
+        // where the epoch before lay (every wave has passed the last barrier of tile ti - 1, the last reader of those)
+        if ((ti & 63) == 0 && wave == 0) fill_table(ti + 64);
     }
     WNTRACE(31);
 }
@@ -655,7 +700,7 @@ int motif_conv_wino_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream
     const long T = (long)a.tiles_x * ncgG * d->N * P * tiles_y;
     if (T >= 0x7fffffffL) return MOTIF_ELIMIT;
     const int G = (int)(T < cus ? T : cus);
-    const size_t ldsb = ((size_t)4 * 16 + (size_t)2 * 3 * (2 * 16 * 34 + 4) + (size_t)4 * 640) * 16;
+    const size_t ldsb = ((size_t)4 * 16 + (size_t)2 * 3 * (2 * 16 * 34 + 4) + (size_t)4 * 640 + (size_t)128 * 4) * 16;      // bias | staging | landing | tile table
     hipError_t e = hipFuncSetAttribute(P > 1 ? (const void*)conv_wino_kernel<true> : (const void*)conv_wino_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     if (P > 1) conv_wino_kernel<true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);

@@ -39,7 +39,7 @@ def main():
         m = Conv2d(ci, co, k, s, k // 2).cuda()
         x = torch.randn(n, ci, h, w, device="cuda")
         res = torch.randn(n, co, h // s, w // s, device="cuda") if os.environ.get("RES") else None
-        kw = dict(act=1, res=res, res_mode=1) if res is not None else dict(act=1)
+        kw = dict(act=int(os.environ.get("ACT", "1")), res=res, res_mode=1) if res is not None else dict(act=int(os.environ.get("ACT", "1")))
         for _ in range(3):
             y = m(x, **kw)
         torch.cuda.synchronize()

@@ -14,7 +14,7 @@ n, ci, co, k, s, h, w = SHAPES[int(sys.argv[1]) if len(sys.argv) > 1 else 0]
 m = Conv2d(ci, co, k, s, k // 2).cuda()
 x = torch.randn(n, ci, h, w, device="cuda")
 res = torch.randn(n, co, h // s, w // s, device="cuda") if os.environ.get("RES") else None
-kw = dict(act=1, res=res, res_mode=1) if res is not None else dict(act=1)
+kw = dict(act=int(os.environ.get("ACT", "1")), res=res, res_mode=1) if res is not None else dict(act=int(os.environ.get("ACT", "1")))
 for _ in range(3):
     y = m(x, **kw)
 torch.cuda.synchronize()
@@ -46,12 +46,9 @@ buf2 = (ctypes.c_longlong * (256 * 4 * 8 * 8))()
 lib.motif_debug_wino_trace2.restype = ctypes.c_int
 rc = lib.motif_debug_wino_trace2(buf2, 256 * 4 * 8 * 8)
 t2 = np.frombuffer(buf2, dtype=np.int64).reshape(256, 4, 8, 8).astype(np.float64)
-print("per super-step (cycles): chunk | ss0 .. ss5 | total   [mean over blocks and waves]")
-for c in range(8):
-    d = t2[:, :, c, 1:7] - t2[:, :, c, 0:6]
-    okc = (t2[:, :, c, 0] > 0) & (t2[:, :, c, 6] > 0)
+print("epilogue of the first tiles (cycles): setup + residual requests | transform + transpose of pass 0 | pass 0 | pass 1 | pass 2 | pass 3")
+for k in range(3):
+    okc = (t2[:, :, k, 0] > 0) & (t2[:, :, k, 6] > 0)
     if okc.any():
-        print("  staged chunk %d: %s | %6.0f" % (c, " ".join("%6.0f" % d[..., i][okc].mean() for i in range(6)), (t2[:, :, c, 6] - t2[:, :, c, 0])[okc].mean()))
-for wv in range(4):
-    d = t2[:, wv, 1, 1:7] - t2[:, wv, 1, 0:6]
-    print("  wave %d chunk 1: %s" % (wv, " ".join("%6.0f" % d[:, i].mean() for i in range(6))))
+        d = t2[:, :, k, 1:7] - t2[:, :, k, 0:6]
+        print("  tile %d: %s | total %6.0f" % (k, " ".join("%6.0f" % d[..., i][okc].mean() for i in range(6)), (t2[:, :, k, 6] - t2[:, :, k, 0])[okc].mean()))
