@@ -152,6 +152,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     u32x4* stg0 = lds_raw + WAVES * 16;                               // [2 buffers][NP][SLOTS]
     u32x4* land = lds_raw + WAVES * 16 + 2 * STG + wave * LW;         // [WAVES][LW]: fp32 landing area / epilogue scratch
     const float* landf = (const float*)land;
+    u32x4 zq = {0u, 0u, 0u, 0u};                         // see init_acc
+    asm volatile("" : "+v"(zq));
     constexpr int TT = 128;                              // tile-parameter table: [TT][4] x 16 bytes, entry = ordinal of the tile in this workgroup
     u32x4* ttab = lds_raw + WAVES * 16 + 2 * STG + WAVES * LW;
 
@@ -418,13 +420,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
     };
     int ti = 0;                                          // ordinal of the current tile in this workgroup
-    auto zero_acc = [&]() __attribute__((always_inline)) {
+    // Accumulators of a new tile: zero, except position 1, which starts from the bias (M1 enters both output rows of a pair with +1:
+    // out(2T) = M0 + M1 + M2, out(2T+1) = M1 - M2 - M3) -- the zeros written by SIX matrix instructions with zero operands and C = 0
+    // instead of 96 v_accvgpr_write (one issue slot each, beside the epilogue's vector work), the bias by 32 moves instead of 64
+    // additions in the epilogue.  The wave's bias lies in LDS (bias_w, written by its lanes 0..31 just before: same wave, in order).
+    auto init_acc = [&]() __attribute__((always_inline)) {
+        f32x16 bvec;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b4 = *(const f32x4*)(bias_w + 8 * q + 4 * half);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bvec[4 * q + u] = b4[u];
+        }
+        // zq: a register quad of zeros written once at kernel start (opaque to the compiler: it cannot re-materialise it right in front
+        // of an instruction whose operand hazards it does not know); s_nop: wait states of a just-written operand, whatever wrote it
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+            for (int p = 0; p < 4; ++p) {
+                if (p == 1) acc[tl][p] = bvec;           // (C and D of an MFMA share a register class: the bias vector goes in by plain moves)
+#ifdef WINO_NOMFMAINIT
+                else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[tl][p][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) acc[tl][p][r] = 0.f;
+                }
+#else
+                else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[tl][p]) : "v"(zq));
+#endif
+            }
     };
     // After a tile's last chunk: inverse transform + bias in the C/D layout, then four passes of 8 couts x 4 rows x 32 pixels through
     // the landing area (free between the last read-back and the next chunk's parks): lane item it of a pass = cout half + 2 it, row
@@ -432,7 +455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto finish_tile = [&](const TileP& t) __attribute__((always_inline)) {
         const int ty = t.ty, tx = t.tx;
         const int cb = t.cbg + ct * 32, cl = t.clg - ct * 32;
-        if (cl <= 0 || (WINO_ABL & 256)) { zero_acc(); return; }        // the upper cout tile of a partial group has nothing to store
+        if (cl <= 0 || (WINO_ABL & 256)) return;        // the upper cout tile of a partial group has nothing to store (the caller re-initialises the accumulators)
 #ifdef MOTIF_TRACE
         long long es[8];
         int esn = 0;
@@ -450,6 +473,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int oy = ty * TH + 4 * tp + (l5 >> 3), ox = tx * 32 + (l5 & 7) * 4;
         const bool okl = oy < a.Ho && ox < a.Wo;
         const unsigned lb = (unsigned)hf * HWo + (unsigned)(oy * a.Wo + ox);
+#ifdef WINO_NOFULL
+        const bool full = false;
+#else
+        const bool full = cl >= 32 && ty * TH + 4 * tp + 4 <= a.Ho && tx * 32 + 32 <= a.Wo;     // uniform: every lane stores every item
+#endif
         auto okv = [&](int pass, int it) __attribute__((always_inline)) { return okl && 8 * pass + 2 * it + hf < cl; };
         auto offv = [&](int pass, int it) __attribute__((always_inline)) { return lb + (unsigned)(8 * pass + 2 * it) * HWo; };
         // all 16 residual quads are requested before the inverse transform (first touches of another XCD's output: ~2 k cycles; the
@@ -457,28 +485,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         f32x4 rv[4][4];
         auto load_res = [&](int pass) __attribute__((always_inline)) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) rv[pass][it] = *(const f32x4*)(rb + (okv(pass, it) ? offv(pass, it) : 0u));   // masked lanes read element 0
+            for (int it = 0; it < 4; ++it) rv[pass][it] = *(const f32x4*)(rb + ((full || okv(pass, it)) ? offv(pass, it) : 0u));   // masked lanes read element 0
         };
         if (rm) { load_res(0); load_res(1); load_res(2); load_res(3); }
         EPSTAMP();
         float* scr = (float*)land;                       // two halves of [8 couts][4 rows x 32 px]
         const int ew = hf * 512 + l5, er = hf * 128 + (l5 >> 3) * 32 + (l5 & 7) * 4;
-        // pass p = couts 8p .. 8p+7 = registers 4p .. 4p+3 of every accumulator: inverse transform + bias of those 16 values, transpose
-        // through the scratch half p & 1, and a quarter of the accumulators zeroed for the next tile -- written per pass so that the
-        // compiler overlaps pass p+1's register work with pass p's LDS round trip
+        // pass p = couts 8p .. 8p+7 = registers 4p .. 4p+3 of every accumulator: inverse transform of those 16 values, transpose through
+        // the scratch half p & 1 -- written per pass so that the compiler overlaps pass p+1's register work with pass p's LDS round trip
         auto write_pass = [&](int pass) __attribute__((always_inline)) {
-            const f32x4 b4 = *(const f32x4*)(bias_w + 8 * pass + 4 * hf);
 #pragma unroll
             for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
                 for (int r3 = 0; r3 < 4; ++r3) {
                     const int r = 4 * pass + r3;
-                    const float o0 = ((acc[tl][0][r] + acc[tl][1][r]) + acc[tl][2][r]) + b4[r3];
-                    const float o1 = ((acc[tl][1][r] - acc[tl][2][r]) - acc[tl][3][r]) + b4[r3];
+                    const float o0 = (acc[tl][0][r] + acc[tl][1][r]) + acc[tl][2][r];        // the bias is inside M1 (init_acc)
+                    const float o1 = (acc[tl][1][r] - acc[tl][2][r]) - acc[tl][3][r];
                     scr[(pass & 1) * 1024 + ew + r3 * 128 + (2 * tl) * 32] = o0;
                     scr[(pass & 1) * 1024 + ew + r3 * 128 + (2 * tl + 1) * 32] = o1;
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) acc[tl][p][r] = 0.f;
                 }
         };
         // AC / RM >= 0: activation / residual mode known at compile time (the common layers: one straight-line body, no per-item
@@ -517,12 +541,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     } else if (rmv == 4) v[it] *= rv[pass][it];
                 }
 #pragma unroll
-                for (int it = 0; it < 4; ++it)
-                    if (okv(pass, it)) {
-                        const unsigned bo = offv(pass, it) * 4u;
-                        const f32x4 val = v[it];
-                        asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(bo), "v"(val), "s"(obq) : "memory");
-                    }
+                for (int it = 0; it < 4; ++it) {
+                    const unsigned bo = offv(pass, it) * 4u;
+                    const f32x4 val = v[it];
+                    // s_nop: the wait state between a store of more than 8 bytes and the next vector write of its data registers -- hipcc
+                    // inserts it for its own stores, not around inline assembly
+                    if (full) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(bo), "v"(val), "s"(obq) : "memory");
+                    else if (okv(pass, it)) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(bo), "v"(val), "s"(obq) : "memory");
+                }
                 EPSTAMP();
             }
         };
@@ -549,7 +575,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- prologue: step 0 staged in full, the row pieces of step 1 requested (nothing to hide them under) --------------------
     int t = bq;
     WNTRACE(0);
-    zero_acc();
     if (wave == 0) {
         fill_table(0);
         if ((long)bq + 64L * G < ntiles) fill_table(64);
@@ -568,6 +593,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < NLD; ++i) st_load(i, 0);
     static_for<WSched::S>([&](auto ic) __attribute__((always_inline)) { piece(std::integral_constant<int, kWSched.ext[decltype(ic)::value]>{}, stg0); });
     if (lane < 32) bias_w[lane] = bias_v;
+    init_acc();
 #pragma unroll
     for (int i = 0; i < NLD; ++i) st_load(i, 16);        // nch >= 2: step 1 is chunk 1 of this tile
     __syncthreads();
@@ -591,7 +617,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (slot < 29) WNTRACE(slot);                // trace: body end | epilogue end | barrier passed, for the first 9 chunks
             if (last) {
                 finish_tile(load_tile(ti));
-                if (lane < 32) bias_w[lane] = bias_v;    // the next tile's bias (this tile's has just been read)
+                if (lane < 32) bias_w[lane] = bias_v;    // the next tile's bias,
+                init_acc();                              // into its accumulators
             }
             if (slot < 29) WNTRACE(slot + 1);
             __syncthreads();

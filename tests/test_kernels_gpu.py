@@ -303,6 +303,35 @@ def test_conv_split2_persistent_tiles(shape, tile, keep_mma):
     close(out, old, tol, tol, "split2 / wino vs two-block kernel")
 
 
+@pytest.mark.parametrize("case", [(6, 64, 64, 180, 320, "lrelu", 0), (3, 64, 64, 64, 96, "relu", 2), (3, 128, 64, 64, 96, "relu", 0), (3, 64, 216, 64, 96, "none", 0),
+                                  (5, 64, 64, 16, 24, "none", 1)], ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_wino_same_bits_whatever_the_batch_and_the_run(case, keep_mma):
+    """A frame's output bits depend neither on the batch it sits in (which workgroup picks a tile up, what that workgroup did before)
+    nor on the run.  Found a timing-dependent fault the tolerance tests let through: gfx950 wants TWO wait states between a store of
+    more than 8 bytes and the next vector write of its data registers, and hipcc adds none around inline-assembly stores."""
+    from motif_amd import ops
+    from motif_amd.models.modules.layers import Conv2d
+    n, cin, cout, H, W, actn, rm = case
+    act = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU}[actn]
+    m = Conv2d(cin, cout, 3, 1, 1)
+    with torch.no_grad():
+        m.weight.copy_(rnd(*m.weight.shape, seed=1, scale=1.0 / math.sqrt(cin * 9)))
+        m.bias.copy_(rnd(cout, seed=2, scale=0.1))
+    m = m.to(dev())
+    x, res = rnd(n, cin, H, W, seed=3).to(dev()), rnd(n, cout, H, W, seed=4).to(dev())
+    ops.set_conv_mma(ops.MMA_BF16X3)
+    try:
+        ops.set_option("conv_engine", 5)
+        kw = lambda k: dict(act=act) if rm == 0 else dict(act=act, res=res[:k].contiguous(), res_mode=rm)
+        full = m(x, **kw(n)).clone()
+        for rep in range(8):
+            assert torch.equal(m(x, **kw(n)), full), "run %d differs from run 0" % rep
+        for k in range(1, n):
+            assert torch.equal(m(x[:k].contiguous(), **kw(k)), full[:k]), "the first %d frames alone differ from the same frames inside the batch of %d" % (k, n)
+    finally:
+        ops.set_option("conv_engine", 0)
+
+
 # ------------------------------------------------------------------------------------------- DCNv2
 def test_dcn_matches_kernel_text_restatement():
     from oracle import native
