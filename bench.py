@@ -10,16 +10,19 @@ Launch: `python bench.py --gpus N` starts N ranks itself (a `python -m torch.dis
 this process touches the GPU; nothing is re-exec'ed) when it is not already running under a launcher; under
 `torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.  Rank 0 prints the one JSON line.
 
-Arithmetic (--mma): "bf16x3" (default) runs the dense contractions (3x3 convolutions, fused DCN, the three MLPs) on the
+Arithmetic (--mma): "bf16x3" runs the dense contractions (3x3 convolutions, fused DCN, the three MLPs) on the
 bf16 matrix cores with every fp32 operand split exactly into three bf16 parts and six products accumulated in fp32 --
 fp32-equivalent (error below an fp32 FMA chain, tests/test_kernels_gpu.py::test_conv_split_engine_is_fp32_equivalent);
-"fp32" runs them on v_mfma_f32_32x32x2_f32.  The line carries the fp32-MFMA number of the same run as `fp32_mfma`.
+"f16x2" (default, round 4) is the same except that the 3x3 stride-1 convolutions served by conv_wino.hip split every operand into
+TWO fp16 parts (hi = rne(x), lo = rne(x - hi): 22+ bits) and take three products -- half the matrix instructions, error against
+fp64 at or below the three-part form's (same test); "fp32" runs everything on v_mfma_f32_32x32x2_f32.  The line carries the
+bf16x3 and fp32-MFMA numbers of the same run as `bf16x3` and `fp32_mfma`.
 
 Extra objects on the JSON line:
   roofline     dominant kernel = the 3x3 convolution engine (conv_split_kernel<3,4>, or conv_igemm_kernel<2> with
                --mma fp32): algorithmic FLOP of its launches / their measured duration (events on the launch
-               stream, one instrumented clip after the timed region).  Peak: bf16 dense MFMA 2500 TFLOP/s / 6
-               products per fp32 MAC = 416.7 TFLOP/s for bf16x3, 157.3 TFLOP/s fp32 MFMA for fp32.
+               stream, one instrumented clip after the timed region).  Peak: bf16 / fp16 dense MFMA 2500 TFLOP/s / products
+               per fp32 MAC = 833.3 TFLOP/s for f16x2 (3 products), 416.7 for bf16x3 (6), 157.3 TFLOP/s fp32 MFMA for fp32.
   stages       the same measurement for every stage of the path (event pairs around each C-ABI call of the
                instrumented clip): ms per clip, algorithmic work, achieved rate, the bound and the fraction of it.
   parity       PSNR / L-inf of the HIP path against the CPU oracle on the cpu_baseline clip (both engines).
@@ -53,7 +56,7 @@ def parse():
     ap.add_argument("--lr", type=int, nargs=2, default=[180, 320], help="LR height width")
     ap.add_argument("--scale", type=int, default=4)
     ap.add_argument("--times", type=int, default=7)
-    ap.add_argument("--mma", choices=["bf16x3", "fp32"], default="bf16x3", help="arithmetic of the dense contractions")
+    ap.add_argument("--mma", choices=["f16x2", "bf16x3", "fp32"], default="f16x2", help="arithmetic of the dense contractions")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the secondary fp32-MFMA measurement")
     ap.add_argument("--streams", type=int, default=2,
                     help="clips in flight per GPU, each on its own HIP stream and model instance (default 2: the next clip's launches fill the "
@@ -213,6 +216,7 @@ def instrumented_clip(model, sample):
         net.overlap_raft = overlap
         model.use_graph = use_graph
     mfma_peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
+    conv3_peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if ops.get_conv_mma() == ops.MMA_F16X2 else mfma_peak      # two fp16 parts: 3 products per fp32 MAC
     bounds = {"conv3x3": "mfma", "conv_other": "mfma", "dcn": "mfma", "imnet": "mfma", "flow_imnet": "mfma", "synth_net": "mfma", "splat": "hbm"}
     stages = {}
     for stage, e0, e1, work, _ in rec:
@@ -225,9 +229,11 @@ def instrumented_clip(model, sample):
         row = {"ms_per_clip": round(s["ms"], 3), "calls": s["launches"]}
         b = bounds.get(stage)
         if b == "mfma" and s["ms"] > 0:
-            peak = FP32_MFMA_PEAK_TFLOPS if stage == "conv_other" else mfma_peak          # non-3x3 / narrow layers run on the fp32 MFMA
+            peak = FP32_MFMA_PEAK_TFLOPS if stage == "conv_other" else conv3_peak if stage == "conv3x3" else mfma_peak      # non-3x3 / narrow layers run on the fp32 MFMA
             ach = s["work"] / (s["ms"] * 1e-3) / 1e12
             row.update(bound="mfma", tflop=round(s["work"] / 1e12, 4), achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4))
+            if stage == "conv3x3" and conv3_peak != mfma_peak:
+                row["frac_of_6_product_bound"] = round(ach / mfma_peak, 4)       # the basis of rounds 2-4's bf16x3 figures (416.7 TFLOP/s)
         elif b == "hbm" and s["ms"] > 0:
             ach = s["work"] / (s["ms"] * 1e-3) / 1e9
             row.update(bound="hbm", gbyte=round(s["work"] / 1e9, 3), achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
@@ -326,7 +332,8 @@ def cpu_baseline_and_parity(times, model, mma, lr=(180, 320), scale=4):
                            "clip's values further than 1e-3 from the oracle (isolated pixels where a splat target coordinate floors to the other "
                            "side of an integer under 1e-7 of flow noise)"}
     try:
-        for mode in ("bf16x3", "fp32"):
+        modes = ("f16x2", "bf16x3", "fp32") if mma == "f16x2" else ("bf16x3", "fp32")
+        for mode in modes:
             ops.set_mma(mode)
             model.feed_data(data)
             model.test()
@@ -344,7 +351,7 @@ def cpu_baseline_and_parity(times, model, mma, lr=(180, 320), scale=4):
             parity[mode] = row
     finally:
         ops.set_mma(mma)
-    parity["pass"] = bool(all(parity[m]["pass"] for m in ("bf16x3", "fp32")))
+    parity["pass"] = bool(all(parity[m]["pass"] for m in modes))
     return base, parity
 
 
@@ -560,6 +567,9 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"arithmetic": ("fp32-equivalent on the bf16 matrix cores: every fp32 operand = 3 exact bf16 parts, 6 products, fp32 "
                                   "accumulate (3x3 convolutions, fused DCN and the three MLPs); everything else fp32" if a.mma == "bf16x3"
+                                  else "fp32-equivalent on the 16-bit matrix cores: 3x3 stride-1 convolutions with every fp32 operand = 2 fp16 parts "
+                                  "(22+ bits), 3 products, fp32 accumulate (conv_wino.hip); fused DCN, the three MLPs and the remaining split "
+                                  "convolutions with 3 exact bf16 parts, 6 products; everything else fp32" if a.mma == "f16x2"
                                   else "fp32 MFMA (v_mfma_f32_32x32x2_f32) and fp32 VALU"),
                    "workload": ("c2" if world == 1 else "c4 (independent c2 clips sharded over %d GPUs as the reference's DistIterSampler strides them: "
                                 "%d clips per GPU in the timed region, %d in total; 8 GPUs x 8 clips = BASELINE configs[3])" % (world, a.steps * a.batch, world * a.steps * a.batch))
@@ -597,13 +607,19 @@ def main():
         nstreams[0] = len(models)
         line["streams1"] = {"value": world * a.steps * px / dt1, "unit": "px/s", "ms_per_step": 1000.0 * dt1 / a.steps,
                             "note": "the same job with ONE clip in flight per GPU (--streams 1); the headline keeps %d in flight" % a.streams}
-    if a.mma == "bf16x3" and not a.no_fp32_leg:
+    if a.mma != "fp32" and not a.no_fp32_leg:
         # the same job on the fp32 MFMA (all ranks, same barriers), reported next to the headline value
         from motif_amd import ops
+        if a.mma == "f16x2":
+            ops.set_mma("bf16x3")
+            setup()
+            dt6 = timed(1, a.steps)
+            line["bf16x3"] = {"value": world * a.steps * px / dt6, "unit": "px/s", "ms_per_step": 1000.0 * dt6 / a.steps,
+                              "note": "same job with --mma bf16x3 (three bf16 parts, six products, in every split kernel: the arithmetic of rounds 2-3)"}
         ops.set_mma("fp32")
         setup()                               # re-pack for the fp32 engines outside the measurement
         dt32 = timed(1, a.steps)
-        ops.set_mma("bf16x3")
+        ops.set_mma(a.mma)
         setup()                               # and back, before the instrumented clip
         line["fp32_mfma"] = {"value": world * a.steps * px / dt32, "unit": "px/s", "ms_per_step": 1000.0 * dt32 / a.steps,
                              "note": "same job with --mma fp32 (v_mfma_f32_32x32x2_f32 contractions)"}
@@ -611,7 +627,7 @@ def main():
         if not a.no_roofline:
             r = instrumented_clip(model, clips[0])
             ach = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
-            split = a.mma == "bf16x3"
+            split = a.mma != "fp32"
             traffic, traffic_src = None, None
             for name in ("r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_split_traffic.json") if split else ("r01_conv_traffic.json",):
                 tj = os.path.join(ROOT, "profiles", name)
@@ -623,7 +639,7 @@ def main():
                         traffic["algorithmic_bytes_per_launch"] = tdoc.get("algorithmic_bytes_per_launch")
                     traffic_src = "profiles/" + name
                     break
-            peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
+            peak = BF16_MFMA_PEAK_TFLOPS / (3.0 if a.mma == "f16x2" else 6.0) if split else FP32_MFMA_PEAK_TFLOPS
             clip_flop = sum(v.get("tflop", 0.0) for k, v in r["table"].items() if isinstance(v, dict)) * 1e12
             line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                 "frac": ach / peak, "traffic": None, "traffic_from_profile": traffic, "traffic_source": traffic_src,
@@ -631,8 +647,11 @@ def main():
                                             "frac": clip_flop / (dt / a.steps) / 1e12 / peak,
                                             "note": "dense FLOP of one clip (all conv / DCN / MLP stages as executed, t-independent part once) over "
                                                     "the timed wall time per clip, against the same peak"},
-                                "peak_basis": ("bf16 dense MFMA 2500 TFLOP/s / 6 bf16 products per fp32 MAC" if split
+                                "peak_basis": ("fp16 dense MFMA 2500 TFLOP/s / 3 fp16 products per fp32 MAC (the six-product bf16x3 form of rounds 2-4 "
+                                               "was priced against 2500 / 6 = 416.7: `frac_of_6_product_bound`)" if a.mma == "f16x2"
+                                               else "bf16 dense MFMA 2500 TFLOP/s / 6 bf16 products per fp32 MAC" if split
                                                else "fp32 MFMA 157.3 TFLOP/s"),
+                                "frac_of_6_product_bound": (ach / (BF16_MFMA_PEAK_TFLOPS / 6.0)) if a.mma == "f16x2" else None,
                                 "kernel": ("3x3 engine: conv_wino_kernel (Winograd F(2,3) along the rows, one wave per SIMD: 2/3 of the direct form's MFMAs for the "
                                            "algorithmic FLOP counted here) wherever it applies, the direct conv_split2 / conv_split kernels for the layers with a "
                                            "transcendental epilogue or a single 16-channel chunk") if split else "conv_igemm_kernel<2>",

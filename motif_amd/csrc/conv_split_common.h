@@ -41,7 +41,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[NP]) {
 }
 }  // namespace
 
-static inline int split_parts(int mma) { return mma == 6 ? 3 : mma == 3 ? 2 : mma == 1 ? 1 : 0; }
+// mma = 7 (two fp16 parts, conv_wino.hip only): every other kernel runs such a layer in the three-part bf16 form
+static inline int split_parts(int mma) { return (mma == 6 || mma == 7) ? 3 : mma == 3 ? 2 : mma == 1 ? 1 : 0; }
 
 // round-3 kernel (conv_split2.hip): same packed weights, same ConvArgs as conv_split.hip
 bool motif_conv_split2_eligible(const MotifConvDesc* d, const ConvArgs& a, int P);

@@ -39,83 +39,100 @@
 #ifdef MOTIF_TRACE
 __device__ long long g_wn_trace[1024 * 4 * 32];
 #define WNTRACE(slot) do { if (lane == 0 && blockIdx.x < 1024) g_wn_trace[(blockIdx.x * 4 + wave) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define WNTRACE_RT(slot) do { if (lane == 0 && blockIdx.x < 1024) g_wn_trace[(blockIdx.x * 4 + wave) * 32 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)   // the constant 100 MHz counter: shader clock = cycles / time
 extern "C" int motif_debug_wino_trace(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wn_trace), sizeof(long long) * n); }
 // per-super-step stamps of the first 8 chunks of a workgroup: [block][wave][chunk][7]
 __device__ long long g_wn_trace2[256 * 4 * 8 * 8];
 extern "C" int motif_debug_wino_trace2(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wn_trace2), sizeof(long long) * n); }
 #else
 #define WNTRACE(slot)
+#define WNTRACE_RT(slot)
 #endif
 
 #ifndef WINO_ABL
 #define WINO_ABL 0        // ablation builds (tools/wino_ablate.sh): bit 0 no loads, 1 no parks, 2 no read-back, 3 no transform/split,
-#endif                    // 4 no staging stores, 5 no halo item, 6 no B fragments, 7 no weight fragments, 8 no epilogue pieces
+#endif                    // 4 no staging stores, 5 no halo item, 6 no B fragments, 7 no weight fragments, 8 no epilogue pieces,
+                          // 9 every second product only (the MFMA count of a 3-product split), 10 no MFMAs at all
 
 namespace {
 // Products ordered by ACTIVATION part, smallest part first (w = weight part, x = activation part).
-struct WOrder {
+// NP = 3: three bf16 parts per operand, the six products whose dropped remainder is <= 2^-25 relative (conv_split.hip).
+// NP = 2: two fp16 parts per operand (hi = rne(x), lo = rne(x - hi): 22+ significant bits, |x - hi - lo| <= 2^-23 |x| while the
+//         parts stay normal numbers), three products -- half the matrix instructions.  See the header of the file for the range.
+template <int NP> struct WOrder;
+template <> struct WOrder<3> {
     static constexpr int n = 6;
     static constexpr int w[6] = {0, 1, 0, 2, 1, 0};
     static constexpr int x[6] = {2, 1, 1, 0, 0, 0};
 };
+template <> struct WOrder<2> {
+    static constexpr int n = 3;
+    static constexpr int w[3] = {0, 1, 0};
+    static constexpr int x[3] = {1, 0, 0};
+};
 
-enum { WP_PARK = 2, WP_READ = 3, WP_X = 4, WP_W = 5, WP_HREAD = 6, WP_HX = 7, WP_HW = 8 };
+enum { WP_PARK = 2, WP_READ = 3, WP_X = 4, WP_W = 5, WP_HREAD = 6, WP_HX = 7, WP_HW = 8, WP_READ2 = 9 };
 
-// Static schedule of a chunk: 6 super-steps (position pair, kx) of M = 24 MFMAs = product x (position of the pair, row pair), four
-// accumulators in rotation.  Slot s = ss * M + m follows MFMA m of super-step ss and holds at most one request of each kind and one
-// staging piece.  Every operand register has ONE copy per prefetch depth and is re-requested right after the last product that
-// reads it:
+// Static schedule of a chunk: 6 super-steps (position pair, kx) of M = 4 * products MFMAs = product x (position of the pair, row
+// pair), four accumulators in rotation.  Slot s = ss * M + m follows MFMA m of super-step ss and holds at most one request of each
+// kind and one staging piece.  Every operand register has ONE copy per prefetch depth and is re-requested right after the last
+// product that reads it (NP = 3 figures; NP = 2 follows the same rules on its 12-slot super-steps):
 //   rb[s]:  B fragment (part * 4 + j) of the NEXT super-step (part 2 after MFMAs 0..3, part 1 after 8..11, part 0 after 20..23);
-//   ra[s]:  weight fragment (position of the pair * 3 + part) of the super-step THREE ahead, into the set in use (three sets): part 2
+//   ra[s]:  weight fragment (position of the pair * NP + part) of the super-step THREE ahead, into the set in use (three sets): part 2
 //           after MFMAs 13 / 15, part 1 after 17 / 19, part 0 after 21 / 23 -- ~2.2 super-steps (~2 k cycles) before its first use.
 //           vmcnt retires in order, so a weight fragment can only be consumed once every OLDER load has returned, raw row pieces
 //           included (first touches of another XCD's output: ~2 k cycles); hence
-//   rl[s]:  raw row piece i of the step after next is requested as soon as its landing registers are free (two slots after its
+//   rl[s]:  raw row piece i of the step after next is requested as soon as its landing registers are free (right after its
 //           park): it then has >= four super-steps before the next chunk parks it, and the weight fragments requested behind it are
 //           not needed for two.  Parks and requests are spread over super-steps 0 and 1: 14 one-KB requests in one super-step are
 //           900 cycles of the CU's L1 path, 40 ds_write_b128 of four waves 500 of the LDS store path.
-//   ext[s]: staging piece of the NEXT step: parks (every fourth slot of super-steps 0 and 1), read-back, halo reads, per position 13
-//           transform / split stages of <= 4 INDEPENDENT instructions + 3 stores, the halo item last.
+//   ext[s]: staging piece of the NEXT step: parks (NP = 3: every fourth slot of super-steps 0 and 1; NP = 2: every second), read-back,
+//           halo reads, per position XS transform / split stages of <= 4 INDEPENDENT instructions + NP stores, the halo item last.
+template <int NP>
 struct WSched {
-    static constexpr int SS = 6, M = 24, S = SS * M, NLD = 10;
+    static constexpr int SS = 6, M = 4 * WOrder<NP>::n, S = SS * M, NLD = 10;
+    static constexpr int XS = NP == 3 ? 13 : 6;          // transform / split stages per position (st_x)
+    static constexpr int HXS = NP == 3 ? 4 : 3;          // ... of the halo item (st_hx)
     int rb[S], ra[S], rl[S], ext[S], used, clash;
     constexpr WSched() : rb(), ra(), rl(), ext(), used(0), clash(0) {
+        using O = WOrder<NP>;
         for (int s = 0; s < S; ++s) { rb[s] = -1; ra[s] = -1; rl[s] = -1; ext[s] = 0; }
-        constexpr int aslot[6] = {13, 15, 17, 19, 21, 23};            // (pi 0, part 2), (pi 1, part 2), (0, 1), (1, 1), (0, 0), (1, 0)
+        int lastx[NP] = {}, lastw[NP] = {};                                   // last product reading activation / weight part p
+        for (int k = 0; k < O::n; ++k) { lastx[O::x[k]] = k; lastw[O::w[k]] = k; }
         for (int ss = 0; ss < SS; ++ss) {
-            if (ss + 1 < SS) {
-                for (int j = 0; j < 4; ++j) {
-                    rb[ss * M + j] = 2 * 4 + j;
-                    rb[ss * M + 8 + j] = 1 * 4 + j;
-                    rb[ss * M + 20 + j] = 0 * 4 + j;
-                }
-            }
-            for (int i = 0; i < 6; ++i) ra[ss * M + aslot[i]] = (i & 1) * 3 + (2 - (i >> 1));
+            if (ss + 1 < SS)
+                for (int p = 0; p < NP; ++p)
+                    for (int j = 0; j < 4; ++j) rb[ss * M + lastx[p] * 4 + j] = p * 4 + j;
+            for (int p = 0; p < NP; ++p)
+                for (int pi = 0; pi < 2; ++pi) ra[ss * M + lastw[p] * 4 + 2 * pi + 1] = pi * NP + p;
         }
         int f = 0;
-        int pslot[NLD] = {};
-        for (int i = 0; i < NLD; ++i) { ext[f] = (WP_PARK << 8) | i; pslot[i] = f; f += 4; }
-#ifndef WINO_LATE_LOADS
-        for (int i = 0; i < NLD; ++i) {
-            const int ls = pslot[i] + 2;                                         // a row piece is requested right after its park
-            if (rl[ls] >= 0 || ra[ls] >= 0) clash = 1;
-            rl[ls] = i;
-        }
-#else
-        {   // experiment: requests spread over super-steps 2..5 (the L1 path of super-steps 0 / 1 carries the parks' neighbours only)
-            constexpr int lslot[NLD] = {2 * M + 6, 2 * M + 12, 3 * M + 2, 3 * M + 6, 3 * M + 12, 4 * M + 2, 4 * M + 6, 4 * M + 12, 5 * M + 2, 5 * M + 6};
+        if (NP == 3) {
+            int pslot[NLD] = {};
+            for (int i = 0; i < NLD; ++i) { ext[f] = (WP_PARK << 8) | i; pslot[i] = f; f += 4; }
             for (int i = 0; i < NLD; ++i) {
-                if (rl[lslot[i]] >= 0 || ra[lslot[i]] >= 0) clash = 1;
-                rl[lslot[i]] = i;
+                const int ls = pslot[i] + 2;                                     // a row piece is requested right after its park
+                if (rl[ls] >= 0 || ra[ls] >= 0) clash = 1;
+                rl[ls] = i;
             }
+            for (int r = 0; r < 16; ++r) ext[f++] = (WP_READ << 8) | r;
+        } else {
+            // parks in the odd slots 1 .. 19, requests in the even slot behind (the weight requests sit in odd slots); the read-back of
+            // row r (row piece quads 160 r .. 160 r + 159: pieces 0-2 | 2-4 | 5-7 | 7-9) in the even slots behind its last park
+            for (int i = 0; i < NLD; ++i) {
+                ext[2 * i + 1] = (WP_PARK << 8) | i;
+                if (rl[2 * i + 2] >= 0 || ra[2 * i + 2] >= 0) clash = 1;
+                rl[2 * i + 2] = i;
+            }
+            constexpr int rslot[8] = {6, 8, 10, 12, 16, 18, 20, 21};
+            for (int r = 0; r < 8; ++r) { if (ext[rslot[r]]) clash = 1; ext[rslot[r]] = (WP_READ2 << 8) | r; }
+            f = 22;
         }
-#endif
-        for (int r = 0; r < 16; ++r) ext[f++] = (WP_READ << 8) | r;
         for (int r = 0; r < 2; ++r) ext[f++] = (WP_HREAD << 8) | r;
         for (int pos = 0; pos < 4; ++pos)
-            for (int i = 0; i < 16; ++i) ext[f++] = (i < 13 ? (WP_X << 8) | (pos * 16 + i) : (WP_W << 8) | (pos * 3 + i - 13));
-        for (int h = 0; h < 4; ++h) ext[f++] = (WP_HX << 8) | h;
-        for (int p = 0; p < 3; ++p) ext[f++] = (WP_HW << 8) | p;
+            for (int i = 0; i < XS + NP; ++i) ext[f++] = (i < XS ? (WP_X << 8) | (pos * 16 + i) : (WP_W << 8) | (pos * NP + i - XS));
+        for (int h = 0; h < HXS; ++h) ext[f++] = (WP_HX << 8) | h;
+        for (int p = 0; p < NP; ++p) ext[f++] = (WP_HW << 8) | p;
         used = f;
     }
 };
@@ -125,8 +142,20 @@ struct WSched {
 __device__ __forceinline__ float fadd1(float a, float b) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float fsub1(float a, float b) { float r; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-constexpr WSched kWSched{};
-static_assert(kWSched.used <= WSched::S && kWSched.clash == 0, "pieces do not fit the slots of a chunk");
+template <int NP> constexpr WSched<NP> kWSchedOf{};
+static_assert(kWSchedOf<3>.used <= WSched<3>::S && kWSchedOf<3>.clash == 0, "pieces do not fit the slots of a chunk");
+static_assert(kWSchedOf<2>.used <= WSched<2>::S && kWSchedOf<2>.clash == 0, "pieces do not fit the slots of a chunk (two-part form)");
+
+// fp16 pair helpers of the two-part form: round-to-nearest pack (v_cvt_pk_f16_f32), and x - (float)half of a packed pair as ONE
+// mixed-precision FMA (v_fma_mix_f32: half * -1.0 + x; the product by -1 is exact)
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pk_f16(float a, float b) { const f16x2v h = {(_Float16)a, (_Float16)b}; return __builtin_bit_cast(unsigned, h); }
+__device__ __forceinline__ float sub_f16_lo(float x, unsigned pk) { float r; asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x)); return r; }
+__device__ __forceinline__ float sub_f16_hi(float x, unsigned pk) { float r; asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x)); return r; }
+// the weights of the two-part form are packed times 2^8 (a weight of everyday magnitude 1e-3 .. 1 then has BOTH its parts in fp16's
+// normal range; 2^8 |U| must stay below 65504, U = the transformed kernel rows of the header), the epilogue multiplies by 2^-8 (exact)
+constexpr float kWinoF16Scale = 256.f;
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) -- every slot of the schedule is its own
 // instantiation (the loop unroller's size estimate, taken before the dispatch on the slot's piece is folded, refuses 144 slots)
@@ -138,13 +167,15 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make
 
 // MULTI: more than one problem in the launch (the per-problem argument selects are ~100 scalar instructions per tile: a lone wave
 // hides none of them).
-template <bool MULTI>
+template <int NP, bool MULTI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino_kernel(ConvArgs a, int ntiles, int tiles_y) {
-    constexpr int NP = 3, WAVES = 4, TH = 8, PW = 34, OCT = 16 * PW;   // 16 (pair, position) planes of 34 pixels per octet
+    using WS = WSched<NP>;
+    using WO = WOrder<NP>;
+    constexpr int WAVES = 4, TH = 8, PW = 34, OCT = 16 * PW;   // 16 (pair, position) planes of 34 pixels per octet
     constexpr int SLOTS = 2 * OCT + 4;                   // per part: [2 octets][16 planes][34] 16-byte slots (+ pad)
     constexpr int STG = NP * SLOTS;                      // one bf16 staging buffer (u32x4)
-    constexpr int NLD = WSched::NLD, LW = NLD * 64;      // a wave's landing area: [4 rows][2 octets][8 channels][40 px] floats
-    constexpr int M = WSched::M, SS = WSched::SS;
+    constexpr int NLD = WS::NLD, LW = NLD * 64;      // a wave's landing area: [4 rows][2 octets][8 channels][40 px] floats
+    constexpr int M = WS::M, SS = WS::SS;
     extern __shared__ __attribute__((aligned(16))) u32x4 lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), ct = wave & 1, tp = wave >> 1;
@@ -254,7 +285,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wb, wvoff, (ks * NP + p) * (2 * 64 * 16), 0));
     };
     auto bias_of = [&](const TileP& t) __attribute__((always_inline)) {
-        return (t.bp && lane < 32 && ct * 32 + lane < t.clg) ? t.bp[ct * 32 + lane] : 0.f;
+        const float b = (t.bp && lane < 32 && ct * 32 + lane < t.clg) ? t.bp[ct * 32 + lane] : 0.f;
+        return NP == 2 ? b * kWinoF16Scale : b;             // the accumulators of the two-part form carry 2^8 x the sums (exact)
     };
     auto setup_loads = [&](const TileP& t, bool valid) __attribute__((always_inline)) {
         st_g = t.g;
@@ -307,22 +339,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         };
         auto pack = [&](int p) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { xpk[q] = pk_bf16(xv[2 * q], xv[2 * q + 1]); sparts[p][q] = xpk[q]; }
+            for (int q = 0; q < 4; ++q) { xpk[q] = NP == 2 ? pk_f16(xv[2 * q], xv[2 * q + 1]) : pk_bf16(xv[2 * q], xv[2 * q + 1]); sparts[p][q] = xpk[q]; }
         };
         if (st < 2) {
             const int ra = pos == 0 ? 0 : pos == 2 ? 2 : 1, rb = pos == 0 ? 2 : pos == 2 ? 1 : pos == 1 ? 2 : 3;
 #pragma unroll
             for (int e = 4 * st; e < 4 * st + 4; ++e) xv[e] = pos == 1 ? fadd1(sv[ra][e], sv[rb][e]) : fsub1(sv[ra][e], sv[rb][e]);
         } else if (st == 2) pack(0);
-        else if (st == 3 || st == 4) expand(st - 3);
-        else if (st == 5 || st == 6) sub(st - 5);
-        else if (st == 7) pack(1);
-        else if (st == 8 || st == 9) expand(st - 8);
-        else if (st == 10 || st == 11) sub(st - 10);
-        else if (st == 12) pack(2);
+        else if constexpr (NP == 2) {
+            if (st == 3 || st == 4) {                     // remainder after the first part: one mixed-precision FMA per value
+#pragma unroll
+                for (int q = 2 * (st - 3); q < 2 * (st - 3) + 2; ++q) { xv[2 * q] = sub_f16_lo(xv[2 * q], xpk[q]); xv[2 * q + 1] = sub_f16_hi(xv[2 * q + 1], xpk[q]); }
+            } else if (st == 5) pack(1);
+        } else {
+            if (st == 3 || st == 4) expand(st - 3);
+            else if (st == 5 || st == 6) sub(st - 5);
+            else if (st == 7) pack(1);
+            else if (st == 8 || st == 9) expand(st - 8);
+            else if (st == 10 || st == 11) sub(st - 10);
+            else if (st == 12) pack(2);
+        }
     };
     auto st_w = [&](int idx, u32x4* dstbuf) __attribute__((always_inline)) {            // one part of position idx / 3 -> staging buffer
-        const int pos = idx / 3, p = idx - pos * 3;
+        const int pos = idx / NP, p = idx - pos * NP;
         dstbuf[p * SLOTS + mslot + pos * PW] = sparts[p];
     };
     float ha0 = 0.f, ha1 = 0.f, hb0 = 0.f, hb1 = 0.f, hv0 = 0.f, hv1 = 0.f, he0 = 0.f, he1 = 0.f;
@@ -332,7 +371,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         else { hb0 = landf[h_rdb]; hb1 = landf[h_rdb + 40]; }
     };
     auto st_hx = [&](int h) __attribute__((always_inline)) {
-        if (h == 0) {
+        if constexpr (NP == 2) {
+            if (h == 0) {
+                hv0 = __builtin_fmaf(h_sgn, hb0, ha0); hv1 = __builtin_fmaf(h_sgn, hb1, ha1);   // a +- b: the product by +-1 is exact
+                hpk = pk_f16(hv0, hv1);
+                hparts[0] = hpk;
+            } else if (h == 1) {
+                hv0 = sub_f16_lo(hv0, hpk); hv1 = sub_f16_hi(hv1, hpk);
+            } else hparts[1] = pk_f16(hv0, hv1);
+        } else if (h == 0) {
             hv0 = __builtin_fmaf(h_sgn, hb0, ha0); hv1 = __builtin_fmaf(h_sgn, hb1, ha1);   // a +- b: the product by +-1 is exact
             hpk = pk_bf16(hv0, hv1);
             hparts[0] = hpk;
@@ -343,7 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             hparts[1] = hpk;
             he0 = bf_lo(hpk); he1 = bf_hi(hpk);
         } else {
-            hparts[2] = pk_bf16(fsub1(hv0, he0), fsub1(hv1, he1));
+            hparts[NP - 1] = pk_bf16(fsub1(hv0, he0), fsub1(hv1, he1));
         }
     };
     auto st_hw = [&](int p, u32x4* dstbuf) __attribute__((always_inline)) { ((unsigned*)(dstbuf + p * SLOTS))[h_wr] = hparts[p]; };
@@ -351,6 +398,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int e = decltype(ec)::value, kind = e >> 8, idx = e & 255;
         if constexpr (kind == WP_PARK) { if constexpr (!(WINO_ABL & 2)) st_park(idx); }
         else if constexpr (kind == WP_READ) { if constexpr (!(WINO_ABL & 4)) st_read(idx); }
+        else if constexpr (kind == WP_READ2) { if constexpr (!(WINO_ABL & 4)) { st_read(2 * idx); st_read(2 * idx + 1); } }
         else if constexpr (kind == WP_X) { if constexpr (!(WINO_ABL & 8)) st_x(idx); }
         else if constexpr (kind == WP_W) { if constexpr (!(WINO_ABL & 16)) st_w(idx, dstbuf); }
         else if constexpr (kind == WP_HREAD) { if constexpr (!(WINO_ABL & 32)) st_hread(idx); }
@@ -398,16 +446,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef MOTIF_TRACE_SS
             if constexpr (m == 0) ts[ss] = __builtin_amdgcn_s_memtime();
 #endif
-            acc[tl][pos] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ss % WB][pi][WOrder::w[k]]),
-                                                                   __builtin_bit_cast(bf16x8, bfr[WOrder::x[k]][j]), acc[tl][pos], 0, 0, 0);
-            if constexpr (kWSched.rb[s] >= 0 && !(WINO_ABL & 64)) loadb(ss + 1, kWSched.rb[s] >> 2, kWSched.rb[s] & 3);
-            if constexpr (kWSched.ra[s] >= 0 && !(WINO_ABL & 128)) {
-                constexpr int qi = kWSched.ra[s] / 3, p = kWSched.ra[s] % 3;
+            if constexpr (!(WINO_ABL & 1024) && (!(WINO_ABL & 512) || (k & 1)))
+            {
+                if constexpr (NP == 2) acc[tl][pos] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[ss % WB][pi][WO::w[k]]),
+                                                                                            __builtin_bit_cast(f16x8, bfr[WO::x[k]][j]), acc[tl][pos], 0, 0, 0);
+                else acc[tl][pos] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ss % WB][pi][WO::w[k]]),
+                                                                            __builtin_bit_cast(bf16x8, bfr[WO::x[k]][j]), acc[tl][pos], 0, 0, 0);
+            }
+            if constexpr (kWSchedOf<NP>.rb[s] >= 0 && !(WINO_ABL & 64)) loadb(ss + 1, kWSchedOf<NP>.rb[s] >> 2, kWSchedOf<NP>.rb[s] & 3);
+            if constexpr (kWSchedOf<NP>.ra[s] >= 0 && !(WINO_ABL & 128)) {
+                constexpr int qi = kWSchedOf<NP>.ra[s] / NP, p = kWSchedOf<NP>.ra[s] % NP;
                 if constexpr (ss + 3 < SS) wf[ss % WB][qi][p] = wfrag(wbase, c * 12 + wks(ss + 3, qi), p);
                 else wf[ss % WB][qi][p] = wfrag(wn, sc * 12 + wks(ss + 3 - SS, qi), p);
             }
-            if constexpr (kWSched.rl[s] >= 0 && !(WINO_ABL & 1)) st_load(kWSched.rl[s], lc0);
-            piece(std::integral_constant<int, kWSched.ext[s]>{}, dstbuf);
+            if constexpr (kWSchedOf<NP>.rl[s] >= 0 && !(WINO_ABL & 1)) st_load(kWSchedOf<NP>.rl[s], lc0);
+            piece(std::integral_constant<int, kWSchedOf<NP>.ext[s]>{}, dstbuf);
             __builtin_amdgcn_sched_barrier(0);
         });
 #ifdef MOTIF_TRACE_SS
@@ -445,6 +498,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     for (int r = 0; r < 16; ++r) acc[tl][p][r] = 0.f;
                 }
 #else
+                else if constexpr (NP == 2) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %1, 0" : "=a"(acc[tl][p]) : "v"(zq));
                 else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[tl][p]) : "v"(zq));
 #endif
             }
@@ -525,6 +579,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int it = 0; it < 4; ++it) v[it] = *(const f32x4*)(scr + (pass & 1) * 1024 + er + it * 256);
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
+                    if constexpr (NP == 2) v[it] *= 1.f / kWinoF16Scale;
                     if (rmv == 1) v[it] += rv[pass][it];
                     if constexpr (AC == MOTIF_ACT_RELU) {
 #pragma unroll
@@ -575,6 +630,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- prologue: step 0 staged in full, the row pieces of step 1 requested (nothing to hide them under) --------------------
     int t = bq;
     WNTRACE(0);
+    WNTRACE_RT(30);
     if (wave == 0) {
         fill_table(0);
         if ((long)bq + 64L * G < ntiles) fill_table(64);
@@ -591,7 +647,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float bias_v = bias_of(load_tile(0));
 #pragma unroll
     for (int i = 0; i < NLD; ++i) st_load(i, 0);
-    static_for<WSched::S>([&](auto ic) __attribute__((always_inline)) { piece(std::integral_constant<int, kWSched.ext[decltype(ic)::value]>{}, stg0); });
+    static_for<WS::S>([&](auto ic) __attribute__((always_inline)) { piece(std::integral_constant<int, kWSchedOf<NP>.ext[decltype(ic)::value]>{}, stg0); });
     if (lane < 32) bias_w[lane] = bias_v;
     init_acc();
 #pragma unroll
@@ -632,16 +688,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if ((ti & 63) == 0 && wave == 0) fill_table(ti + 64);
     }
     WNTRACE(31);
+    WNTRACE_RT(29);
 }
 
-// weight [Cout, Cin_g, 3, 3] fp32 -> A fragments [group][cout group of 64][k-step][part][cout tile][lane][8] bf16,
+// weight [Cout, Cin_g, 3, 3] fp32 -> A fragments [group][cout group of 64][k-step][part][cout tile][lane][8] bf16 (NP = 3) / fp16 of 2^8 x (NP = 2),
 // k-step = (channel group of 16, position, kx); value = U_position[kx] of the file header, formed in fp64 and split from there
+template <int NP>
 __global__ void conv_wino_pack_kernel(const float* w, unsigned short* wp, int Cout_g, int Cin_g, int nks, int ncg, long total) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), ct = (int)((i >> 9) & 1);
     long tt = i >> 10;
-    const int part = (int)(tt % 3); tt /= 3;
+    const int part = (int)(tt % NP); tt /= NP;
     const int ks = (int)(tt % nks); tt /= nks;
     const int cgi = (int)(tt % ncg);
     const int g = (int)(tt / ncg);
@@ -654,10 +712,19 @@ __global__ void conv_wino_pack_kernel(const float* w, unsigned short* wp, int Co
         v = pos == 0 ? g0 : pos == 1 ? 0.5 * (g0 + g1 + g2) : pos == 2 ? 0.5 * (g0 - g1 + g2) : g2;
     }
     unsigned short out = 0;
-    for (int p = 0; p <= part; ++p) {
-        const unsigned pk = pk_bf16((float)v, 0.f);
-        out = (unsigned short)(pk & 0xffffu);
-        v -= (double)bf_lo(pk);
+    if constexpr (NP == 2) {
+        v *= (double)kWinoF16Scale;
+        for (int p = 0; p <= part; ++p) {
+            const _Float16 h = (_Float16)(float)v;
+            out = __builtin_bit_cast(unsigned short, h);
+            v -= (double)(float)h;
+        }
+    } else {
+        for (int p = 0; p <= part; ++p) {
+            const unsigned pk = pk_bf16((float)v, 0.f);
+            out = (unsigned short)(pk & 0xffffu);
+            v -= (double)bf_lo(pk);
+        }
     }
     wp[i] = out;
 }
@@ -674,28 +741,33 @@ int wn_cu_count() {
 }
 }  // namespace
 
-// The Winograd block follows the direct block in the packed blob of every split-eligible layer with mma = 6 (pack and forward
-// agree from the desc alone); WHICH kernel runs is decided per launch.
+// The Winograd block follows the direct block in the packed blob of every split-eligible layer with mma = 6 (three bf16 parts) or
+// mma = 7 (two fp16 parts; the direct block of such a layer is the three-part one: the other kernels know no other); pack and forward
+// agree from the desc alone.  WHICH kernel runs is decided per launch.
+static inline int wino_parts(int mma) { return mma == 7 ? 2 : mma == 6 ? 3 : 0; }
+
 long motif_conv_wino_packed_floats(const MotifConvDesc* d) {
-    if (split_parts(d->mma) != 3) return 0;
+    const int NP = wino_parts(d->mma);
+    if (NP == 0) return 0;
     const int Cin_g = (d->C0 + d->C1) / d->groups, Cout_g = d->Cout / d->groups;
     const long nks = 12L * ((Cin_g + 15) / 16), ncg = (Cout_g + 63) / 64;
-    return (long)d->groups * ncg * nks * 3 * 2 * 64 * 4;
+    return (long)d->groups * ncg * nks * NP * 2 * 64 * 4;
 }
 
 int motif_conv_wino_pack(const MotifConvDesc* d, const float* weight, float* packed, hipStream_t s) {
-    const int Cin_g = (d->C0 + d->C1) / d->groups, Cout_g = d->Cout / d->groups;
+    const int Cin_g = (d->C0 + d->C1) / d->groups, Cout_g = d->Cout / d->groups, NP = wino_parts(d->mma);
     const int nks = 12 * ((Cin_g + 15) / 16), ncg = (Cout_g + 63) / 64;
-    const long total = (long)d->groups * ncg * nks * 3 * 2 * 64 * 8;
-    conv_wino_pack_kernel<<<cdiv(total, 256), 256, 0, s>>>(weight, (unsigned short*)packed, Cout_g, Cin_g, nks, ncg, total);
+    const long total = (long)d->groups * ncg * nks * NP * 2 * 64 * 8;
+    if (NP == 2) conv_wino_pack_kernel<2><<<cdiv(total, 256), 256, 0, s>>>(weight, (unsigned short*)packed, Cout_g, Cin_g, nks, ncg, total);
+    else conv_wino_pack_kernel<3><<<cdiv(total, 256), 256, 0, s>>>(weight, (unsigned short*)packed, Cout_g, Cin_g, nks, ncg, total);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }
 
 // Same layout conditions as conv_split2 (zero padding 1, rows of whole 16-byte units, aligned tensors, activation split on an
-// 8-cout boundary); 3-part arithmetic only.
+// 8-cout boundary); split arithmetic only.
 bool motif_conv_wino_eligible(const MotifConvDesc* d, const ConvArgs& a, int P) {
-    if (split_parts(d->mma) != 3 || d->pad != 1 || d->pad_mode != 0 || (d->W & 3)) return false;
+    if (wino_parts(d->mma) == 0 || d->pad != 1 || d->pad_mode != 0 || (d->W & 3)) return false;
     const long HW = (long)d->H * d->W;
     if (HW * 64 >= 0x7fffffffL) return false;
     const int Cout_g = d->Cout / d->groups;
@@ -712,7 +784,7 @@ bool motif_conv_wino_eligible(const MotifConvDesc* d, const ConvArgs& a, int P) 
 }
 
 int motif_conv_wino_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s) {
-    const int Cin_g = (d->C0 + d->C1) / d->groups, Cout_g = d->Cout / d->groups;
+    const int Cin_g = (d->C0 + d->C1) / d->groups, Cout_g = d->Cout / d->groups, NP = wino_parts(d->mma);
     const int Ho = d->H, Wo = d->W;                      // pad 1
     a.Ho = Ho; a.Wo = Wo; a.Cin_g = Cin_g; a.Cout_g = Cout_g;
     a.Kpad = 12 * ((Cin_g + 15) / 16);
@@ -727,11 +799,18 @@ int motif_conv_wino_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream
     const long T = (long)a.tiles_x * ncgG * d->N * P * tiles_y;
     if (T >= 0x7fffffffL) return MOTIF_ELIMIT;
     const int G = (int)(T < cus ? T : cus);
-    const size_t ldsb = ((size_t)4 * 16 + (size_t)2 * 3 * (2 * 16 * 34 + 4) + (size_t)4 * 640 + (size_t)128 * 4) * 16;      // bias | staging | landing | tile table
-    hipError_t e = hipFuncSetAttribute(P > 1 ? (const void*)conv_wino_kernel<true> : (const void*)conv_wino_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const size_t ldsb = ((size_t)4 * 16 + (size_t)2 * NP * (2 * 16 * 34 + 4) + (size_t)4 * 640 + (size_t)128 * 4) * 16;      // bias | staging | landing | tile table
+    const void* fn = NP == 2 ? (P > 1 ? (const void*)conv_wino_kernel<2, true> : (const void*)conv_wino_kernel<2, false>)
+                             : (P > 1 ? (const void*)conv_wino_kernel<3, true> : (const void*)conv_wino_kernel<3, false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    if (P > 1) conv_wino_kernel<true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
-    else conv_wino_kernel<false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+    if (NP == 2) {
+        if (P > 1) conv_wino_kernel<2, true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+        else conv_wino_kernel<2, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+    } else {
+        if (P > 1) conv_wino_kernel<3, true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+        else conv_wino_kernel<3, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+    }
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

@@ -58,18 +58,19 @@ def _planar(t):
 
 # ----------------------------------------------------------------------------------------- conv engine
 # Arithmetic of the convolution contractions (MotifConvDesc.mma): 0 = fp32 MFMA, 6 = fp32-equivalent 3-way bf16
-# split on the bf16 matrix cores (6 products, fp32 accumulate), 3 = 2-way split, 1 = plain bf16.
-MMA_FP32, MMA_BF16X3, MMA_BF16X2, MMA_BF16 = 0, 6, 3, 1
-_MMA_NAMES = {"fp32": MMA_FP32, "bf16x3": MMA_BF16X3, "bf16x2": MMA_BF16X2, "bf16": MMA_BF16}
-_default_mma = _MMA_NAMES[os.environ.get("MOTIF_MMA", "bf16x3")]
+# split on the bf16 matrix cores (6 products, fp32 accumulate), 3 = 2-way split, 1 = plain bf16, 7 = fp32-equivalent 2-way
+# fp16 split (3 products) in the kernels that have that form (conv_wino.hip: 3x3 stride 1) and 6 everywhere else.
+MMA_FP32, MMA_BF16X3, MMA_BF16X2, MMA_BF16, MMA_F16X2 = 0, 6, 3, 1, 7
+_MMA_NAMES = {"fp32": MMA_FP32, "bf16x3": MMA_BF16X3, "bf16x2": MMA_BF16X2, "bf16": MMA_BF16, "f16x2": MMA_F16X2}
+_default_mma = _MMA_NAMES[os.environ.get("MOTIF_MMA", "f16x2")]
 _conv_mma = int(os.environ.get("MOTIF_CONV_MMA", str(_default_mma)))
 
 
 def set_conv_mma(mode):
     """Select the arithmetic for eligible conv layers (3x3, stride 1, > 32 couts); plans re-pack on the next call."""
     global _conv_mma
-    if mode not in (MMA_FP32, MMA_BF16X3, MMA_BF16X2, MMA_BF16):
-        raise ValueError("conv mma mode must be 0, 6, 3 or 1")
+    if mode not in (MMA_FP32, MMA_BF16X3, MMA_BF16X2, MMA_BF16, MMA_F16X2):
+        raise ValueError("conv mma mode must be 0, 6, 3, 1 or 7")
     _conv_mma = mode
 
 
@@ -207,7 +208,7 @@ def dcn_v2_multi(dplans, xs, oms, dg=8, act=ACT_NONE, kh=3, kw=3, stride=1, pad=
     fused = (kh == 3 and kw == 3 and stride == 1 and pad == 1 and dil == 1 and (c // dg) % 4 == 0
              and act in (ACT_NONE, ACT_LRELU, ACT_RELU) and not os.environ.get("MOTIF_DCN_UNFUSED"))
     if fused:
-        split = _conv_mma == MMA_BF16X3 and not os.environ.get("MOTIF_DCN_FP32")
+        split = _conv_mma in (MMA_BF16X3, MMA_F16X2) and not os.environ.get("MOTIF_DCN_FP32")
         packs = [dp.packed_split() if split else dp.plan3x3().packed() for dp in dplans]
         biases = [dp.bias.detach() for dp in dplans]
         masks = (ctypes.c_void_p * P)(*[o.data_ptr() + 4 * 2 * dg * t * ho * wo for o in oms])
@@ -345,9 +346,10 @@ _siren_mma = int(os.environ.get("MOTIF_SIREN_MMA", str(MMA_BF16X3 if _default_mm
 
 
 def set_mma(name):
-    """Arithmetic of the dense contractions on the path: "bf16x3" (default: fp32-equivalent 3-way bf16 split on the
-    bf16 matrix cores, convolutions and MLPs), "fp32" (v_mfma_f32_32x32x2_f32 everywhere), "bf16x2" / "bf16"
-    (convolutions only; reduced precision, the MLPs stay bf16x3)."""
+    """Arithmetic of the dense contractions on the path: "bf16x3" (fp32-equivalent 3-way bf16 split on the bf16 matrix
+    cores, convolutions and MLPs), "f16x2" (default: the same, with the fp32-equivalent 2-way fp16 split in the 3x3 stride-1
+    convolutions conv_wino.hip serves), "fp32" (v_mfma_f32_32x32x2_f32 everywhere), "bf16x2" / "bf16" (convolutions only;
+    reduced precision, the MLPs stay bf16x3)."""
     mode = _MMA_NAMES[name]
     set_conv_mma(mode)
     set_siren_mma(MMA_FP32 if mode == MMA_FP32 else MMA_BF16X3)

@@ -441,12 +441,15 @@ def test_raft_checkpoint_ingestion_follows_the_reference_rename_loop(tmp_path):
 
 
 def test_arithmetic_mode_option_plumbing():
-    """network_G.mma / ops.set_mma select the contraction engines; default is the bf16x3 split."""
+    """network_G.mma / ops.set_mma select the contraction engines; default is "f16x2" (the bf16x3 split with the
+    two-part fp16 form in conv_wino.hip's layers)."""
     from motif_amd import ops, option
     from motif_amd.models import networks
     before = ops.get_mma()
     try:
-        assert before in ("bf16x3", "fp32", "bf16x2", "bf16")
+        assert before in ("f16x2", "bf16x3", "fp32", "bf16x2", "bf16")
+        networks.define_G(option.default_opt(mma="f16x2"))
+        assert ops.get_conv_mma() == ops.MMA_F16X2 and ops.get_siren_mma() == ops.MMA_BF16X3
         networks.define_G(option.default_opt(mma="fp32"))
         assert ops.get_mma() == "fp32" and ops.get_conv_mma() == ops.MMA_FP32 and ops.get_siren_mma() == ops.MMA_FP32
         networks.define_G(option.default_opt(mma="bf16"))

@@ -34,11 +34,11 @@ def close(a, b, atol, rtol=0.0, what=""):
         what, err.max().item(), atol, int(bad.sum()), bad.numel(), b.abs().max().item())
 
 
-@pytest.fixture(params=["bf16x3", "fp32"])
+@pytest.fixture(params=["f16x2", "bf16x3", "fp32"])
 def engine(request):
     """Arithmetic engine of the dense contractions for one test: the 3-way bf16 split on the bf16 matrix cores
-    (conv_split_kernel / dcn_fused_kernel<8,true>, the bench default) and the fp32 MFMA (conv_igemm_kernel /
-    dcn_fused_kernel<8,false>).  The previous mode is restored afterwards -- no test leaks its mode into the next."""
+    (conv_split_kernel / dcn_fused_kernel<8,true>), the same with the two-part fp16 form of conv_wino.hip on the 3x3 stride-1
+    layers ("f16x2", the bench default) and the fp32 MFMA (conv_igemm_kernel / dcn_fused_kernel<8,false>).  The previous mode is restored afterwards -- no test leaks its mode into the next."""
     from motif_amd import ops
     before = ops.get_mma()
     ops.set_mma(request.param)
@@ -170,8 +170,8 @@ SPLIT_CASES = [  # cin, cout, groups, pad_mode, H, W, N, two-source split (0 = s
 
 @pytest.mark.parametrize("case", SPLIT_CASES)
 def test_conv_split_engine_is_fp32_equivalent(case, keep_mma):
-    """mma=6 (3-way bf16 split, 6 products on the bf16 matrix cores) against an fp64 convolution: its error must
-    not exceed the fp32-MFMA engine's; mma=3 / mma=1 keep 16 / 8 mantissa bits."""
+    """mma=6 (3-way bf16 split, 6 products on the bf16 matrix cores) and mma=7 (2-way fp16 split, 3 products) against an fp64
+    convolution: their error must not exceed the fp32-MFMA engine's; mma=3 / mma=1 keep 16 / 8 mantissa bits."""
     from motif_amd import ops
     from motif_amd.models.modules.layers import Conv2d
     cin, cout, groups, pm, H, W, N, c0 = case
@@ -187,13 +187,15 @@ def test_conv_split_engine_is_fp32_equivalent(case, keep_mma):
     xd, rd = x.to(dev()), res.to(dev())
     args = (xd[:, :c0].contiguous(), xd[:, c0:].contiguous()) if c0 else (xd, None)
     err = {}
-    for mode in (ops.MMA_FP32, ops.MMA_BF16X3, ops.MMA_BF16X2, ops.MMA_BF16):
+    for mode in (ops.MMA_FP32, ops.MMA_BF16X3, ops.MMA_F16X2, ops.MMA_BF16X2, ops.MMA_BF16):
         ops.set_conv_mma(mode)
         out = m(*args, act=ops.ACT_LRELU, res=rd, res_mode=1)
         err[mode] = float((out.detach().double().cpu() - ref).abs().max())
     scale = float(ref.abs().max())
     assert err[ops.MMA_FP32] < 2e-6 * scale, err
     assert err[ops.MMA_BF16X3] <= 1.25 * err[ops.MMA_FP32] + 1e-7 * scale, err
+    # two fp16 parts, three products (conv_wino.hip where the layer is eligible, the three-part kernels elsewhere): the same bound
+    assert err[ops.MMA_F16X2] <= 1.25 * err[ops.MMA_FP32] + 1e-7 * scale, err
     assert err[ops.MMA_BF16X2] < 1e-4 * scale, err
     assert 1e-4 * scale < err[ops.MMA_BF16] < 3e-2 * scale, err      # really ran in bf16
 
@@ -273,7 +275,7 @@ def test_conv_split_multi_problem_and_views(keep_mma):
     assert float(buf[:, :8].abs().max()) == 0 and float(buf[:, 72:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("tile", [2, 3, 4, 5], ids=["rows12", "rows8", "rows6x2", "wino"])
+@pytest.mark.parametrize("tile", [2, 3, 4, 5, 7], ids=["rows12", "rows8", "rows6x2", "wino", "wino_f16x2"])
 @pytest.mark.parametrize("shape", [(3, 64, 64, 180, 320), (2, 64, 216, 90, 160), (5, 128, 64, 63, 100), (1, 48, 80, 19, 36), (2, 81, 96, 12, 16)])
 def test_conv_split2_persistent_tiles(shape, tile, keep_mma):
     """The round-3 conv kernel over MANY tiles per workgroup (persistent loop, next tile staged under the last chunk, ragged last
@@ -290,22 +292,24 @@ def test_conv_split2_persistent_tiles(shape, tile, keep_mma):
     x, res = rnd(n, cin, H, W, seed=3), rnd(n, cout, H, W, seed=4)
     ref = F.relu(F.conv2d(x, m.weight, m.bias, 1, 1)) + res
     m = m.to(dev())
-    ops.set_conv_mma(ops.MMA_BF16X3)
+    ops.set_conv_mma(ops.MMA_F16X2 if tile == 7 else ops.MMA_BF16X3)
     try:
-        ops.set_option("conv_engine", tile)               # the round-3 kernel, 12-row (2) or 8-row (3) tiles, whatever the tile count; 5 = the round-4 Winograd F(2,3) kernel
+        ops.set_option("conv_engine", 5 if tile == 7 else tile)      # the round-3 kernel, 12-row (2) or 8-row (3) tiles, whatever the tile count; 5 = the round-4 Winograd F(2,3) kernel (7: its two-part fp16 form)
         out = m(x.to(dev()), act=ops.ACT_RELU, res=res.to(dev()), res_mode=2)
+        ops.set_conv_mma(ops.MMA_BF16X3)
         ops.set_option("conv_engine", 1)
         old = m(x.to(dev()), act=ops.ACT_RELU, res=res.to(dev()), res_mode=2)
     finally:
         ops.set_option("conv_engine", 0)
     close(out, ref, 2e-5, 2e-5, "split2 vs torch")
-    tol = 4e-6 if tile == 5 else 2e-6                    # Winograd F(2,3): one more fp32 addition per operand and a three-term output sum
+    tol = 4e-6 if tile in (5, 7) else 2e-6                    # Winograd F(2,3): one more fp32 addition per operand and a three-term output sum
     close(out, old, tol, tol, "split2 / wino vs two-block kernel")
 
 
 @pytest.mark.parametrize("case", [(6, 64, 64, 180, 320, "lrelu", 0), (3, 64, 64, 64, 96, "relu", 2), (3, 128, 64, 64, 96, "relu", 0), (3, 64, 216, 64, 96, "none", 0),
                                   (5, 64, 64, 16, 24, "none", 1)], ids=lambda c: "x".join(str(v) for v in c))
-def test_conv_wino_same_bits_whatever_the_batch_and_the_run(case, keep_mma):
+@pytest.mark.parametrize("parts", [3, 2], ids=["bf16x3", "f16x2"])
+def test_conv_wino_same_bits_whatever_the_batch_and_the_run(case, parts, keep_mma):
     """A frame's output bits depend neither on the batch it sits in (which workgroup picks a tile up, what that workgroup did before)
     nor on the run.  Found a timing-dependent fault the tolerance tests let through: gfx950 wants TWO wait states between a store of
     more than 8 bytes and the next vector write of its data registers, and hipcc adds none around inline-assembly stores."""
@@ -319,7 +323,7 @@ def test_conv_wino_same_bits_whatever_the_batch_and_the_run(case, keep_mma):
         m.bias.copy_(rnd(cout, seed=2, scale=0.1))
     m = m.to(dev())
     x, res = rnd(n, cin, H, W, seed=3).to(dev()), rnd(n, cout, H, W, seed=4).to(dev())
-    ops.set_conv_mma(ops.MMA_BF16X3)
+    ops.set_conv_mma(ops.MMA_BF16X3 if parts == 3 else ops.MMA_F16X2)
     try:
         ops.set_option("conv_engine", 5)
         kw = lambda k: dict(act=act) if rm == 0 else dict(act=act, res=res[:k].contiguous(), res_mode=rm)
@@ -1057,7 +1061,7 @@ def test_dcn_fused_multi_vs_kernel_text(engine):
     dcn_fused_kernel<8,true> (the bench default: GEMM on the bf16 matrix cores), fp32 runs dcn_fused_kernel<8,false>."""
     from oracle import native
     from motif_amd import ops
-    assert ops.get_conv_mma() == (ops.MMA_BF16X3 if engine == "bf16x3" else ops.MMA_FP32)
+    assert ops.get_conv_mma() == {"bf16x3": ops.MMA_BF16X3, "f16x2": ops.MMA_F16X2, "fp32": ops.MMA_FP32}[engine]      # f16x2: the DCN GEMM stays three-part
     assert not os.environ.get("MOTIF_DCN_UNFUSED") and not os.environ.get("MOTIF_DCN_FP32")
     B, C, H, W, dg, P = 2, 64, 21, 45, 8, 3
     outs_ref, plans, xs, oms = [], [], [], []

@@ -41,10 +41,14 @@ def psnr(a, b):
     return 99.0 if mse == 0 else 10 * np.log10(1.0 / mse)
 
 
-@pytest.fixture(params=["bf16x3", "fp32"], autouse=True)
+DEFAULT_MMA = "f16x2"
+
+
+@pytest.fixture(params=["f16x2", "bf16x3", "fp32"], autouse=True)
 def mma_mode(request):
-    """Every model-level parity test runs on both contraction engines: the bf16 matrix cores with the 3-way split
-    (default) and the fp32 MFMA."""
+    """Every model-level parity test runs on all contraction engines: the 16-bit matrix cores with the fp32-equivalent splits
+    ("f16x2" = the default: two fp16 parts in conv_wino.hip's 3x3 layers, three bf16 parts elsewhere; "bf16x3": three bf16 parts
+    everywhere) and the fp32 MFMA."""
     from motif_amd import ops
     before = ops.get_mma()
     ops.set_mma(request.param)
@@ -344,7 +348,7 @@ def test_c3_vimeo_septuplet_bf16_path(mma_mode):
     convolution arithmetic modes against the fp32-MFMA engine on the same weights/inputs: bf16x3 (fp32-equivalent
     split) >= 90 dB, plain bf16 convolutions (`mma: bf16`, the "bf16 MFMA path") >= 60 dB with a Y-PSNR against the
     synthetic GT within 0.05 dB (measured on MI355X: 106.1 dB / 71.8 dB)."""
-    if mma_mode != "bf16x3":
+    if mma_mode != DEFAULT_MMA:
         pytest.skip("runs all arithmetic modes itself")
     from motif_amd import ops
     from motif_amd.data.synthetic import synthetic_sample
@@ -359,7 +363,7 @@ def test_c3_vimeo_septuplet_bf16_path(mma_mode):
     gt = smp["GT"][0, :9]
     outs, ypsnr = {}, {}
     try:
-        for mode in ("fp32", "bf16x3", "bf16"):
+        for mode in ("fp32", "bf16x3", "f16x2", "bf16"):
             ops.set_mma(mode)
             model.feed_data(data)
             model.test()
@@ -367,11 +371,11 @@ def test_c3_vimeo_septuplet_bf16_path(mma_mode):
             assert outs[mode].shape == (9, 1, 3, 1024, 1792)
             ypsnr[mode] = util.y_psnr_per_frame(gt, outs[mode][:, 0])
     finally:
-        ops.set_mma("bf16x3")
-    p3, p1 = psnr(outs["bf16x3"], outs["fp32"]), psnr(outs["bf16"], outs["fp32"])
-    print("c3: PSNR(bf16x3, fp32) = %.1f dB, PSNR(bf16, fp32) = %.1f dB" % (p3, p1))
-    assert p3 >= 90.0 and p1 >= 60.0, (p3, p1)
-    assert np.abs(ypsnr["bf16"] - ypsnr["fp32"]).max() < 0.05 and np.abs(ypsnr["bf16x3"] - ypsnr["fp32"]).max() < 0.05
+        ops.set_mma(DEFAULT_MMA)
+    p3, p2, p1 = psnr(outs["bf16x3"], outs["fp32"]), psnr(outs["f16x2"], outs["fp32"]), psnr(outs["bf16"], outs["fp32"])
+    print("c3: PSNR(bf16x3, fp32) = %.1f dB, PSNR(f16x2, fp32) = %.1f dB, PSNR(bf16, fp32) = %.1f dB" % (p3, p2, p1))
+    assert p3 >= 90.0 and p2 >= 90.0 and p1 >= 60.0, (p3, p2, p1)
+    assert max(np.abs(ypsnr[m] - ypsnr["fp32"]).max() for m in ("bf16", "bf16x3", "f16x2")) < 0.05
 
 
 def test_row_band_tiling_matches_untiled(net):
@@ -501,7 +505,7 @@ def test_c5_row_bands_match_untiled_at_full_size(mma_mode):
     after band in this one process, is bit-identical to the untiled render -- frames and returned flow."""
     from motif_amd import dist as md
     from motif_amd.data.synthetic import synthetic_sample
-    if mma_mode != "bf16x3":
+    if mma_mode != DEFAULT_MMA:
         pytest.skip("one engine is enough at this size (the band mechanism is engine independent)")
     h, w, s, T, bands, halo = 540, 960, 4, 5, 8, 64
     HH, WW = h * s, w * s
@@ -545,7 +549,7 @@ def test_c5_cropped_tile_mode_psnr(mma_mode):
     more than 30 % of the LR rows (that is what makes an 8-GPU job >= 3.5x faster than one GPU)."""
     from motif_amd import dist as md
     from motif_amd.data.synthetic import synthetic_sample
-    if mma_mode != "bf16x3":
+    if mma_mode != DEFAULT_MMA:
         pytest.skip("one engine is enough at this size")
     h, w, s, T, bands, halo, R = 540, 960, 4, 5, 8, 64, 16
     HH, WW = h * s, w * s
@@ -590,7 +594,7 @@ def test_c3_crop_bf16_path_vs_oracle(mma_mode):
     crop of the Vimeo-7 septuplet shape the oracle finishes in seconds: 7 LR frames 64x112, x4 spatial, x8 temporal = 9
     timestamps.  Tolerance for bf16: PSNR(build, oracle) >= 55 dB and Y-PSNR vs the seeded GT within 0.05 dB; the
     fp32-equivalent engines must reach >= 60 dB on the same clip."""
-    if mma_mode != "bf16x3":
+    if mma_mode != DEFAULT_MMA:
         pytest.skip("runs all arithmetic modes itself")
     from oracle.motif_ref import MotifRef
     from motif_amd import ops
@@ -610,16 +614,16 @@ def test_c3_crop_bf16_path_vs_oracle(mma_mode):
     yref = util.y_psnr_per_frame(gt, ref[:, 0])
     res = {}
     try:
-        for mode in ("bf16", "bf16x3", "fp32"):
+        for mode in ("bf16", "bf16x3", "f16x2", "fp32"):
             ops.set_mma(mode)
             model.feed_data(data)
             model.test()
             out = model.fake_H.float().cpu()
             res[mode] = (psnr(out, ref), float(np.abs(util.y_psnr_per_frame(gt, out[:, 0]) - yref).max()))
     finally:
-        ops.set_mma("bf16x3")
+        ops.set_mma(DEFAULT_MMA)
     print("c3 crop vs oracle: " + ", ".join("%s %.1f dB (dY %.4f)" % (k, v[0], v[1]) for k, v in res.items()))
-    assert res["bf16"][0] >= 55.0 and res["bf16x3"][0] >= 60.0 and res["fp32"][0] >= 60.0, res
+    assert res["bf16"][0] >= 55.0 and res["bf16x3"][0] >= 60.0 and res["f16x2"][0] >= 60.0 and res["fp32"][0] >= 60.0, res
     assert max(v[1] for v in res.values()) < 0.05, res
 
 
@@ -690,7 +694,7 @@ def test_two_clips_in_flight_equal_the_serial_renders():
 def test_four_frame_generators_full_size_properties(which, mma_mode):
     """The 4-frame generators at BASELINE config-2 size (180x320 -> 720x1280) through the shell: shapes, range, finiteness, and
     for Ours_44 the one-timestamp-per-call branch with the residual picked by int(t*6) (t = 5/6 -> feature 4, t = 1 -> 6)."""
-    if mma_mode != "bf16x3":
+    if mma_mode != DEFAULT_MMA:
         pytest.skip("one engine is enough at this size")
     from motif_amd.data.synthetic import synthetic_sample
     from motif_amd.models import create_model

@@ -30,6 +30,8 @@ def main():
     reps = int(os.environ.get("REPS", "20"))
     only = os.environ.get("ONLY")
     from motif_amd import ops
+    if os.environ.get("MMA"):
+        ops.set_conv_mma(int(os.environ["MMA"]))                       # 6 = three bf16 parts, 7 = two fp16 parts (conv_wino.hip)
     if os.environ.get("ENGINE"):
         ops.set_option("conv_engine", int(os.environ["ENGINE"]))      # 1 = round-2 two-block kernel, 2 / 3 = round-3 kernel, 5 = round-4 Winograd kernel, 6 = never it, 0 = the library's choice
     print("conv mma mode", ops.get_conv_mma(), "engine", ops.get_option("conv_engine"))

@@ -18,8 +18,10 @@ kw = dict(act=int(os.environ.get("ACT", "1")), res=res, res_mode=1) if res is no
 for _ in range(3):
     y = m(x, **kw)
 torch.cuda.synchronize()
+if os.environ.get("MMA"):
+    ops.set_conv_mma(int(os.environ["MMA"]))
 ops.set_option("conv_engine", 5)
-for _ in range(2):
+for _ in range(int(os.environ.get("REPS", "2"))):      # REPS=500: the traced (last) launch sees the clock of a sustained run
     y = m(x, **kw)
 torch.cuda.synchronize()
 lib = _lib.load()
@@ -41,6 +43,8 @@ for i in range(9):
         row.append("%s %6.2f" % (lab[k3] if k3 else "chunk(from prev stamp)", ((t[:, :, sl] - t[:, :, sl - 1])[v].mean() / 1e3) if v.any() else float("nan")))
     print("  iteration %d (chunk %d): %s" % (i, i % nch, " | ".join(row)))
 print("block duration mean %.2f kcyc, max %.2f" % ((t[:, :, 31] - t[:, :, 0])[ok].mean() / 1e3, (t[:, :, 31] - t[:, :, 0])[ok].max() / 1e3))
+rt = (t[:, :, 29] - t[:, :, 30])[ok] / 100.0                      # us on the constant 100 MHz counter
+print("block duration mean %.2f us -> shader clock %.0f MHz while the kernel runs" % (rt.mean(), ((t[:, :, 31] - t[:, :, 0])[ok] / rt).mean()))
 
 buf2 = (ctypes.c_longlong * (256 * 4 * 8 * 8))()
 lib.motif_debug_wino_trace2.restype = ctypes.c_int

@@ -21,7 +21,7 @@ for n, cin, cout, H, W in CASES:
     ref = F.relu(F.conv2d(x.double(), m.weight.double(), m.bias.double(), 1, 1)) + res.double()
     m = m.cuda()
     errs = {}
-    for name, mma, eng in (("fp32", ops.MMA_FP32, 0), ("split", ops.MMA_BF16X3, 1), ("split2", ops.MMA_BF16X3, 2), ("wino", ops.MMA_BF16X3, 5)):
+    for name, mma, eng in (("fp32", ops.MMA_FP32, 0), ("split", ops.MMA_BF16X3, 1), ("split2", ops.MMA_BF16X3, 2), ("wino", ops.MMA_BF16X3, 5), ("wino_f16x2", ops.MMA_F16X2, 5)):
         ops.set_conv_mma(mma)
         ops.set_option("conv_engine", eng)
         out = m(x.cuda(), act=ops.ACT_RELU, res=res.cuda(), res_mode=2)

@@ -11,7 +11,7 @@ def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.rand(*shape, generator=g) * 2 - 1) * scale
 
-ops.set_conv_mma(ops.MMA_BF16X3)
+ops.set_conv_mma(int(os.environ.get("MMA", str(ops.MMA_BF16X3))))
 ops.set_option("conv_engine", int(os.environ.get("ENGINE", "5")))
 bad = 0
 for n, cin, cout, H, W, act, rm in [(3, 64, 64, 64, 96, ops.ACT_RELU, 2), (3, 64, 64, 64, 96, ops.ACT_NONE, 0), (6, 64, 64, 180, 320, ops.ACT_LRELU, 0),
