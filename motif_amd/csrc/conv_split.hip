@@ -255,9 +255,10 @@ int motif_conv_split_pack(const MotifConvDesc* d, const float* weight, float* pa
 int motif_conv_split_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s) {
     {                                                    // round 4: conv_wino.hip (conv_engine 5 = wherever it applies, 6 = never)
         const int force = motif_opt(MOTIF_OPT_CONV_ENGINE);
-        // by measurement inside the clip (gpurun_out/r4/shapes_*.txt): faster on every 3x3 layer except those with a transcendental
-        // epilogue (the offset | sigmoid(mask) layers of the DCNs: a lone wave hides none of the exp / rcp chains of its exposed epilogue)
-        const bool plain_act = d->act_split <= 0 && (d->act == MOTIF_ACT_NONE || d->act == MOTIF_ACT_RELU || d->act == MOTIF_ACT_LRELU);
+        // by measurement inside the clip (gpurun_out/r4/shapes_*.txt): the three-part form is faster on every 3x3 layer except those
+        // with a transcendental epilogue (the offset | sigmoid(mask) layers of the DCNs: a lone wave hides none of the exp / rcp chains
+        // of its exposed epilogue); the two-part form (mma = 7) is faster there too (507 vs 723 us on 8 x 64 -> 216 x 180 x 320)
+        const bool plain_act = d->mma == 7 || (d->act_split <= 0 && (d->act == MOTIF_ACT_NONE || d->act == MOTIF_ACT_RELU || d->act == MOTIF_ACT_LRELU));
         if ((force == 5 || (force == 0 && plain_act)) && motif_conv_wino_eligible(d, a, P)) return motif_conv_wino_launch(d, a, P, s);
     }
     if (motif_opt(MOTIF_OPT_CONV_ENGINE) != 1 && motif_conv_split2_eligible(d, a, P)) return motif_conv_split2_launch(d, a, P, s);   // round 3: conv_split2.hip

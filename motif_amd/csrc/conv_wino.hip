@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     scr[(pass & 1) * 1024 + ew + r3 * 128 + (2 * tl + 1) * 32] = o1;
                 }
         };
-        // AC / RM >= 0: activation / residual mode known at compile time (the common layers: one straight-line body, no per-item
+        // AC / RM >= 0 (AC = -2: no activation below act_split, sigmoid from there on): activation / residual mode known at compile time (the common layers: one straight-line body, no per-item
         // scalar branches -- 16 items x the generic chain of wave-uniform tests cost a lone wave ~2 k cycles); -1: run-time switches.
         auto passes = [&](auto ac_tag, auto rm_tag) __attribute__((always_inline)) {
             constexpr int AC = decltype(ac_tag)::value, RM = decltype(rm_tag)::value;
@@ -587,6 +587,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     } else if constexpr (AC == MOTIF_ACT_LRELU) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[it][q] = v[it][q] > 0.f ? v[it][q] : 0.1f * v[it][q];
+                    } else if constexpr (AC == -2) {         // offset | sigmoid(mask): one uniform test per pass, 1 / (1 + e^-x) with the hardware reciprocal (1 ulp)
+                        if (cb + 8 * pass >= a.act_split) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[it][q] = __builtin_amdgcn_rcpf(1.f + expf(-v[it][q]));
+                        }
                     } else if constexpr (AC < 0) v[it] = act_uniform(v[it], ac);
                     if (rmv == 2) v[it] += rv[pass][it];
                     else if (rmv == 3) {
@@ -609,7 +614,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         };
         using I = std::integral_constant<int, 0>;
         const int act = a.act;
-        if (a.act_split > 0) passes(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
+        if (a.act_split > 0 && rm == 0 && act == MOTIF_ACT_NONE && a.act2 == MOTIF_ACT_SIGMOID) passes(std::integral_constant<int, -2>{}, I{});    // the DCNs' offset | mask layer
+        else if (a.act_split > 0) passes(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
         else if (rm == 0 && act == MOTIF_ACT_NONE) passes(std::integral_constant<int, MOTIF_ACT_NONE>{}, I{});
         else if (rm == 0 && act == MOTIF_ACT_RELU) passes(std::integral_constant<int, MOTIF_ACT_RELU>{}, I{});
         else if (rm == 0 && act == MOTIF_ACT_LRELU) passes(std::integral_constant<int, MOTIF_ACT_LRELU>{}, I{});

@@ -42,6 +42,8 @@ def main():
         x = torch.randn(n, ci, h, w, device="cuda")
         res = torch.randn(n, co, h // s, w // s, device="cuda") if os.environ.get("RES") else None
         kw = dict(act=int(os.environ.get("ACT", "1")), res=res, res_mode=1) if res is not None else dict(act=int(os.environ.get("ACT", "1")))
+        if os.environ.get("ACT_SPLIT"):                     # the offset | sigmoid(mask) layer of a DCN: ACT=0 ACT_SPLIT=144
+            kw.update(act2=ops.ACT_SIGMOID, act_split=int(os.environ["ACT_SPLIT"]))
         for _ in range(3):
             y = m(x, **kw)
         torch.cuda.synchronize()
