@@ -13,9 +13,10 @@ this process touches the GPU; nothing is re-exec'ed) when it is not already runn
 Arithmetic (--mma): "bf16x3" runs the dense contractions (3x3 convolutions, fused DCN, the three MLPs) on the
 bf16 matrix cores with every fp32 operand split exactly into three bf16 parts and six products accumulated in fp32 --
 fp32-equivalent (error below an fp32 FMA chain, tests/test_kernels_gpu.py::test_conv_split_engine_is_fp32_equivalent);
-"f16x2" (default, round 4) is the same except that the 3x3 stride-1 convolutions served by conv_wino.hip split every operand into
-TWO fp16 parts (hi = rne(x), lo = rne(x - hi): 22+ bits) and take three products -- half the matrix instructions, error against
-fp64 at or below the three-part form's (same test); "fp32" runs everything on v_mfma_f32_32x32x2_f32.  The line carries the
+"f16x2" (default, round 4) is the same except that the 3x3 stride-1 convolutions served by conv_wino.hip and the three MLPs
+(siren_split.hip) split every operand into TWO fp16 parts (hi = rne(x), lo = rne(x - hi): 22+ bits) and take three products -- half
+the matrix instructions, error against fp64 at or below the three-part form's (same tests); the fused DCN and the 3x3 layers
+conv_wino.hip does not take stay three-part.  "fp32" runs everything on v_mfma_f32_32x32x2_f32.  The line carries the
 bf16x3 and fp32-MFMA numbers of the same run as `bf16x3` and `fp32_mfma`.
 
 Extra objects on the JSON line:
@@ -217,6 +218,8 @@ def instrumented_clip(model, sample):
         model.use_graph = use_graph
     mfma_peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
     conv3_peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if ops.get_conv_mma() == ops.MMA_F16X2 else mfma_peak      # two fp16 parts: 3 products per fp32 MAC
+    siren_peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if ops.get_siren_mma() == ops.MMA_F16X2 else mfma_peak     # (the fused DCN stays three-part: 6 products)
+    three = {"conv3x3": conv3_peak, "imnet": siren_peak, "flow_imnet": siren_peak, "synth_net": siren_peak}
     bounds = {"conv3x3": "mfma", "conv_other": "mfma", "dcn": "mfma", "imnet": "mfma", "flow_imnet": "mfma", "synth_net": "mfma", "splat": "hbm"}
     stages = {}
     for stage, e0, e1, work, _ in rec:
@@ -229,10 +232,10 @@ def instrumented_clip(model, sample):
         row = {"ms_per_clip": round(s["ms"], 3), "calls": s["launches"]}
         b = bounds.get(stage)
         if b == "mfma" and s["ms"] > 0:
-            peak = FP32_MFMA_PEAK_TFLOPS if stage == "conv_other" else conv3_peak if stage == "conv3x3" else mfma_peak      # non-3x3 / narrow layers run on the fp32 MFMA
+            peak = FP32_MFMA_PEAK_TFLOPS if stage == "conv_other" else three.get(stage, mfma_peak)      # non-3x3 / narrow layers run on the fp32 MFMA
             ach = s["work"] / (s["ms"] * 1e-3) / 1e12
             row.update(bound="mfma", tflop=round(s["work"] / 1e12, 4), achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4))
-            if stage == "conv3x3" and conv3_peak != mfma_peak:
+            if peak != mfma_peak and stage != "conv_other":
                 row["frac_of_6_product_bound"] = round(ach / mfma_peak, 4)       # the basis of rounds 2-4's bf16x3 figures (416.7 TFLOP/s)
         elif b == "hbm" and s["ms"] > 0:
             ach = s["work"] / (s["ms"] * 1e-3) / 1e9
@@ -567,8 +570,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"arithmetic": ("fp32-equivalent on the bf16 matrix cores: every fp32 operand = 3 exact bf16 parts, 6 products, fp32 "
                                   "accumulate (3x3 convolutions, fused DCN and the three MLPs); everything else fp32" if a.mma == "bf16x3"
-                                  else "fp32-equivalent on the 16-bit matrix cores: 3x3 stride-1 convolutions with every fp32 operand = 2 fp16 parts "
-                                  "(22+ bits), 3 products, fp32 accumulate (conv_wino.hip); fused DCN, the three MLPs and the remaining split "
+                                  else "fp32-equivalent on the 16-bit matrix cores: 3x3 stride-1 convolutions (conv_wino.hip) and the three MLPs with every "
+                                  "fp32 operand = 2 fp16 parts (22+ bits), 3 products, fp32 accumulate; fused DCN and the remaining split "
                                   "convolutions with 3 exact bf16 parts, 6 products; everything else fp32" if a.mma == "f16x2"
                                   else "fp32 MFMA (v_mfma_f32_32x32x2_f32) and fp32 VALU"),
                    "workload": ("c2" if world == 1 else "c4 (independent c2 clips sharded over %d GPUs as the reference's DistIterSampler strides them: "

@@ -105,20 +105,23 @@ long motif_siren_pack(const float* const* w, const float* const* b, const int* d
 
 /* The same three networks (mode 0 imnet 66-64-64-256-64, 1 flow_imnet 67-64-64-256-3, 2 synth_net
  * 198-64-64-64-256-3) packed for the bf16 matrix cores: every weight split into three bf16 parts (fp32-equivalent,
- * see MotifConvDesc.mma = 6), stored as MFMA fragments.  Pass the blob with pre = 2.  Size query with packed = NULL. */
+ * see MotifConvDesc.mma = 6), stored as MFMA fragments.  Pass the blob with pre = 2.  Size query with packed = NULL.
+ * mode + 8: the two-part fp16 form (every weight x 2^8 split into two fp16 parts, three products per fp32 MAC instead of six,
+ * MotifConvDesc.mma = 7; hidden activations are sines, so both operands suit fp16's range); pass that blob with pre = 3. */
 long motif_siren_pack_split(int mode, const float* const* w, const float* const* b, float* packed, void* stream);
 
 /* `pre` (all three): 0 = `*_lr` holds the raw LR feature (64 ch) and the whole first layer runs per HR pixel;
  * 1 = `*_lr` holds the LR-resolution partial pre-activation W0[:, gathered 64 channels] . feature + b0 (a 1x1
  * convolution done once per clip -- it depends neither on the HR pixel nor on t), which seeds the accumulator;
- * 2 = as 1, with `packed` from motif_siren_pack_split: the contractions run as 6 bf16 products per fp32 MAC.
+ * 2 = as 1, with `packed` from motif_siren_pack_split: the contractions run as 6 bf16 products per fp32 MAC;
+ * 3 = as 2, with `packed` from motif_siren_pack_split(mode + 8): 3 fp16 products per fp32 MAC.
  * imnet: in = [feat_lr[d*B+b](64 gathered) | rel_y | rel_x] -> out [2B,64,Q] planar. */
 int motif_siren_imnet_fwd(const float* packed, const float* feat_lr, const int32_t* iy, const int32_t* ix,
                           const float* rel_y, const float* rel_x, float* out,
                           int B2, int H, int W, int HH, int WW, int pre, void* stream);
 /* motif_siren_imnet_fwd with an LR tensor add_lr [2B,64,H,W] gathered through the same tables and ADDED to the 64 output planes
  * (fp32 add after the head): the pre-contracted splat's G term (see motif_splat_motif_pre_fwd, g_lr = NULL), which costs the
- * splat one load per source and plane instead of two.  pre must be 2; add_lr = NULL is motif_siren_imnet_fwd. */
+ * splat one load per source and plane instead of two.  pre must be 2 or 3; add_lr = NULL is motif_siren_imnet_fwd. */
 int motif_siren_imnet_add_fwd(const float* packed, const float* feat_lr, const float* add_lr, const int32_t* iy, const int32_t* ix,
                               const float* rel_y, const float* rel_x, float* out,
                               int B2, int H, int W, int HH, int WW, int pre, void* stream);
@@ -135,10 +138,10 @@ int motif_siren_synth_fwd(const float* packed, const float* acc, const float* re
 /* synth on the pre-contracted accumulator of motif_splat_motif_pre_fwd: pre-activation of the first layer =
  * residual_l0 (the LR partial W0[:, 133:197] . residual + b0, as with pre = 1/2) + acc[0:64] / warped_z +
  * W0[:, 130:133] . extra + W0[:, 197] t, with the exact-equality patches of Ours.py:811-830 on warped_z / count;
- * `packed` from motif_siren_pack_split(kind = 3).  bf16x3 arithmetic only. */
+ * `packed` from motif_siren_pack_split(kind = 3 [+ 8]).  Split arithmetic only: pre = 2 (three bf16 parts) or 3 (two fp16 parts). */
 int motif_siren_synth_pre_fwd(const float* packed, const float* acc67, const float* residual_l0,
                               const int32_t* iy, const int32_t* ix, const float* times, float* frames,
-                              int B, int N, int H, int W, int HH, int WW, void* stream);
+                              int B, int N, int H, int W, int HH, int WW, int pre, void* stream);
 /* debugging/parity aid: materialise the 198-channel synth input [B*N,198,HH,WW] (Ours.py:839-844). */
 int motif_synth_input_fwd(const float* acc, const float* residual_lr, const int32_t* iy, const int32_t* ix,
                           const float* times, float* out, int B, int N, int H, int W, int HH, int WW, void* stream);
@@ -168,7 +171,15 @@ typedef struct MotifConvDesc {
                                  (layout, alignment, epilogue: option conv_engine).  The Winograd form has the same
                                  6-product arithmetic with 2/3 of the matrix instructions; its rounding differs from the
                                  direct form by one fp32 addition per operand and a three-term output sum (measured
-                                 against fp64: not larger than the direct form's error). */
+                                 against fp64: not larger than the direct form's error).
+                                 7 = as 6, except that the Winograd block and kernel use the TWO-PART fp16 form: every
+                                 operand = hi + lo, hi = rne_fp16(x), lo = rne_fp16(x - hi) (|x - hi - lo| <= 2^-23 |x| while
+                                 both parts are normal fp16 numbers, an absolute 2^-25 below that), three products per
+                                 fp32 MAC instead of six; the weights are packed times 2^8 (so that the low parts of
+                                 everyday weights are normal) and the epilogue multiplies by 2^-8, both exact.  Range:
+                                 |2 x| and 2^8 |1.5 w| must stay below 65504 (fp16), beyond that the result is inf / NaN,
+                                 never a silently clamped value; measured against fp64 its error is at or below mode 6's
+                                 (tests/test_kernels_gpu.py).  Layers the Winograd kernel does not take run as mode 6. */
 } MotifConvDesc;
 
 long motif_conv2d_packed_size(const MotifConvDesc* d);

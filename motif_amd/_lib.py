@@ -31,7 +31,7 @@ _SIGS = {
     "motif_splat_motif_fwd": (c_int, [P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_splat_motif_acc_fwd": (c_int, [P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_splat_motif_pre_fwd": (c_int, [P, P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "motif_siren_synth_pre_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "motif_siren_synth_pre_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_reliability_pairs_fwd": (c_int, [P, c_long, c_long, P, P, POINTER(c_int), POINTER(c_float), c_int, c_int, P, P, c_int, c_int, c_int, P]),
     "motif_siren_pack": (c_long, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), c_int, P, P]),
     "motif_frames_u8_to_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

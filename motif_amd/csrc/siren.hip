@@ -479,7 +479,7 @@ extern "C" int motif_siren_imnet_fwd(const float* packed, const float* feat_lr, 
                                      int B2, int H, int W, int HH, int WW, int pre, void* stream) {
     if (!packed || !feat_lr || !iy || !ix || !rel_y || !rel_x || !out || B2 < 1) return MOTIF_EINVAL;
     SirenArgs a{packed, feat_lr, nullptr, iy, ix, rel_y, rel_x, nullptr, out, B2, 1, B2, H, W, HH, WW};
-    if (pre == 2) return motif_siren_split_launch(MODE_IMNET, a, stream);
+    if (pre == 2 || pre == 3) return motif_siren_split_launch(MODE_IMNET, a, stream, pre == 3 ? 2 : 3);
     return pre ? launch_siren<MODE_IMNET, SIREN_TP_IMNET, true>(a, stream) : launch_siren<MODE_IMNET, SIREN_TP_IMNET, false>(a, stream);
 }
 
@@ -488,10 +488,10 @@ extern "C" int motif_siren_imnet_add_fwd(const float* packed, const float* feat_
                                          int B2, int H, int W, int HH, int WW, int pre, void* stream) {
     if (!add_lr) return motif_siren_imnet_fwd(packed, feat_lr, iy, ix, rel_y, rel_x, out, B2, H, W, HH, WW, pre, stream);
     if (!packed || !feat_lr || !iy || !ix || !rel_y || !rel_x || !out || B2 < 1) return MOTIF_EINVAL;
-    if (pre != 2) return MOTIF_EINVAL;                // the added LR term exists for the split (bf16 matrix core) engine only
+    if (pre != 2 && pre != 3) return MOTIF_EINVAL;    // the added LR term exists for the split (16-bit matrix core) engines only
     SirenArgs a{packed, feat_lr, nullptr, iy, ix, rel_y, rel_x, nullptr, out, B2, 1, B2, H, W, HH, WW};
     a.add_lr = add_lr;
-    return motif_siren_split_launch(MODE_IMNET, a, stream);
+    return motif_siren_split_launch(MODE_IMNET, a, stream, pre == 3 ? 2 : 3);
 }
 
 extern "C" int motif_siren_flow_fwd(const float* packed, const float* flowfeat_lr, const int32_t* iy, const int32_t* ix,
@@ -499,7 +499,7 @@ extern "C" int motif_siren_flow_fwd(const float* packed, const float* flowfeat_l
                                     int B2, int N, int H, int W, int HH, int WW, int pre, void* stream) {
     if (!packed || !flowfeat_lr || !iy || !ix || !rel_y || !rel_x || !times || !pred || B2 < 2 || (B2 & 1) || N < 1) return MOTIF_EINVAL;
     SirenArgs a{packed, flowfeat_lr, nullptr, iy, ix, rel_y, rel_x, times, pred, B2 * N, N, B2 / 2, H, W, HH, WW};
-    if (pre == 2) return motif_siren_split_launch(MODE_FLOW, a, stream);
+    if (pre == 2 || pre == 3) return motif_siren_split_launch(MODE_FLOW, a, stream, pre == 3 ? 2 : 3);
     return pre ? launch_siren<MODE_FLOW, SIREN_TP_FLOW, true>(a, stream) : launch_siren<MODE_FLOW, SIREN_TP_FLOW, false>(a, stream);
 }
 
@@ -508,16 +508,16 @@ extern "C" int motif_siren_synth_fwd(const float* packed, const float* acc, cons
                                      int B, int N, int H, int W, int HH, int WW, int pre, void* stream) {
     if (!packed || !acc || !residual_lr || !iy || !ix || !times || !frames || B < 1 || N < 1) return MOTIF_EINVAL;
     SirenArgs a{packed, residual_lr, acc, iy, ix, nullptr, nullptr, times, frames, B * N, N, B, H, W, HH, WW};
-    if (pre == 2) return motif_siren_split_launch(MODE_SYNTH, a, stream);
+    if (pre == 2 || pre == 3) return motif_siren_split_launch(MODE_SYNTH, a, stream, pre == 3 ? 2 : 3);
     return pre ? launch_siren<MODE_SYNTH, SIREN_TP_SYNTH, true>(a, stream) : launch_siren<MODE_SYNTH, SIREN_TP_SYNTH, false>(a, stream);
 }
 
 extern "C" int motif_siren_synth_pre_fwd(const float* packed, const float* acc, const float* residual_l0,
                                          const int32_t* iy, const int32_t* ix, const float* times, float* frames,
-                                         int B, int N, int H, int W, int HH, int WW, void* stream) {
-    if (!packed || !acc || !residual_l0 || !iy || !ix || !times || !frames || B < 1 || N < 1) return MOTIF_EINVAL;
+                                         int B, int N, int H, int W, int HH, int WW, int pre, void* stream) {
+    if (!packed || !acc || !residual_l0 || !iy || !ix || !times || !frames || B < 1 || N < 1 || (pre != 2 && pre != 3)) return MOTIF_EINVAL;
     SirenArgs a{packed, residual_l0, acc, iy, ix, nullptr, nullptr, times, frames, B * N, N, B, H, W, HH, WW};
-    return motif_siren_split_launch(MODE_SYNTHC, a, stream);
+    return motif_siren_split_launch(MODE_SYNTHC, a, stream, pre == 3 ? 2 : 3);
 }
 
 // parity aid: the 198-channel synth input, materialised (never used on the product path)

@@ -98,4 +98,4 @@ template <> struct Net<MODE_SYNTHC> { static constexpr int K0 = 198, NH = 4, HEA
 
 
 // siren_split.hip: same networks on the bf16 matrix cores (blob from motif_siren_pack_split, LR partial required)
-int motif_siren_split_launch(int mode, const SirenArgs& a, void* stream);
+int motif_siren_split_launch(int mode, const SirenArgs& a, void* stream, int parts = 3);    // parts 2: blob of two fp16 parts (mode + 8 at pack time)

@@ -17,9 +17,32 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
 namespace {
-constexpr int PW[6] = {2, 0, 1, 1, 0, 0};      // (weight part, activation part) of the six products, small terms first
-constexpr int PX[6] = {0, 2, 1, 0, 1, 0};
+// (weight part, activation part) of the products, small terms first.  NP = 3: three bf16 parts per operand, six products.
+// NP = 2 (round 4): two fp16 parts per operand (hi = rne(x), lo = rne(x - hi): 22+ significant bits while both parts are normal
+// numbers), three products -- half the matrix instructions.  The operands suit fp16: every hidden activation is a sine, the
+// first layers' extra inputs are coordinates / t / normalised sums of O(1); the weights (x 30 / 2 pi, magnitude 0.02 .. 0.1) are
+// packed times 2^8 so that their low parts are normal fp16 numbers too, every accumulator then holds 2^8 x its sum (exact) and
+// the sine (or the store of imnet's linear head) multiplies by 2^-8.
+template <int NP> struct SProd;
+template <> struct SProd<3> {
+    static constexpr int n = 6;
+    static constexpr int w[6] = {2, 0, 1, 1, 0, 0};
+    static constexpr int x[6] = {0, 2, 1, 0, 1, 0};
+};
+template <> struct SProd<2> {
+    static constexpr int n = 3;
+    static constexpr int w[3] = {1, 0, 0};
+    static constexpr int x[3] = {0, 1, 0};
+};
+template <int NP> constexpr bool last_use_w(int k) {      // product k is the last of a k-step to read its weight part
+    for (int j = k + 1; j < SProd<NP>::n; ++j) if (SProd<NP>::w[j] == SProd<NP>::w[k]) return false;
+    return true;
+}
+template <int NP> constexpr float kSirenScale = NP == 2 ? 256.f : 1.f;
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     bf16x2 p = {(__bf16)a, (__bf16)b};
@@ -28,17 +51,38 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
 __device__ __forceinline__ float bf_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float bf_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
 
-__device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[3]) {
+__device__ __forceinline__ unsigned pk_f16(float a, float b) { const f16x2v h = {(_Float16)a, (_Float16)b}; return __builtin_bit_cast(unsigned, h); }
+// x - (float)half of a packed pair as ONE mixed-precision FMA (half * -1.0 + x; the product by -1 is exact)
+__device__ __forceinline__ float sub_f16_lo(float x, unsigned pk) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x)); return r; }
+__device__ __forceinline__ float sub_f16_hi(float x, unsigned pk) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x)); return r; }
+
+// one value pair -> its NP packed parts
+template <int NP>
+__device__ __forceinline__ void split_pair(float x0, float x1, u32x4 (&out)[NP], int q) {
+    if constexpr (NP == 2) {
+        const unsigned hi = pk_f16(x0, x1);
+        out[0][q] = hi;
+        out[1][q] = pk_f16(sub_f16_lo(x0, hi), sub_f16_hi(x1, hi));
+    } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float x0 = v[2 * q], x1 = v[2 * q + 1];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const unsigned pk = pk_bf16(x0, x1);
             out[p][q] = pk;
-            if (p < 2) { x0 -= bf_lo(pk); x1 -= bf_hi(pk); }
+            if (p + 1 < NP) { x0 -= bf_lo(pk); x1 -= bf_hi(pk); }
         }
     }
+}
+
+template <int NP>
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[NP]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split_pair<NP>(v[2 * q], v[2 * q + 1], out, q);
+}
+
+template <int NP>
+__device__ __forceinline__ f32x16 mfma16(u32x4 w, u32x4 x, f32x16 c) {
+    if constexpr (NP == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
 }
 
 // The sine layers compute sin(30 * (W h + b)) (SIREN.py:44-45, omega_0 = 30).  Here every layer that feeds a sine is packed with its
@@ -48,18 +92,22 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[3]) {
 // is the error of the argument in both forms; what is dropped is only the reference's extra rounding of 30 * (W h + b).  Measured
 // against the oracle in tests/test_kernels_gpu.py (same tolerances as before) and end to end in bench.py's parity block.
 #define SIREN_TURNS 4.774648292756860                         // 30 / (2 pi)
-__device__ __forceinline__ float sin_turns(float t) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t)); }
+template <int NP>
+__device__ __forceinline__ float sin_turns(float t) {
+    if constexpr (NP == 2) t *= 1.f / kSirenScale<2>;     // the accumulators of the two-part form carry 2^8 x the argument
+    return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t));
+}
 
-template <int MODE> struct SLayout {
+template <int MODE, int NP> struct SLayout {
     static constexpr bool SYN = MODE >= MODE_SYNTH;       // both synth forms: five linear layers, first layer streamed
     static constexpr int KS0 = (MODE == MODE_SYNTH) ? 9 : 1;
-    // fragment section, in u32x4 (16-byte) units: layer = [KS][3 parts][MT][64 lanes]
+    // fragment section, in u32x4 (16-byte) units: layer = [KS][NP parts][MT][64 lanes]
     static constexpr long F_W0 = 0;
-    static constexpr long F_W1 = F_W0 + (long)KS0 * 3 * 2 * 64;
-    static constexpr long F_W1B = F_W1 + 4L * 3 * 2 * 64;
-    static constexpr long F_W2 = F_W1B + (SYN ? 4L * 3 * 2 * 64 : 0);
-    static constexpr long F_W3 = F_W2 + 4L * 3 * 8 * 64;
-    static constexpr long F_END = F_W3 + (MODE == MODE_IMNET ? 16L * 3 * 2 * 64 : 0);
+    static constexpr long F_W1 = F_W0 + (long)KS0 * NP * 2 * 64;
+    static constexpr long F_W1B = F_W1 + 4L * NP * 2 * 64;
+    static constexpr long F_W2 = F_W1B + (SYN ? 4L * NP * 2 * 64 : 0);
+    static constexpr long F_W3 = F_W2 + 4L * NP * 8 * 64;
+    static constexpr long F_END = F_W3 + (MODE == MODE_IMNET ? 16L * NP * 2 * 64 : 0);
     // float section (after the fragments): B1, [B1b], B2, then B3 (imnet) or the fp32 VALU head Wv[3][32][2][4] + bias[4]
     static constexpr int O_B1 = 0;
     static constexpr int O_B1B = 64;
@@ -86,59 +134,58 @@ __device__ __forceinline__ void init_bias_s(f32x16 (&acc)[TP][MT], const float* 
 }
 
 // weight fragments of one k-step for MT output tiles: wk[(part * MTW + t0 + t) * 64]
-template <int MT, int MTW>
-__device__ __forceinline__ void load_w(u32x4 (&w)[MT][3], const u32x4* wk, int t0) {
+template <int MT, int MTW, int NP>
+__device__ __forceinline__ void load_w(u32x4 (&w)[MT][NP], const u32x4* wk, int t0) {
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int part = 0; part < 3; ++part) w[t][part] = wk[(part * MTW + t0 + t) * 64];
+        for (int part = 0; part < NP; ++part) w[t][part] = wk[(part * MTW + t0 + t) * 64];
 }
 
 // one k-step.  Products outermost so that consecutive MFMAs go to different accumulators.
-template <int MT, int TP>
-__device__ __forceinline__ void mfma_step(const u32x4 (&w)[MT][3], const u32x4 (&x)[TP][3], f32x16 (&acc)[TP][MT]) {
+template <int MT, int TP, int NP>
+__device__ __forceinline__ void mfma_step(const u32x4 (&w)[MT][NP], const u32x4 (&x)[TP][NP], f32x16 (&acc)[TP][MT]) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k)
+    for (int k = 0; k < SProd<NP>::n; ++k)
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int p = 0; p < TP; ++p)
-                acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t][PW[k]]),
-                                                                     __builtin_bit_cast(bf16x8, x[p][PX[k]]), acc[p][t], 0, 0, 0);
+                acc[p][t] = mfma16<NP>(w[t][SProd<NP>::w[k]], x[p][SProd<NP>::x[k]], acc[p][t]);
 }
 
-template <int MT, int MTW, int TP>
-__device__ __forceinline__ void split_step(const u32x4 (&x)[TP][3], f32x16 (&acc)[TP][MT], const u32x4* wk, int t0) {
-    u32x4 w[MT][3];
-    load_w<MT, MTW>(w, wk, t0);
-    mfma_step<MT, TP>(w, x, acc);
+template <int MT, int MTW, int TP, int NP>
+__device__ __forceinline__ void split_step(const u32x4 (&x)[TP][NP], f32x16 (&acc)[TP][MT], const u32x4* wk, int t0) {
+    u32x4 w[MT][NP];
+    load_w<MT, MTW, NP>(w, wk, t0);
+    mfma_step<MT, TP, NP>(w, x, acc);
 }
 
 // KS k-steps; `wfirst` holds the fragments of k-step 0 (requested by the caller before the preceding sine stretch),
 // the fragments of k-step ks+1 are requested before the MFMAs of k-step ks
-template <int KS, int MT, int MTW, int TP>
-__device__ __forceinline__ void split_layer(const u32x4 (&h)[TP][KS][3], f32x16 (&acc)[TP][MT], const u32x4* wp, int t0,
-                                            const u32x4 (&wfirst)[MT][3]) {
-    u32x4 w[2][MT][3];
+template <int KS, int MT, int MTW, int TP, int NP>
+__device__ __forceinline__ void split_layer(const u32x4 (&h)[TP][KS][NP], f32x16 (&acc)[TP][MT], const u32x4* wp, int t0,
+                                            const u32x4 (&wfirst)[MT][NP]) {
+    u32x4 w[2][MT][NP];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int part = 0; part < 3; ++part) w[0][t][part] = wfirst[t][part];
+        for (int part = 0; part < NP; ++part) w[0][t][part] = wfirst[t][part];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) load_w<MT, MTW>(w[(ks + 1) & 1], wp + (long)(ks + 1) * 3 * MTW * 64, t0);
-        u32x4 hx[TP][3];
+        if (ks + 1 < KS) load_w<MT, MTW, NP>(w[(ks + 1) & 1], wp + (long)(ks + 1) * NP * MTW * 64, t0);
+        u32x4 hx[TP][NP];
 #pragma unroll
         for (int p = 0; p < TP; ++p)
 #pragma unroll
-            for (int part = 0; part < 3; ++part) hx[p][part] = h[p][ks][part];
-        mfma_step<MT, TP>(w[ks & 1], hx, acc);
+            for (int part = 0; part < NP; ++part) hx[p][part] = h[p][ks][part];
+        mfma_step<MT, TP, NP>(w[ks & 1], hx, acc);
     }
 }
 
 // h[p][2t+u] = split(sin(2 pi * acc[p][t][8u .. 8u+7]))   (accumulators are in turns)
-template <int TP, int MT>
-__device__ __forceinline__ void sine_split(const f32x16 (&acc)[TP][MT], u32x4 (&h)[TP][2 * MT][3]) {
+template <int TP, int MT, int NP>
+__device__ __forceinline__ void sine_split(const f32x16 (&acc)[TP][MT], u32x4 (&h)[TP][2 * MT][NP]) {
 #pragma unroll
     for (int p = 0; p < TP; ++p)
 #pragma unroll
@@ -147,15 +194,15 @@ __device__ __forceinline__ void sine_split(const f32x16 (&acc)[TP][MT], u32x4 (&
             for (int u = 0; u < 2; ++u) {
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = sin_turns(acc[p][t][8 * u + e]);
-                split8(v, h[p][2 * t + u]);
+                for (int e = 0; e < 8; ++e) v[e] = sin_turns<NP>(acc[p][t][8 * u + e]);
+                split8<NP>(v, h[p][2 * t + u]);
                 __builtin_amdgcn_sched_barrier(0);
             }
 }
 
 #ifdef MOTIF_SIREN_DBG
-template <int TP, int MT>
-__device__ __forceinline__ void fake_split(const f32x16 (&acc)[TP][MT], u32x4 (&h)[TP][2 * MT][3]) {
+template <int TP, int MT, int NP>
+__device__ __forceinline__ void fake_split(const f32x16 (&acc)[TP][MT], u32x4 (&h)[TP][2 * MT][NP]) {
 #pragma unroll
     for (int p = 0; p < TP; ++p)
 #pragma unroll
@@ -163,7 +210,7 @@ __device__ __forceinline__ void fake_split(const f32x16 (&acc)[TP][MT], u32x4 (&
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int part = 0; part < 3; ++part)
+                for (int part = 0; part < NP; ++part)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) h[p][2 * t + u][part][q] = __builtin_bit_cast(unsigned, acc[p][t][8 * u + 2 * q + (part & 1)]);
 }
@@ -178,7 +225,7 @@ __device__ __forceinline__ void fake_f32(const f32x16 (&acc)[TP][MT], float (&h)
 }
 #endif
 
-template <int TP, int MT>
+template <int TP, int MT, int NP>
 __device__ __forceinline__ void sine_f32(const f32x16 (&acc)[TP][MT], float (&h)[TP][MT * 16]) {
 #pragma unroll
     for (int p = 0; p < TP; ++p)
@@ -186,67 +233,66 @@ __device__ __forceinline__ void sine_f32(const f32x16 (&acc)[TP][MT], float (&h)
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                h[p][t * 16 + r] = sin_turns(acc[p][t][r]);
+                h[p][t * 16 + r] = sin_turns<NP>(acc[p][t][r]);
             }
 }
 
 // One sine/split unit of k-step ks of the layer input `src` (pre-activations): units 0..7 = one sine each,
-// units 8..11 = split of one value pair into the three packed-bf16 parts.
-template <int TP>
-__device__ __forceinline__ void ss_unit(int u, const f32x16 (&src)[TP][2], int ks, float (&tmp)[TP][8], u32x4 (&hx)[TP][3]) {
+// units 8..11 = split of one value pair into its NP packed parts.
+template <int TP, int NP>
+__device__ __forceinline__ void ss_unit(int u, const f32x16 (&src)[TP][2], int ks, float (&tmp)[TP][8], u32x4 (&hx)[TP][NP]) {
     const int t = ks >> 1, uu = ks & 1;
 #pragma unroll
     for (int p = 0; p < TP; ++p) {
         if (u < 8) {
-            tmp[p][u] = sin_turns(src[p][t][8 * uu + u]);
+            tmp[p][u] = sin_turns<NP>(src[p][t][8 * uu + u]);
         } else {
             const int q = u - 8;
-            float x0 = tmp[p][2 * q], x1 = tmp[p][2 * q + 1];
-#pragma unroll
-            for (int part = 0; part < 3; ++part) {
-                const unsigned pk = pk_bf16(x0, x1);
-                hx[p][part][q] = pk;
-                if (part < 2) { x0 -= bf_lo(pk); x1 -= bf_hi(pk); }
-            }
+            split_pair<NP>(tmp[p][2 * q], tmp[p][2 * q + 1], hx[p], q);
         }
     }
 }
 
 // dst += W . sin(30 src) for a 64-wide input: the sine + split of k-step ks+1 (12 VALU units) is interleaved, unit by
-// unit, with the 12 MFMAs of k-step ks, so only the first k-step's vector work and the last k-step's MFMAs are exposed.
+// unit, with the MFMAs of k-step ks (12 with three parts: one unit each; 6 with two: two units each), so only the first k-step's
+// vector work and the last k-step's MFMAs are exposed.
 // One set of weight fragments, refilled in place after the last use of each part.  KEEP: also store the split input.
-template <int MTW, int TP, bool KEEP>
+template <int MTW, int TP, bool KEEP, int NP>
 __device__ __forceinline__ void fused_layer(const f32x16 (&src)[TP][2], f32x16 (&dst)[TP][2], const u32x4* wp, int t0,
-                                            u32x4 (&keep)[TP][4][3]) {
-    u32x4 hx[2][TP][3];
+                                            u32x4 (&keep)[TP][4][NP]) {
+    using SP = SProd<NP>;
+    constexpr int UPM = 12 / (2 * SP::n);                  // vector units per MFMA
+    u32x4 hx[2][TP][NP];
     float tmp[TP][8];
-    u32x4 w[2][3];
-    load_w<2, MTW>(w, wp, t0);
+    u32x4 w[2][NP];
+    load_w<2, MTW, NP>(w, wp, t0);
 #pragma unroll
-    for (int u = 0; u < 12; ++u) ss_unit<TP>(u, src, 0, tmp, hx[0]);
+    for (int u = 0; u < 12; ++u) ss_unit<TP, NP>(u, src, 0, tmp, hx[0]);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         if constexpr (KEEP) {
 #pragma unroll
             for (int p = 0; p < TP; ++p)
 #pragma unroll
-                for (int part = 0; part < 3; ++part) keep[p][ks][part] = hx[ks & 1][p][part];
+                for (int part = 0; part < NP; ++part) keep[p][ks][part] = hx[ks & 1][p][part];
         }
-        const u32x4* wnext = wp + (long)(ks + 1) * 3 * MTW * 64;
+        const u32x4* wnext = wp + (long)(ks + 1) * NP * MTW * 64;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < SP::n; ++k) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
 #pragma unroll
                 for (int p = 0; p < TP; ++p)
-                    dst[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t][PW[k]]),
-                                                                         __builtin_bit_cast(bf16x8, hx[ks & 1][p][PX[k]]), dst[p][t], 0, 0, 0);
-                if (ks < 3) ss_unit<TP>(2 * k + t, src, ks + 1, tmp, hx[(ks + 1) & 1]);
+                    dst[p][t] = mfma16<NP>(w[t][SP::w[k]], hx[ks & 1][p][SP::x[k]], dst[p][t]);
+                if (ks < 3) {
+#pragma unroll
+                    for (int j = 0; j < UPM; ++j) ss_unit<TP, NP>(UPM * (2 * k + t) + j, src, ks + 1, tmp, hx[(ks + 1) & 1]);
+                }
                 __builtin_amdgcn_sched_barrier(0x180);               // only DS instructions may cross
             }
-            if (ks < 3 && (k == 0 || k == 3 || k == 5)) {             // last use of part PW[k] in this k-step
+            if (ks < 3 && last_use_w<NP>(k)) {                        // last use of part w[k] in this k-step
 #pragma unroll
-                for (int t = 0; t < 2; ++t) w[t][PW[k]] = wnext[(PW[k] * MTW + t0 + t) * 64];
+                for (int t = 0; t < 2; ++t) w[t][SP::w[k]] = wnext[(SP::w[k] * MTW + t0 + t) * 64];
             }
         }
     }
@@ -261,14 +307,16 @@ extern "C" int motif_debug_siren_trace(long long* host, int n) { return (int)hip
 #define PH(i)
 #endif
 
-template <int MODE, int TP>
+template <int MODE, int TP, int NP>
 __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void siren_split_kernel(SirenArgs a) {
 #ifdef MOTIF_TRACE
     long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = __builtin_amdgcn_s_memtime();
 #endif
     extern __shared__ __attribute__((aligned(16))) u32x4 ldsv[];
-    using L = SLayout<MODE>;
+    using L = SLayout<MODE, NP>;
+    using SP = SProd<NP>;
+    constexpr float SCL = kSirenScale<NP>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
     const u32x4* gfr = (const u32x4*)a.packed;
     float* ldsf0 = (float*)(ldsv + (L::LDS_F1 - L::LDS_F0));
@@ -329,7 +377,7 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[p][t][r] = gp[(long)(32 * t + (r & 3) + 8 * (r >> 2)) * HWl] * (float)SIREN_TURNS;   // LR partial -> turns
+                for (int r = 0; r < 16; ++r) acc[p][t][r] = gp[(long)(32 * t + (r & 3) + 8 * (r >> 2)) * HWl] * (float)(SIREN_TURNS * SCL);   // LR partial -> turns (x 2^8 in the two-part form)
         }
     };
     const unsigned utotal = (unsigned)total, stride = gridDim.x * SIREN_WAVES;
@@ -358,22 +406,22 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
         if constexpr (L::SYN) gather(acc0, cur);    // synth: no spare registers to carry it across the tile
         if constexpr (MODE == MODE_IMNET || MODE == MODE_FLOW) {
             // natural K order: imnet k0 = rel_y, k1 = rel_x; flow k0 = t, k1 = rel_y, k2 = rel_x (lower half-wave)
-            u32x4 x[TP][3];
+            u32x4 x[TP][NP];
 #pragma unroll
             for (int p = 0; p < TP; ++p) {
                 float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if constexpr (MODE == MODE_FLOW) { v[0] = a.times[img % (a.B * a.N)]; v[1] = a.rel_y[Y[p]]; v[2] = a.rel_x[X[p]]; }
                 else { v[0] = a.rel_y[Y[p]]; v[1] = a.rel_x[X[p]]; }
                 if (hf) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; }
-                split8(v, x[p]);
+                split8<NP>(v, x[p]);
             }
-            split_step<2, 2, TP>(x, acc0, w0, 0);
+            split_step<2, 2, TP, NP>(x, acc0, w0, 0);
         } else if constexpr (MODE == MODE_SYNTHC) {
             // pre-contracted first layer (splat.hip, PRE form): the accumulator already holds W0[:, 0:130] . (splat sums), so
             // the pre-activation is  LR partial + sums / warped_z + W0[:, 130:133] . extra + W0[:, 197] t  -- 32 plane loads in
             // C/D order and ONE k-step (natural K order: 0 zmax, 1 cnt/16, 2 wz_/cnt_, 3 t) instead of nine.
             const float tval = a.times[img];
-            u32x4 x[TP][3];
+            u32x4 x[TP][NP];
 #pragma unroll
             for (int p = 0; p < TP; ++p) {
                 const float* A = a.acc + (long)img * 67 * Q + (cur.valid[p] ? cur.pp[p] : (int)Q - 1);
@@ -388,16 +436,16 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
                 if (wz == 0.f) wz = 1.0f;                                 // Ours.py:813
                 const float cnt_ = (cnt == 0.f) ? 1.0f : cnt;             // Ours.py:828
                 const float wz_ = (wz == 1.0f) ? 0.f : wz;                // Ours.py:830
-                const float iw = (1.0f / wz) * (float)SIREN_TURNS;          // the normalised sums enter the first layer's pre-activation: in turns
+                const float iw = (1.0f / wz) * (float)(SIREN_TURNS * SCL);          // the normalised sums enter the first layer's pre-activation: in turns
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc0[p][t][r] = fmaf(sv[t][r], iw, acc0[p][t][r]);
                 float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (!hf) { d[0] = zmax; d[1] = cnt / 16.0f; d[2] = wz_ / cnt_; d[3] = tval; }
-                split8(d, x[p]);
+                split8<NP>(d, x[p]);
             }
-            split_step<2, 2, TP>(x, acc0, w0, 0);
+            split_step<2, 2, TP, NP>(x, acc0, w0, 0);
         } else {
             // synth, natural K order: k < 130 sum/wz; 130 zmax; 131 cnt/16; 132 wz_/cnt_; 133 t; 134..143 zero
             const float tval = a.times[img];
@@ -431,22 +479,22 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
                         for (int e = 0; e < 8; ++e) vn[p][e] = ap[p][(long)e * Q];
                     }
                 }
-                u32x4 x[TP][3];
+                u32x4 x[TP][NP];
 #pragma unroll
                 for (int p = 0; p < TP; ++p) {
                     float d[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) d[e] = v[p][e] / wz[p];
-                    split8(d, x[p]);
+                    split8<NP>(d, x[p]);
                 }
-                split_step<2, 2, TP>(x, acc0, w0 + (long)ks * 3 * 2 * 64, 0);
+                split_step<2, 2, TP, NP>(x, acc0, w0 + (long)ks * NP * 2 * 64, 0);
 #pragma unroll
                 for (int p = 0; p < TP; ++p)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[p][e] = vn[p][e];
             }
             {
-                u32x4 x[TP][3];
+                u32x4 x[TP][NP];
 #pragma unroll
                 for (int p = 0; p < TP; ++p) {
                     float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -458,9 +506,9 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
                         d[4] = wz_[p] / cnt_[p];
                         d[5] = tval;
                     }
-                    split8(d, x[p]);
+                    split8<NP>(d, x[p]);
                 }
-                split_step<2, 2, TP>(x, acc0, w0 + 8L * 3 * 2 * 64, 0);
+                split_step<2, 2, TP, NP>(x, acc0, w0 + 8L * NP * 2 * 64, 0);
             }
         }
         PH(1);                                               // layer 0 (gather + MFMA issue)
@@ -473,10 +521,10 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
             // instructions fill the issue slots its MFMAs leave free.  The barriers pin MFMA/VALU order only; LDS
             // reads (weight fragments, head weights) may be hoisted across them.
             // 64 -> 64 (x2 for synth) -> first 64-wide chunk of 64 -> 256, each layer fused with the sine of its input
-            u32x4 h2[TP][4][3];
+            u32x4 h2[TP][4][NP];
             f32x16 acc1[TP][2];
             init_bias_s(acc1, ldsf + L::O_B1, hf);
-            fused_layer<2, TP, false>(acc0, acc1, lw1, 0, h2);
+            fused_layer<2, TP, false, NP>(acc0, acc1, lw1, 0, h2);
             if constexpr (!L::SYN) {
                 if (has_next) { locate(work + stride, nxt); gather(acc0, nxt); }
             }
@@ -484,13 +532,13 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
             f32x16 acc2[2][TP][2];
             if constexpr (L::SYN) {
                 init_bias_s(acc0, ldsf + L::O_B1B, hf);                   // acc0 is free: reuse as the 1b accumulator
-                fused_layer<2, TP, false>(acc1, acc0, lw1b, 0, h2);
+                fused_layer<2, TP, false, NP>(acc1, acc0, lw1b, 0, h2);
                 init_bias_s(acc2[0], ldsf + L::O_B2, hf);
-                fused_layer<8, TP, true>(acc0, acc2[0], lw2, 0, h2);
+                fused_layer<8, TP, true, NP>(acc0, acc2[0], lw2, 0, h2);
                 if (has_next) locate(work + stride, nxt);
             } else {
                 init_bias_s(acc2[0], ldsf + L::O_B2, hf);
-                fused_layer<8, TP, true>(acc1, acc2[0], lw2, 0, h2);
+                fused_layer<8, TP, true, NP>(acc1, acc2[0], lw2, 0, h2);
             }
             PH(5);                                           // 64->256 chunk 0 MFMAs
             const float* headw = ldsf + L::O_HEAD;
@@ -500,7 +548,7 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
                 auto valu_unit = [&](int u) {                // 32 sines, then 24 x (4 FMAs of one head output)
                     if (u < 32) {
 #pragma unroll
-                        for (int p = 0; p < TP; ++p) hc[p][u] = sin_turns(acc2[c & 1][p][u >> 4][u & 15]);
+                        for (int p = 0; p < TP; ++p) hc[p][u] = sin_turns<NP>(acc2[c & 1][p][u >> 4][u & 15]);
                     } else if (u < 56) {
                         const int q = (u - 32) / 3, o = (u - 32) % 3;
                         const f32x4 w4 = *(const f32x4*)(headw + ((o * 32 + 8 * c + q) * 2 + hf) * 4);
@@ -518,28 +566,28 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
                     f32x16 (&nxt)[TP][2] = acc2[(c + 1) & 1];
                     // one set of weight fragments, refilled in place: part PW[k] of the next k-step is requested right
                     // after its last use in this one (products are ordered so that parts retire 2, 1, 0)
-                    u32x4 w[2][3];
-                    load_w<2, 8>(w, lw2, 2 * c + 2);
+                    u32x4 w[2][NP];
+                    load_w<2, 8, NP>(w, lw2, 2 * c + 2);
                     init_bias_s(nxt, ldsf + L::O_B2 + (c + 1) * 64, hf);
+                    constexpr int UPM = 12 / (2 * SP::n);    // vector units per MFMA: 48 of the 56 under the chunk's MFMAs either way
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
-                        const u32x4* wnext = lw2 + (long)(ks + 1) * 3 * 8 * 64;
+                        const u32x4* wnext = lw2 + (long)(ks + 1) * NP * 8 * 64;
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) {
+                        for (int k = 0; k < SP::n; ++k) {
 #pragma unroll
                             for (int t = 0; t < 2; ++t) {
 #pragma unroll
                                 for (int p = 0; p < TP; ++p)
-                                    nxt[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                        __builtin_bit_cast(bf16x8, w[t][PW[k]]), __builtin_bit_cast(bf16x8, h2[p][ks][PX[k]]),
-                                        nxt[p][t], 0, 0, 0);
-                                valu_unit(unit++);
+                                    nxt[p][t] = mfma16<NP>(w[t][SP::w[k]], h2[p][ks][SP::x[k]], nxt[p][t]);
+#pragma unroll
+                                for (int j = 0; j < UPM; ++j) valu_unit(unit++);
                                 if ((unit & 3) == 0) __builtin_amdgcn_sched_barrier(0);      // bound the LDS-read hoisting
                                 else __builtin_amdgcn_sched_barrier(0x180);                   // only DS instructions may cross
                             }
-                            if (ks < 3 && (k == 0 || k == 3 || k == 5)) {      // last use of part PW[k]
+                            if (ks < 3 && last_use_w<NP>(k)) {      // last use of part w[k]
 #pragma unroll
-                                for (int t = 0; t < 2; ++t) w[t][PW[k]] = wnext[(PW[k] * 8 + 2 * c + 2 + t) * 64];
+                                for (int t = 0; t < 2; ++t) w[t][SP::w[k]] = wnext[(SP::w[k] * 8 + 2 * c + 2 + t) * 64];
                             }
                         }
                     }
@@ -573,9 +621,9 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
                 }
             }
         } else {
-            u32x4 wn[2][3];                                  // first fragments of the next layer, in flight during the sine
-            load_w<2, 2>(wn, lw1, 0);
-            u32x4 h1[TP][4][3];
+            u32x4 wn[2][NP];                                  // first fragments of the next layer, in flight during the sine
+            load_w<2, 2, NP>(wn, lw1, 0);
+            u32x4 h1[TP][4][NP];
             DBG_V(sine_split(acc0, h1), fake_split(acc0, h1));
             if (has_next) { locate(work + stride, nxt); gather(acc0, nxt); }
 
@@ -583,15 +631,15 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
             // ------------------------------------------------ 64 -> 64 (x2 for synth)
             f32x16 acc1[TP][2];
             init_bias_s(acc1, ldsf + L::O_B1, hf);
-            DBG_M((split_layer<4, 2, 2, TP>(h1, acc1, lw1, 0, wn)));
+            DBG_M((split_layer<4, 2, 2, TP, NP>(h1, acc1, lw1, 0, wn)));
             PH(3);                                               // layer 1 MFMAs
-            if constexpr (MODE == MODE_SYNTH) load_w<2, 2>(wn, lw1b, 0); else load_w<2, 8>(wn, lw2, 0);
-            u32x4 h2[TP][4][3];
+            if constexpr (MODE == MODE_SYNTH) load_w<2, 2, NP>(wn, lw1b, 0); else load_w<2, 8, NP>(wn, lw2, 0);
+            u32x4 h2[TP][4][NP];
             DBG_V(sine_split(acc1, h2), fake_split(acc1, h2));
             if constexpr (MODE == MODE_SYNTH) {
                 init_bias_s(acc1, ldsf + L::O_B1B, hf);
-                DBG_M((split_layer<4, 2, 2, TP>(h2, acc1, lw1b, 0, wn)));
-                load_w<2, 8>(wn, lw2, 0);
+                DBG_M((split_layer<4, 2, 2, TP, NP>(h2, acc1, lw1b, 0, wn)));
+                load_w<2, 8, NP>(wn, lw2, 0);
                 DBG_V(sine_split(acc1, h2), fake_split(acc1, h2));
             }
 
@@ -604,13 +652,13 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
             for (int c = 0; c < 4; ++c) {
                 f32x16 acc2[TP][2];
                 init_bias_s(acc2, ldsf + L::O_B2 + c * 64, hf);
-                split_layer<4, 2, 8, TP>(h2, acc2, lw2, 2 * c, wn);
-                u32x4 w3[2][3];
-                load_w<2, 2>(w3, w3g + (long)c * 4 * 3 * 2 * 64, 0);
-                u32x4 hc[TP][4][3];
+                split_layer<4, 2, 8, TP, NP>(h2, acc2, lw2, 2 * c, wn);
+                u32x4 w3[2][NP];
+                load_w<2, 2, NP>(w3, w3g + (long)c * 4 * NP * 2 * 64, 0);
+                u32x4 hc[TP][4][NP];
                 sine_split(acc2, hc);
-                if (c < 3) load_w<2, 8>(wn, lw2, 2 * c + 2);
-                split_layer<4, 2, 2, TP>(hc, acc3, w3g + (long)c * 4 * 3 * 2 * 64, 0, w3);
+                if (c < 3) load_w<2, 8, NP>(wn, lw2, 2 * c + 2);
+                split_layer<4, 2, 2, TP, NP>(hc, acc3, w3g + (long)c * 4 * NP * 2 * 64, 0, w3);
             }
 #pragma unroll
             for (int p = 0; p < TP; ++p) {
@@ -621,14 +669,14 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc3[p][t][r] = acc3[p][t][r] + gp[(long)(32 * t + (r & 3) + 8 * (r >> 2)) * HWl];
+                        for (int r = 0; r < 16; ++r) acc3[p][t][r] = acc3[p][t][r] * (1.f / SCL) + gp[(long)(32 * t + (r & 3) + 8 * (r >> 2)) * HWl];    // (x 1: exact)
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                        a.out[((long)img * 64 + m) * Q + cur.pp[p]] = acc3[p][t][r];
+                        a.out[((long)img * 64 + m) * Q + cur.pp[p]] = (NP == 2 && !a.add_lr) ? acc3[p][t][r] * (1.f / SCL) : acc3[p][t][r];
                     }
             }
         }
@@ -646,9 +694,10 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
 // parameters in network order.
 struct SplitPackArgs { const float* w[5]; const float* b[5]; int mode; };
 
-template <int MODE>
+template <int MODE, int NP>
 __device__ void siren_split_pack_elem(const SplitPackArgs& pa, unsigned short* frags, float* floats, long i) {
-    using L = SLayout<MODE>;
+    using L = SLayout<MODE, NP>;
+    constexpr double SCL = (double)kSirenScale<NP>;            // two-part form: fragments and accumulator biases times 2^8
     constexpr int K0 = Net<MODE>::K0;
     constexpr int NL = L::SYN ? 5 : 4;                              // linear layers incl. the head
     const long nfrag16 = L::F_END * 8;                              // bf16 elements in the fragment section
@@ -663,7 +712,7 @@ __device__ void siren_split_pack_elem(const SplitPackArgs& pa, unsigned short* f
         else if (f < L::F_W3 / 64) { layer = NL - 2; fb = L::F_W2 / 64; MT = 8; K = 64; M = 256; }
         else { layer = NL - 1; fb = L::F_W3 / 64; MT = 2; K = 256; M = 64; }
         const long fl = f - fb;
-        const int t = (int)(fl % MT), part = (int)((fl / MT) % 3), ks = (int)(fl / (3 * MT));
+        const int t = (int)(fl % MT), part = (int)((fl / MT) % NP), ks = (int)(fl / (NP * MT));
         const int hfl = lane >> 5, m = 32 * t + (lane & 31);
         int k;
         if (layer == 0) {
@@ -677,12 +726,22 @@ __device__ void siren_split_pack_elem(const SplitPackArgs& pa, unsigned short* f
             k = 32 * tt + (e & 3) + 8 * (2 * u + (e >> 2)) + 4 * hfl;
         }
         float v = (k >= 0 && k < K && m < M) ? pa.w[layer][(long)m * K + k] : 0.f;
-        if (!(MODE == MODE_IMNET && layer == NL - 1)) v = (float)((double)v * SIREN_TURNS);     // every fragment layer but imnet's linear head feeds a sine
+        double vd = (double)v * SCL;
+        if (!(MODE == MODE_IMNET && layer == NL - 1)) vd *= SIREN_TURNS;     // every fragment layer but imnet's linear head feeds a sine
         unsigned short out = 0;
-        for (int p = 0; p <= part; ++p) {
-            const unsigned pk = pk_bf16(v, 0.f);
-            out = (unsigned short)(pk & 0xffffu);
-            v -= bf_lo(pk);
+        if constexpr (NP == 2) {
+            for (int p = 0; p <= part; ++p) {
+                const _Float16 h = (_Float16)(float)vd;
+                out = __builtin_bit_cast(unsigned short, h);
+                vd -= (double)(float)h;
+            }
+        } else {
+            v = (float)vd;
+            for (int p = 0; p <= part; ++p) {
+                const unsigned pk = pk_bf16(v, 0.f);
+                out = (unsigned short)(pk & 0xffffu);
+                v -= bf_lo(pk);
+            }
         }
         frags[i] = out;
         return;
@@ -695,10 +754,10 @@ __device__ void siren_split_pack_elem(const SplitPackArgs& pa, unsigned short* f
         return m < M ? b[m] : 0.f;
     };
     float v;
-    if (j < L::O_B1B) v = (float)((double)bias_cd(pa.b[1], j - L::O_B1, 64) * SIREN_TURNS);
-    else if (j < L::O_B2) v = (float)((double)bias_cd(pa.b[2], j - L::O_B1B, 64) * SIREN_TURNS);
-    else if (j < L::O_HEAD) v = (float)((double)bias_cd(pa.b[NL - 2], j - L::O_B2, 256) * SIREN_TURNS);
-    else if (MODE == MODE_IMNET) v = bias_cd(pa.b[NL - 1], j - L::O_HEAD, 64);
+    if (j < L::O_B1B) v = (float)((double)bias_cd(pa.b[1], j - L::O_B1, 64) * SIREN_TURNS * SCL);
+    else if (j < L::O_B2) v = (float)((double)bias_cd(pa.b[2], j - L::O_B1B, 64) * SIREN_TURNS * SCL);
+    else if (j < L::O_HEAD) v = (float)((double)bias_cd(pa.b[NL - 2], j - L::O_B2, 256) * SIREN_TURNS * SCL);
+    else if (MODE == MODE_IMNET) v = (float)((double)bias_cd(pa.b[NL - 1], j - L::O_HEAD, 64) * SCL);
     else {
         const int jj = j - L::O_HEAD;
         if (jj < 3 * 32 * 8) {                                      // Wv[o][q][hf][r]: k = 8q + 4hf + r
@@ -712,44 +771,52 @@ __device__ void siren_split_pack_elem(const SplitPackArgs& pa, unsigned short* f
     floats[j] = v;
 }
 
+template <int NP>
 __global__ void siren_split_pack_kernel(SplitPackArgs pa, float* out, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    if (pa.mode == MODE_IMNET) siren_split_pack_elem<MODE_IMNET>(pa, (unsigned short*)out, out + SLayout<MODE_IMNET>::F_END * 4, i);
-    else if (pa.mode == MODE_FLOW) siren_split_pack_elem<MODE_FLOW>(pa, (unsigned short*)out, out + SLayout<MODE_FLOW>::F_END * 4, i);
-    else if (pa.mode == MODE_SYNTH) siren_split_pack_elem<MODE_SYNTH>(pa, (unsigned short*)out, out + SLayout<MODE_SYNTH>::F_END * 4, i);
-    else siren_split_pack_elem<MODE_SYNTHC>(pa, (unsigned short*)out, out + SLayout<MODE_SYNTHC>::F_END * 4, i);
+    if (pa.mode == MODE_IMNET) siren_split_pack_elem<MODE_IMNET, NP>(pa, (unsigned short*)out, out + SLayout<MODE_IMNET, NP>::F_END * 4, i);
+    else if (pa.mode == MODE_FLOW) siren_split_pack_elem<MODE_FLOW, NP>(pa, (unsigned short*)out, out + SLayout<MODE_FLOW, NP>::F_END * 4, i);
+    else if (pa.mode == MODE_SYNTH) siren_split_pack_elem<MODE_SYNTH, NP>(pa, (unsigned short*)out, out + SLayout<MODE_SYNTH, NP>::F_END * 4, i);
+    else siren_split_pack_elem<MODE_SYNTHC, NP>(pa, (unsigned short*)out, out + SLayout<MODE_SYNTHC, NP>::F_END * 4, i);
 }
 
-extern "C" long motif_siren_pack_split(int mode, const float* const* w, const float* const* b, float* packed, void* stream) {
-    if (mode < 0 || mode > 3) return MOTIF_EINVAL;
-    const long floats = mode == MODE_IMNET ? SLayout<MODE_IMNET>::TOTAL_FLOATS
-                      : mode == MODE_FLOW ? SLayout<MODE_FLOW>::TOTAL_FLOATS
-                      : mode == MODE_SYNTH ? SLayout<MODE_SYNTH>::TOTAL_FLOATS : SLayout<MODE_SYNTHC>::TOTAL_FLOATS;
+template <int NP>
+static long siren_pack_split_np(int mode, const float* const* w, const float* const* b, float* packed, void* stream) {
+    const long floats = mode == MODE_IMNET ? SLayout<MODE_IMNET, NP>::TOTAL_FLOATS
+                      : mode == MODE_FLOW ? SLayout<MODE_FLOW, NP>::TOTAL_FLOATS
+                      : mode == MODE_SYNTH ? SLayout<MODE_SYNTH, NP>::TOTAL_FLOATS : SLayout<MODE_SYNTHC, NP>::TOTAL_FLOATS;
     if (!packed) return floats;
     if (!w || !b) return MOTIF_EINVAL;
     const int nl = mode >= MODE_SYNTH ? 5 : 4;
     SplitPackArgs pa;
     for (int l = 0; l < 5; ++l) { pa.w[l] = l < nl ? w[l] : nullptr; pa.b[l] = l < nl ? b[l] : nullptr; }
     pa.mode = mode;
-    const long fend = mode == MODE_IMNET ? SLayout<MODE_IMNET>::F_END : mode == MODE_FLOW ? SLayout<MODE_FLOW>::F_END
-                    : mode == MODE_SYNTH ? SLayout<MODE_SYNTH>::F_END : SLayout<MODE_SYNTHC>::F_END;
+    const long fend = mode == MODE_IMNET ? SLayout<MODE_IMNET, NP>::F_END : mode == MODE_FLOW ? SLayout<MODE_FLOW, NP>::F_END
+                    : mode == MODE_SYNTH ? SLayout<MODE_SYNTH, NP>::F_END : SLayout<MODE_SYNTHC, NP>::F_END;
     const long nfl = floats - fend * 4;
-    const long total = fend * 8 + nfl;                              // one thread per bf16 element, then per float
-    siren_split_pack_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(pa, packed, total);
+    const long total = fend * 8 + nfl;                              // one thread per 16-bit element, then per float
+    siren_split_pack_kernel<NP><<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(pa, packed, total);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(long)e - 1000;
     return floats;
 }
 
-template <int MODE, int TP>
+// mode: network kind 0 .. 3, + 8 for the two-part fp16 form (forward calls: pre = 3 instead of 2)
+extern "C" long motif_siren_pack_split(int mode, const float* const* w, const float* const* b, float* packed, void* stream) {
+    const int kind = mode & 7, two = mode >> 3;
+    if (mode < 0 || kind > 3 || two > 1) return MOTIF_EINVAL;
+    return two ? siren_pack_split_np<2>(kind, w, b, packed, stream) : siren_pack_split_np<3>(kind, w, b, packed, stream);
+}
+
+template <int MODE, int TP, int NP>
 static int launch_siren_split(const SirenArgs& a_in, void* stream) {
-    using L = SLayout<MODE>;
+    using L = SLayout<MODE, NP>;
     static_assert(L::LDS_BYTES <= 160 * 1024, "resident part of the packed network must fit the 160 KB LDS");
     SirenArgs a = a_in;
     a.stagger = 4;
     if (const int sv = motif_opt(MOTIF_OPT_SIREN_STAGGER)) a.stagger = sv < 0 ? 0 : sv;
-    hipError_t e = hipFuncSetAttribute((const void*)siren_split_kernel<MODE, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)siren_split_kernel<MODE, TP, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -757,14 +824,21 @@ static int launch_siren_split(const SirenArgs& a_in, void* stream) {
     const long tiles = (long)a.NB * ((Q + 32 * TP - 1) / (32 * TP));
     long blocks = (tiles + SIREN_WAVES - 1) / SIREN_WAVES;
     if (blocks > cus) blocks = cus;
-    siren_split_kernel<MODE, TP><<<(int)blocks, SIREN_THREADS, (size_t)L::LDS_BYTES, (hipStream_t)stream>>>(a);
+    siren_split_kernel<MODE, TP, NP><<<(int)blocks, SIREN_THREADS, (size_t)L::LDS_BYTES, (hipStream_t)stream>>>(a);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }
 
-int motif_siren_split_launch(int mode, const SirenArgs& a, void* stream) {
-    if (mode == MODE_IMNET) return launch_siren_split<MODE_IMNET, 1>(a, stream);
-    if (mode == MODE_FLOW) return launch_siren_split<MODE_FLOW, 1>(a, stream);
-    if (mode == MODE_SYNTHC) return launch_siren_split<MODE_SYNTHC, 1>(a, stream);
-    return launch_siren_split<MODE_SYNTH, 1>(a, stream);
+// parts: 3 = blob of three bf16 parts (pre = 2), 2 = blob of two fp16 parts (pre = 3)
+int motif_siren_split_launch(int mode, const SirenArgs& a, void* stream, int parts) {
+    if (parts == 2) {
+        if (mode == MODE_IMNET) return launch_siren_split<MODE_IMNET, 1, 2>(a, stream);
+        if (mode == MODE_FLOW) return launch_siren_split<MODE_FLOW, 1, 2>(a, stream);
+        if (mode == MODE_SYNTHC) return launch_siren_split<MODE_SYNTHC, 1, 2>(a, stream);
+        return launch_siren_split<MODE_SYNTH, 1, 2>(a, stream);
+    }
+    if (mode == MODE_IMNET) return launch_siren_split<MODE_IMNET, 1, 3>(a, stream);
+    if (mode == MODE_FLOW) return launch_siren_split<MODE_FLOW, 1, 3>(a, stream);
+    if (mode == MODE_SYNTHC) return launch_siren_split<MODE_SYNTHC, 1, 3>(a, stream);
+    return launch_siren_split<MODE_SYNTH, 1, 3>(a, stream);
 }

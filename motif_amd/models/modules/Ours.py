@@ -437,7 +437,7 @@ class LunaTokis(nn.Module):
         return c["feat"][:, 1]                                                  # Ours.py:609
 
     def _pc(self):
-        return self.precontract and ops.get_siren_mma() == ops.MMA_BF16X3
+        return self.precontract and ops.siren_is_split()
 
     def _pre_plan(self):
         """Weights of the pre-contracted form, rebuilt when a parameter they derive from changes: with W0 = synth_net's
@@ -449,7 +449,7 @@ class LunaTokis(nn.Module):
           synth_blob  synth_net packed for motif_siren_synth_pre_fwd (first layer = the 3 extra columns + t)."""
         w0 = self.synth_net.net[0].linear.weight
         wh, bh = self.imnet.net[3].weight, self.imnet.net[3].bias
-        key = (self._weights_epoch,) + tuple((t.data_ptr(), t._version) for t in [w0, wh, bh] + [t for wb in self.imnet.linears() + self.synth_net.linears() for t in wb])
+        key = (self._weights_epoch, ops.get_siren_mma()) + tuple((t.data_ptr(), t._version) for t in [w0, wh, bh] + [t for wb in self.imnet.linears() + self.synth_net.linears() for t in wb])
         if getattr(self, "_pre_key", None) != key:
             W0 = w0.detach().double()
             whc = (W0[:, :64] @ wh.detach().double()).float().contiguous()
@@ -465,7 +465,7 @@ class LunaTokis(nn.Module):
     def _imnet_hr(self, c, iy, ix, rel_y, rel_x, HH, WW):
         """imnet over the HR grid described by the tables (whole image or a row band); in the pre-contracted form its head
         already carries W0[:, 0:64]."""
-        split = ops.get_siren_mma() == ops.MMA_BF16X3
+        split = ops.siren_is_split()
         add_lr = None
         if self._pc():
             # U + G: the imnet kernel adds the gathered LR term of the splat sources (W0[:, 66:130] . feature) when it stores U, so
@@ -473,7 +473,7 @@ class LunaTokis(nn.Module):
             blob, add_lr = self._pre_plan()["imnet_blob"], c["g_lr"]
         else:
             blob = self.imnet.packed_split(ops.SIREN_IMNET) if split else self.imnet.packed()
-        return ops.siren_imnet(blob, ops.conv2d(self.imnet.l0_plan(0, 64), c["feat01"]), iy, ix, rel_y, rel_x, HH, WW, pre=2 if split else 1,
+        return ops.siren_imnet(blob, ops.conv2d(self.imnet.l0_plan(0, 64), c["feat01"]), iy, ix, rel_y, rel_x, HH, WW, pre=ops.siren_pre(),
                                add_lr=add_lr)
 
     def _splat_synth(self, c, imnet_out, pred, sl, iy, ix, times, B, N, H, HH, WW, synth_blob, synth_l0, pre, acc, accumulate, row0=0, finish=True):
@@ -626,10 +626,10 @@ class LunaTokis(nn.Module):
         c = self._cache
         iy, ix, rel_y, rel_x = c["tables"]
         times = target_t.contiguous()                                           # [B,N]
-        split = ops.get_siren_mma() == ops.MMA_BF16X3
+        split = ops.siren_is_split()
         flow_blob = self.flow_imnet.packed_split(ops.SIREN_FLOW) if split else self.flow_imnet.packed()
         synth_blob = self.synth_net.packed_split(ops.SIREN_SYNTH) if split else self.synth_net.packed()
-        pre = 2 if split else 1
+        pre = ops.siren_pre()
         if self.band is not None:
             return self._forward_band(c, times, B, N, H, HH, WW, flow_blob, synth_blob, pre, stages)
         # source directions two at a time (the kernels take a direction pair); further pairs add into the accumulator

@@ -61,8 +61,8 @@ class Siren(nn.Module):
         return self._l0_plan
 
     def packed_split(self, kind):
-        """Blob for the bf16-split kernels (ops.siren_*(..., pre=2)); kind = ops.SIREN_IMNET / _FLOW / _SYNTH."""
-        key = (kind,) + tuple((w.data_ptr(), w._version, b._version, str(w.device)) for w, b in self.linears())
+        """Blob for the split kernels (ops.siren_*(..., pre=ops.siren_pre())); kind = ops.SIREN_IMNET / _FLOW / _SYNTH."""
+        key = (kind, ops.siren_pre()) + tuple((w.data_ptr(), w._version, b._version, str(w.device)) for w, b in self.linears())
         if key != getattr(self, "_skey", None):
             self._sblob, self._skey = ops.siren_pack_split(kind, self.linears()), key
         return self._sblob

@@ -342,7 +342,7 @@ def siren_pack(linears):
 
 
 SIREN_IMNET, SIREN_FLOW, SIREN_SYNTH, SIREN_SYNTH_PRE = 0, 1, 2, 3
-_siren_mma = int(os.environ.get("MOTIF_SIREN_MMA", str(MMA_BF16X3 if _default_mma != MMA_FP32 else MMA_FP32)))
+_siren_mma = int(os.environ.get("MOTIF_SIREN_MMA", str(MMA_FP32 if _default_mma == MMA_FP32 else MMA_F16X2 if _default_mma == MMA_F16X2 else MMA_BF16X3)))
 
 
 def set_mma(name):
@@ -352,7 +352,7 @@ def set_mma(name):
     reduced precision, the MLPs stay bf16x3)."""
     mode = _MMA_NAMES[name]
     set_conv_mma(mode)
-    set_siren_mma(MMA_FP32 if mode == MMA_FP32 else MMA_BF16X3)
+    set_siren_mma(MMA_FP32 if mode == MMA_FP32 else MMA_F16X2 if mode == MMA_F16X2 else MMA_BF16X3)
 
 
 def get_mma():
@@ -360,10 +360,11 @@ def get_mma():
 
 
 def set_siren_mma(mode):
-    """0: fp32-MFMA SIREN kernels; 6: 3-way bf16 split on the bf16 matrix cores (needs the LR partial, `pre`)."""
+    """0: fp32-MFMA SIREN kernels; 6: 3-way bf16 split on the bf16 matrix cores (needs the LR partial, `pre`); 7: 2-way fp16
+    split (three products instead of six) in the same kernels."""
     global _siren_mma
-    if mode not in (MMA_FP32, MMA_BF16X3):
-        raise ValueError("siren mma mode must be 0 or 6")
+    if mode not in (MMA_FP32, MMA_BF16X3, MMA_F16X2):
+        raise ValueError("siren mma mode must be 0, 6 or 7")
     _siren_mma = mode
 
 
@@ -371,10 +372,24 @@ def get_siren_mma():
     return _siren_mma
 
 
-def siren_pack_split(kind, linears):
+def siren_is_split():
+    """The MLPs run on the 16-bit matrix cores (blobs from siren_pack_split)."""
+    return _siren_mma in (MMA_BF16X3, MMA_F16X2)
+
+
+def siren_pre():
+    """`pre` argument of the SIREN forward calls for the selected arithmetic: 3 = two fp16 parts, 2 = three bf16 parts (blobs from
+    siren_pack_split), 1 = fp32 MFMA on the LR partial (blob from siren_pack)."""
+    return 3 if _siren_mma == MMA_F16X2 else 2 if _siren_mma == MMA_BF16X3 else 1
+
+
+def siren_pack_split(kind, linears, pre=None):
     """Packed blob of one of the three MoTIF MLPs (kind = SIREN_IMNET / _FLOW / _SYNTH) for the split kernels; pass it
-    with pre=2."""
+    with the same `pre` (2: three bf16 parts, 3: two fp16 parts; default: siren_pre() of the selected arithmetic)."""
     lib = _lib.load()
+    pre = siren_pre() if pre is None else pre
+    if pre not in (2, 3):
+        raise RuntimeError("siren_pack_split: pre must be 2 or 3 (selected arithmetic: %d)" % _siren_mma)
     n = len(linears)
     ws = [_c(w.detach()) for w, _ in linears]
     bs = [_c(b.detach()) for _, b in linears]
@@ -384,6 +399,7 @@ def siren_pack_split(kind, linears):
         raise RuntimeError("siren_pack_split: layer sizes do not match kind %d" % kind)
     wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
     bp = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bs])
+    kind = kind + (8 if pre == 3 else 0)
     total = lib.motif_siren_pack_split(kind, wp, bp, None, None)
     if total <= 0:
         raise RuntimeError("motif_siren_pack_split size query failed (%d)" % total)
@@ -434,14 +450,15 @@ def siren_synth(blob, acc, residual_lr, iy, ix, times, B, N, HH, WW, pre=False):
     return frames
 
 
-def siren_synth_pre(blob, acc67, residual_l0, iy, ix, times, B, N, HH, WW):
-    """synth_net on the pre-contracted accumulator of splat_motif_pre (blob: siren_pack_split(SIREN_SYNTH_PRE, ...))."""
+def siren_synth_pre(blob, acc67, residual_l0, iy, ix, times, B, N, HH, WW, pre=None):
+    """synth_net on the pre-contracted accumulator of splat_motif_pre (blob: siren_pack_split(SIREN_SYNTH_PRE, ...), same `pre`)."""
     lib = _lib.load()
+    pre = siren_pre() if pre is None else pre
     residual_l0 = _c(residual_l0)
     _, _, h, w = residual_l0.shape
     frames = torch.empty(N, B, 3, HH, WW, dtype=torch.float32, device=acc67.device)
     check(lib.motif_siren_synth_pre_fwd(_p(blob), _p(acc67), _p(residual_l0), _p(iy), _p(ix), _p(_c(times)), _p(frames),
-                                        B, N, h, w, HH, WW, _stream()), "motif_siren_synth_pre_fwd")
+                                        B, N, h, w, HH, WW, int(pre), _stream()), "motif_siren_synth_pre_fwd")
     return frames
 
 

@@ -449,7 +449,7 @@ def test_arithmetic_mode_option_plumbing():
     try:
         assert before in ("f16x2", "bf16x3", "fp32", "bf16x2", "bf16")
         networks.define_G(option.default_opt(mma="f16x2"))
-        assert ops.get_conv_mma() == ops.MMA_F16X2 and ops.get_siren_mma() == ops.MMA_BF16X3
+        assert ops.get_conv_mma() == ops.MMA_F16X2 and ops.get_siren_mma() == ops.MMA_F16X2 and ops.siren_pre() == 3
         networks.define_G(option.default_opt(mma="fp32"))
         assert ops.get_mma() == "fp32" and ops.get_conv_mma() == ops.MMA_FP32 and ops.get_siren_mma() == ops.MMA_FP32
         networks.define_G(option.default_opt(mma="bf16"))

@@ -680,15 +680,18 @@ def test_siren_kernels_vs_torch(HW):
     close(o, r, 5e-6, 1e-4, "imnet")
     l0 = ops.conv2d(mine.imnet.l0_plan(0, 64), feat.to(dev()))          # LR partial of layer 0, then pre=1
     close(ops.siren_imnet(mine.imnet.packed(), l0, iy, ix, rel_y, rel_x, HH, WW, pre=True), r, 5e-6, 1e-4, "imnet pre")
-    osp = ops.siren_imnet(mine.imnet.packed_split(ops.SIREN_IMNET), l0, iy, ix, rel_y, rel_x, HH, WW, pre=2)
-    close(osp, r, 5e-6, 1e-4, "imnet split")
-    # motif_siren_imnet_add_fwd: + an LR tensor gathered through the same tables, one fp32 add after the head
+    SPLITS = ((2, "three bf16 parts"), (3, "two fp16 parts"))           # pre = 2 / 3: both forms of the split kernels, same tolerances
     g = rnd(*l0.shape, seed=77).to(dev())
-    h_, w_ = l0.shape[2], l0.shape[3]
-    idx = (iy.long()[:, None] * w_ + ix.long()[None, :]).reshape(-1)
-    want = osp + g.reshape(l0.shape[0], 64, h_ * w_)[:, :, idx].reshape(l0.shape[0], 64, HH, WW)
-    got = ops.siren_imnet(mine.imnet.packed_split(ops.SIREN_IMNET), l0, iy, ix, rel_y, rel_x, HH, WW, pre=2, add_lr=g)
-    assert torch.equal(got, want), "imnet + gathered LR term"
+    for pre, what in SPLITS:
+        blob = ops.siren_pack_split(ops.SIREN_IMNET, mine.imnet.linears(), pre=pre)
+        osp = ops.siren_imnet(blob, l0, iy, ix, rel_y, rel_x, HH, WW, pre=pre)
+        close(osp, r, 5e-6, 1e-4, "imnet split, " + what)
+        # motif_siren_imnet_add_fwd: + an LR tensor gathered through the same tables, one fp32 add after the head
+        h_, w_ = l0.shape[2], l0.shape[3]
+        idx = (iy.long()[:, None] * w_ + ix.long()[None, :]).reshape(-1)
+        want = osp + g.reshape(l0.shape[0], 64, h_ * w_)[:, :, idx].reshape(l0.shape[0], 64, HH, WW)
+        got = ops.siren_imnet(blob, l0, iy, ix, rel_y, rel_x, HH, WW, pre=pre, add_lr=g)
+        assert torch.equal(got, want), "imnet + gathered LR term, " + what
     with pytest.raises(RuntimeError):
         ops.siren_imnet(mine.imnet.packed(), l0, iy, ix, rel_y, rel_x, HH, WW, pre=True, add_lr=g)      # split engine only
     # flow_imnet
@@ -702,7 +705,9 @@ def test_siren_kernels_vs_torch(HW):
     close(o, r, 5e-6, 1e-4, "flow_imnet")
     l0 = ops.conv2d(mine.flow_imnet.l0_plan(0, 64), feat.to(dev()))
     close(ops.siren_flow(mine.flow_imnet.packed(), l0, iy, ix, rel_y, rel_x, times.to(dev()), N, HH, WW, pre=True), r, 5e-6, 1e-4, "flow pre")
-    close(ops.siren_flow(mine.flow_imnet.packed_split(ops.SIREN_FLOW), l0, iy, ix, rel_y, rel_x, times.to(dev()), N, HH, WW, pre=2), r, 5e-6, 1e-4, "flow split")
+    for pre, what in SPLITS:
+        blob = ops.siren_pack_split(ops.SIREN_FLOW, mine.flow_imnet.linears(), pre=pre)
+        close(ops.siren_flow(blob, l0, iy, ix, rel_y, rel_x, times.to(dev()), N, HH, WW, pre=pre), r, 5e-6, 1e-4, "flow split, " + what)
     # synth (with the normalisation prologue): build an accumulator with zeros / ones / exact-equality cases
     acc = rnd(B * N, 133, HH, WW, seed=5, scale=0.5)
     acc[:, 130] = acc[:, 130].abs() * 2 + 1e-3
@@ -731,7 +736,9 @@ def test_siren_kernels_vs_torch(HW):
     close(o, r, 2e-5, 1e-4, "synth")
     l0 = ops.conv2d(mine.synth_net.l0_plan(133, 197), res.to(dev()))
     close(ops.siren_synth(mine.synth_net.packed(), acc.to(dev()), l0, iy, ix, times.to(dev()), B, N, HH, WW, pre=True), r, 2e-5, 1e-4, "synth pre")
-    close(ops.siren_synth(mine.synth_net.packed_split(ops.SIREN_SYNTH), acc.to(dev()), l0, iy, ix, times.to(dev()), B, N, HH, WW, pre=2), r, 2e-5, 1e-4, "synth split")
+    for pre, what in SPLITS:
+        blob = ops.siren_pack_split(ops.SIREN_SYNTH, mine.synth_net.linears(), pre=pre)
+        close(ops.siren_synth(blob, acc.to(dev()), l0, iy, ix, times.to(dev()), B, N, HH, WW, pre=pre), r, 2e-5, 1e-4, "synth split, " + what)
 
 
 # ------------------------------------------------------------------------------------------- fused MoTIF splat
@@ -1041,9 +1048,10 @@ def test_precontracted_splat_and_synth_equal_the_literal_path():
     pre_ref = torch.einsum("ck,bkhw->bchw", w0[:, :130].double().cpu(), (ssum[:, :130] / wz).double()).float()
     close(acc[:, :64].cpu() / wz, pre_ref, 3e-5, 3e-5, "contracted first-layer sums")
     l0 = ops.conv2d(mine.synth_net.l0_plan(133, 197), res.to(dev()))
-    blob = ops.siren_pack_split(ops.SIREN_SYNTH_PRE, mine.synth_net.linears())
-    o = ops.siren_synth_pre(blob, acc, l0, iy, ix, times.to(dev()), B, N, HH, WW)
-    close(o, r, 2e-5, 1e-4, "synth on the pre-contracted accumulator")
+    for pre in (2, 3):                                                   # three bf16 parts / two fp16 parts
+        blob = ops.siren_pack_split(ops.SIREN_SYNTH_PRE, mine.synth_net.linears(), pre=pre)
+        o = ops.siren_synth_pre(blob, acc, l0, iy, ix, times.to(dev()), B, N, HH, WW, pre=pre)
+        close(o, r, 2e-5, 1e-4, "synth on the pre-contracted accumulator (pre = %d)" % pre)
     # fused-source form (what LunaTokis runs): U already holds U + G -- the same fp32 sum the kernel forms from g_lr -- and g_lr = None
     up = iy.long()[:, None] * W + ix.long()[None, :]
     ug = u_hr.to(dev()) + g_lr.reshape(2 * B, 64, H * W)[:, :, up.reshape(-1)].reshape(2 * B, 64, HH, WW)
