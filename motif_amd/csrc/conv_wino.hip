@@ -117,12 +117,19 @@ struct WSched {
             }
             for (int r = 0; r < 16; ++r) ext[f++] = (WP_READ << 8) | r;
         } else {
-            // parks in the odd slots 1 .. 19, requests in the even slot behind (the weight requests sit in odd slots); the read-back of
-            // row r (row piece quads 160 r .. 160 r + 159: pieces 0-2 | 2-4 | 5-7 | 7-9) in the even slots behind its last park
+            // parks in the odd slots 1 .. 19; the read-back of row r (row piece quads 160 r .. 160 r + 159: pieces 0-2 | 2-4 | 5-7 | 7-9)
+            // in the even slots behind its last park.  The row-piece requests are NOT right behind the parks here but two per
+            // super-step in even slots of super-steps 1 .. 5 (the weight requests sit in odd slots): a super-step is 384 MFMA cycles =
+            // 24 KB of the CU's 64 B/clk L1 path, and the four waves' weight fragments alone are 16 KB of it -- with five of the ten
+            // requests in super-step 0 and five in 1 those took 700 / 1050 cycles, spread they all take 540-650 (tools/trace_wino.py SS=1).
             for (int i = 0; i < NLD; ++i) {
                 ext[2 * i + 1] = (WP_PARK << 8) | i;
-                if (rl[2 * i + 2] >= 0 || ra[2 * i + 2] >= 0) clash = 1;
-                rl[2 * i + 2] = i;
+#ifndef WINO_RL2
+#define WINO_RL2 1        // experiments: 0 = right behind the park (the three-part form's rule), 2 / 3 = denser, later
+#endif
+                const int ls = WINO_RL2 == 1 ? 14 + 6 * i : WINO_RL2 == 2 ? 14 + 4 * i : WINO_RL2 == 3 ? 22 + 4 * i : 2 * i + 2;
+                if (rl[ls] >= 0 || ra[ls] >= 0) clash = 1;
+                rl[ls] = i;
             }
             constexpr int rslot[8] = {6, 8, 10, 12, 16, 18, 20, 21};
             for (int r = 0; r < 8; ++r) { if (ext[rslot[r]]) clash = 1; ext[rslot[r]] = (WP_READ2 << 8) | r; }

@@ -56,3 +56,12 @@ for k in range(3):
     if okc.any():
         d = t2[:, :, k, 1:7] - t2[:, :, k, 0:6]
         print("  tile %d: %s | total %6.0f" % (k, " ".join("%6.0f" % d[..., i][okc].mean() for i in range(6)), (t2[:, :, k, 6] - t2[:, :, k, 0])[okc].mean()))
+if os.environ.get("SS"):      # a -DMOTIF_TRACE_SS build: entries 3 .. 7 hold the per-super-step stamps of chunks 3 .. 7 of the workgroup
+    print("super-step durations (cycles) of chunks 3 .. 7: ss0 .. ss5")
+    for k in range(3, 8):
+        okc = (t2[:, :, k, 0] > 0) & (t2[:, :, k, 6] > 0)
+        if okc.any():
+            d = t2[:, :, k, 1:7] - t2[:, :, k, 0:6]
+            print("  chunk %d (chunk %d of its tile): %s | total %6.0f" % (k, k % nch, " ".join("%6.0f" % d[..., i][okc].mean() for i in range(6)), (t2[:, :, k, 6] - t2[:, :, k, 0])[okc].mean()))
+            if k == 5:
+                print("     per wave: " + " | ".join(" ".join("%5.0f" % d[:, w, i][okc[:, w]].mean() for i in range(6)) for w in range(4)))

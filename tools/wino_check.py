@@ -11,7 +11,7 @@ def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.rand(*shape, generator=g) * 2 - 1) * scale
 
-CASES = [(1, 64, 64, 16, 32), (2, 64, 64, 45, 80), (1, 128, 64, 23, 36), (1, 64, 216, 20, 36), (2, 81, 96, 12, 16), (3, 64, 64, 180, 320), (1, 48, 80, 19, 36)]
+CASES = [tuple(int(v) for v in c.split("x")) for c in os.environ["CASES"].split(",")] if os.environ.get("CASES") else [(1, 64, 64, 16, 32), (2, 64, 64, 45, 80), (1, 128, 64, 23, 36), (1, 64, 216, 20, 36), (2, 81, 96, 12, 16), (3, 64, 64, 180, 320), (1, 48, 80, 19, 36)]
 for n, cin, cout, H, W in CASES:
     m = Conv2d(cin, cout, 3, 1, 1)
     with torch.no_grad():
