@@ -1,5 +1,13 @@
 // 3x3 / stride 1 convolution with 1.5x fewer matrix instructions: Winograd F(2,3) along the image ROWS, direct along the
-// columns, fp32-equivalent 3-way bf16 split arithmetic (see conv_split.hip), on the bf16 matrix cores.  Round-4 kernel.
+// columns, fp32-equivalent split arithmetic on the 16-bit matrix cores.  Round-4 kernel, in two forms (template parameter NP):
+//   NP = 3  three bf16 parts per operand, six products (the arithmetic of conv_split.hip; MotifConvDesc.mma = 6);
+//   NP = 2  two fp16 parts per operand (hi = rne(x), lo = rne(x - hi): 22+ bits), THREE products (mma = 7, the default): half the matrix
+//           instructions again.  Why it pays twice: under a chip-wide MFMA load on real data the shader clock is 1.5-1.8 GHz, not 2.4
+//           (tools/ubench_clock.hip: the matrix cores are power-bound), so an MFMA not issued returns its cycles AND clock.  Range = fp16's:
+//           |V| (= up to 2 |activation|) or 2^8 |U| beyond 65504 give inf / NaN, never a clamped value; below 2^-14 a part is subnormal, i.e.
+//           carries an absolute error <= 2^-25.  The weights are packed times 2^8 (so that the low parts of everyday weights are normal
+//           numbers), the accumulators start at 2^8 bias, the epilogue multiplies by 2^-8 -- all exact.  Measured against fp64 the form's
+//           error is at or below the three-part one's (tools/wino_check.py, tests/test_kernels_gpu.py, tests/test_split_arith.py).
 //
 // For an output row pair (2T, 2T+1), input rows d0..d3 = 2T-1 .. 2T+2 and the kernel rows g0, g1, g2 (per column tap kx):
 //     V0 = d0 - d2     U0 = g0                    M_p = sum over (cin, kx) of U_p[kx] * V_p[x + kx]
@@ -25,7 +33,7 @@
 // one costs ~8 cycles, v_pk_add_f32 ~12 that do NOT overlap, a 1 KB load 64 cycles of the CU's L1 path (16 per wave), LDS stores 13):
 //   * the (tile, chunk) pairs of a persistent workgroup form one flat stream of steps; during step s the wave multiplies step s,
 //     parks / transforms / splits step s+1 (loaded during step s-1) and requests the raw rows of step s+2;
-//   * a chunk is 6 super-steps (position pair, kx) of 24 MFMAs; B fragments have ONE register copy (a part's registers take the
+//   * a chunk is 6 super-steps (position pair, kx) of 24 MFMAs (NP = 2: 12); B fragments have ONE register copy (a part's registers take the
 //     next super-step's fragment as soon as its last product is issued), weight fragments are two super-steps ahead, vector-memory
 //     requests are never in adjacent slots;
 //   * the epilogue of a tile is exposed (carrying it under the next tile's chunks needs 64 holding registers on top of the 128
@@ -33,6 +41,8 @@
 //     layout, four 8-cout passes through the wave's landing area (two 4 KB halves: pass p+1 is written before pass p is read back),
 //     residual quads requested two passes ahead, 16-byte stores as inline assembly the wait-count pass does not see (a pending
 //     store would turn every counted wait for a load -- the next step's row pieces and weights are in flight -- into vmcnt(0)).
+// The two-part form runs at the balance point of three CU resources (per chunk: matrix pipe 2.3 k cycles, LDS 304 KB = 2.4 k, L1 path
+// 136 KB = 2.1 k): its row-piece requests are therefore spread two per super-step instead of sitting behind the parks.
 #include "conv_wave_epilogue.h"
 #include <utility>
 

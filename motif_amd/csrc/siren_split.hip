@@ -1,5 +1,7 @@
-// The three SIREN MLPs on the bf16 matrix cores with fp32-equivalent arithmetic (3-way bf16 split, 6 products,
-// fp32 accumulate -- see conv_split.hip for the arithmetic), register-chained like siren.hip.
+// The three SIREN MLPs on the 16-bit matrix cores with fp32-equivalent arithmetic, register-chained like siren.hip.  Template
+// parameter NP: 3 = 3-way bf16 split, 6 products, fp32 accumulate (see conv_split.hip for the arithmetic; pre = 2); 2 = 2-way fp16 split,
+// 3 products (round 4, pre = 3, the default: see SProd below and conv_wino.hip's header -- the operands here are sines, coordinates and
+// normalised sums, i.e. made for fp16's range).  The comments below give the three-part figures.
 //
 // v_mfma_f32_32x32x16_bf16: lane (p = lane&31, hf = lane>>5) supplies 8 consecutive-k bf16 values of pixel p; the
 // C/D layout is the fp32 one (row m = 32t + (r&3) + 8(r>>2) + 4hf in register r of output tile t).  Registers
