@@ -134,10 +134,7 @@ struct WSched {
             // requests in super-step 0 and five in 1 those took 700 / 1050 cycles, spread they all take 540-650 (tools/trace_wino.py SS=1).
             for (int i = 0; i < NLD; ++i) {
                 ext[2 * i + 1] = (WP_PARK << 8) | i;
-#ifndef WINO_RL2
-#define WINO_RL2 1        // experiments: 0 = right behind the park (the three-part form's rule), 2 / 3 = denser, later
-#endif
-                const int ls = WINO_RL2 == 1 ? 14 + 6 * i : WINO_RL2 == 2 ? 14 + 4 * i : WINO_RL2 == 3 ? 22 + 4 * i : 2 * i + 2;
+                const int ls = 14 + 6 * i;               // (measured beside: right behind the park, 14 + 4 i, 22 + 4 i)
                 if (rl[ls] >= 0 || ra[ls] >= 0) clash = 1;
                 rl[ls] = i;
             }
@@ -509,15 +506,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 if (p == 1) acc[tl][p] = bvec;           // (C and D of an MFMA share a register class: the bias vector goes in by plain moves)
-#ifdef WINO_NOMFMAINIT
-                else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[tl][p][r] = 0.f;
-                }
-#else
                 else if constexpr (NP == 2) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %1, 0" : "=a"(acc[tl][p]) : "v"(zq));
                 else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[tl][p]) : "v"(zq));
-#endif
             }
     };
     // After a tile's last chunk: inverse transform + bias in the C/D layout, then four passes of 8 couts x 4 rows x 32 pixels through
@@ -544,11 +534,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int oy = ty * TH + 4 * tp + (l5 >> 3), ox = tx * 32 + (l5 & 7) * 4;
         const bool okl = oy < a.Ho && ox < a.Wo;
         const unsigned lb = (unsigned)hf * HWo + (unsigned)(oy * a.Wo + ox);
-#ifdef WINO_NOFULL
-        const bool full = false;
-#else
         const bool full = cl >= 32 && ty * TH + 4 * tp + 4 <= a.Ho && tx * 32 + 32 <= a.Wo;     // uniform: every lane stores every item
-#endif
         auto okv = [&](int pass, int it) __attribute__((always_inline)) { return okl && 8 * pass + 2 * it + hf < cl; };
         auto offv = [&](int pass, int it) __attribute__((always_inline)) { return lb + (unsigned)(8 * pass + 2 * it) * HWo; };
         // all 16 residual quads are requested before the inverse transform (first touches of another XCD's output: ~2 k cycles; the

@@ -336,6 +336,38 @@ def test_conv_wino_same_bits_whatever_the_batch_and_the_run(case, parts, keep_mm
         ops.set_option("conv_engine", 0)
 
 
+def test_conv_two_part_form_is_loud_outside_fp16_range_and_three_part_form_is_not(keep_mma):
+    """mma = 7 (two fp16 parts) has fp16's range: a transformed activation beyond 65504 must give inf / NaN in the outputs it
+    touches -- never a silently clamped finite value -- and leave every other output untouched; mma = 6 (three bf16 parts, fp32's
+    exponent range) computes the same layer correctly.  include/motif_hip.h, MotifConvDesc.mma."""
+    from motif_amd import ops
+    from motif_amd.models.modules.layers import Conv2d
+    m = Conv2d(64, 64, 3, 1, 1)
+    with torch.no_grad():
+        m.weight.copy_(rnd(*m.weight.shape, seed=1, scale=1.0 / 24))
+        m.bias.copy_(rnd(64, seed=2, scale=0.1))
+    x = rnd(1, 64, 32, 64, seed=3)
+    x[0, 5, 10, 20] = 1.0e5
+    ref = F.conv2d(x.double(), m.weight.double(), m.bias.double(), 1, 1)
+    m = m.to(dev())
+    try:
+        ops.set_option("conv_engine", 5)
+        ops.set_conv_mma(ops.MMA_BF16X3)
+        o6 = m(x.to(dev())).cpu()
+        ops.set_conv_mma(ops.MMA_F16X2)
+        o7 = m(x.to(dev())).cpu()
+    finally:
+        ops.set_option("conv_engine", 0)
+    close(o6, ref.float(), 2e-2, 1e-6, "three bf16 parts with a 1e5 activation")            # fp32 rounding of sums of magnitude 4e3
+    bad = ~torch.isfinite(o7)
+    assert bad.any(), "an out-of-range activation must not pass silently"
+    ys, xs = bad.nonzero()[:, 2], bad.nonzero()[:, 3]
+    assert int(ys.min()) >= 8 and int(ys.max()) <= 12 and int(xs.min()) >= 19 and int(xs.max()) <= 21, "only the outputs the value reaches (3 columns; the rows its Winograd row pairs cover)"
+    near = torch.zeros_like(bad)
+    near[:, :, 8:13, 19:22] = True
+    close(o7[~near], ref.float()[~near], 2e-5, 2e-5, "outputs the value does not reach")
+
+
 # ------------------------------------------------------------------------------------------- DCNv2
 def test_dcn_matches_kernel_text_restatement():
     from oracle import native
