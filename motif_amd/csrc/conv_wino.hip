@@ -156,6 +156,12 @@ struct WSched {
 __device__ __forceinline__ float fadd1(float a, float b) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float fsub1(float a, float b) { float r; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+// A load through a pointer rebuilt from integers (the tile table) is a FLAT load to hipcc: it could be LDS, returns out of order with
+// the buffer loads, and ONE such request possibly pending anywhere in the tile loop turns every counted wait of the loop into
+// s_waitcnt vmcnt(0) (found as an unconditional vmcnt(0) in front of every chunk's first B fragments).  Hence: explicitly global.
+template <class T>
+__device__ __forceinline__ T gload(const T* p) { return *(const __attribute__((address_space(1))) T*)p; }
+
 template <int NP> constexpr WSched<NP> kWSchedOf{};
 static_assert(kWSchedOf<3>.used <= WSched<3>::S && kWSchedOf<3>.clash == 0, "pieces do not fit the slots of a chunk");
 static_assert(kWSchedOf<2>.used <= WSched<2>::S && kWSchedOf<2>.clash == 0, "pieces do not fit the slots of a chunk (two-part form)");
@@ -299,9 +305,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wb, wvoff, (ks * NP + p) * (2 * 64 * 16), 0));
     };
     auto bias_of = [&](const TileP& t) __attribute__((always_inline)) {
-        const float b = (t.bp && lane < 32 && ct * 32 + lane < t.clg) ? t.bp[ct * 32 + lane] : 0.f;
-        return NP == 2 ? b * kWinoF16Scale : b;             // the accumulators of the two-part form carry 2^8 x the sums (exact)
+        return (t.bp && lane < 32 && ct * 32 + lane < t.clg) ? gload(t.bp + ct * 32 + lane) : 0.f;
     };
+    // the accumulators of the two-part form carry 2^8 x the sums (exact).  Scaled where the value is STORED for init_acc, not where it is
+    // requested: arithmetic on it at the request would wait for every vector-memory request in flight (vmcnt is one in-order queue)
+    auto bias_scaled = [](float b) __attribute__((always_inline)) { return NP == 2 ? b * kWinoF16Scale : b; };
     auto setup_loads = [&](const TileP& t, bool valid) __attribute__((always_inline)) {
         st_g = t.g;
         in0n = t.in0n;
@@ -542,7 +550,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         f32x4 rv[4][4];
         auto load_res = [&](int pass) __attribute__((always_inline)) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) rv[pass][it] = *(const f32x4*)(rb + ((full || okv(pass, it)) ? offv(pass, it) : 0u));   // masked lanes read element 0
+            for (int it = 0; it < 4; ++it) rv[pass][it] = gload((const f32x4*)(rb + ((full || okv(pass, it)) ? offv(pass, it) : 0u)));   // masked lanes read element 0
         };
         if (rm) { load_res(0); load_res(1); load_res(2); load_res(3); }
         EPSTAMP();
@@ -654,10 +662,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     loadw(wbase, 1, wf[1]);
     loadw(wbase, 2, wf[2]);
     float bias_v = bias_of(load_tile(0));
+    const float* bp_next = nullptr;                      // bias pointer / valid couts of the next tile (uniform), set at the tile change
+    int clg_next = 0;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) st_load(i, 0);
     static_for<WS::S>([&](auto ic) __attribute__((always_inline)) { piece(std::integral_constant<int, kWSchedOf<NP>.ext[decltype(ic)::value]>{}, stg0); });
-    if (lane < 32) bias_w[lane] = bias_v;
+    if (lane < 32) bias_w[lane] = bias_scaled(bias_v);
     init_acc();
 #pragma unroll
     for (int i = 0; i < NLD; ++i) st_load(i, 16);        // nch >= 2: step 1 is chunk 1 of this tile
@@ -672,7 +682,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int c = 0; c < nch; ++c) {
             if (c == nch - 2) {                          // from here on the row-piece requests belong to the next tile
                 const TileP tq = load_tile(has_next ? ti + 1 : ti);
-                if (has_next) { wnext = wptr(tq); bias_v = bias_of(tq); } else wnext = wbase;
+                if (has_next) { wnext = wptr(tq); bp_next = tq.bp; clg_next = tq.clg; } else wnext = wbase;      // (the next tile's bias is requested under the epilogue)
                 setup_loads(tq, has_next);
             }
             const bool last = c + 1 == nch;
@@ -681,8 +691,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             chunk_body(c, buf, sc, wn, lc0);
             if (slot < 29) WNTRACE(slot);                // trace: body end | epilogue end | barrier passed, for the first 9 chunks
             if (last) {
+                bias_v = (has_next && bp_next && lane < 32 && ct * 32 + lane < clg_next) ? gload(bp_next + ct * 32 + lane) : 0.f;
                 finish_tile(load_tile(ti));
-                if (lane < 32) bias_w[lane] = bias_v;    // the next tile's bias,
+                if (lane < 32) bias_w[lane] = bias_scaled(bias_v);    // the next tile's bias,
                 init_acc();                              // into its accumulators
             }
             if (slot < 29) WNTRACE(slot + 1);
