@@ -1,0 +1,87 @@
+"""Properties of the generated gfx950 code that the performance of the hot kernels rests on, checked on the ISA hipcc emits
+(cross-compiled here, no GPU): each of them was once silently lost and cost a measurable fraction of the kernel.
+
+  * conv_wino_kernel: no register spills in the shipped (two-part) form; no FLAT loads anywhere in the kernel -- a flat request
+    possibly pending in the tile loop turns every counted wait of the loop into s_waitcnt vmcnt(0); the chunk body holds exactly
+    72 (two fp16 parts) / 144 (three bf16 parts) matrix instructions and starts behind a COUNTED wait;
+  * every 16-byte inline-assembly store is followed by two wait states (gfx950: a store of more than 8 bytes must not be followed
+    by a vector write of its data registers within two wait states; hipcc adds them for its own stores only).
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "motif_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def wino_isa(tmp_path_factory):
+    if not shutil.which("hipcc"):
+        pytest.skip("hipcc not on PATH")
+    out = tmp_path_factory.mktemp("isa") / "conv_wino.s"
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-value", "-Wno-pass-failed",
+           "-I", CSRC, "-I", os.path.join(ROOT, "include"), "--cuda-device-only", "-S", os.path.join(CSRC, "conv_wino.hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+    text = out.read_text()
+    kernels = {}
+    for m in re.finditer(r"^(_Z16conv_wino_kernelILi(\d)ELb(\d)EEv8ConvArgsii):", text, re.M):
+        end = text.index(".Lfunc_end", m.end())
+        kernels[(int(m.group(2)), bool(int(m.group(3))))] = text[m.end():end].splitlines()
+    meta = {}
+    for m in re.finditer(r"\.name:\s+(_Z16conv_wino_kernelILi(\d)ELb(\d)EEv8ConvArgsii)\s", text):
+        blk = text[max(0, m.start() - 1500):m.end() + 1500]
+        sp = re.search(r"\.vgpr_spill_count:\s+(\d+)", blk)
+        meta[(int(m.group(2)), bool(int(m.group(3))))] = int(sp.group(1)) if sp else None
+    return kernels, meta
+
+
+def _instr(lines):
+    for ln in lines:
+        t = ln.strip()
+        if t and not t.startswith((";", ".", "/")) and not t.endswith(":"):
+            yield t
+
+
+def test_conv_wino_kernels_exist_without_flat_loads_and_without_spills_in_the_shipped_form(wino_isa):
+    kernels, meta = wino_isa
+    assert set(kernels) == {(2, False), (2, True), (3, False), (3, True)}
+    for key, lines in kernels.items():
+        ops = [t.split()[0] for t in _instr(lines)]
+        assert not [o for o in ops if o.startswith("flat_")], "conv_wino_kernel<%d, %s> has FLAT memory instructions" % key
+    for multi in (False, True):
+        assert meta[(2, multi)] == 0, "the two-part kernel must not spill vector registers (%s)" % meta
+
+
+@pytest.mark.parametrize("parts, mfmas", [(2, 72), (3, 144)])
+def test_conv_wino_chunk_body_is_one_run_of_matrix_instructions_behind_a_counted_wait(wino_isa, parts, mfmas):
+    kernels, _ = wino_isa
+    lines = kernels[(parts, False)]
+    idx = [i for i, ln in enumerate(lines) if "v_mfma_f32_32x32x16" in ln]
+    runs, start, prev, n = [], idx[0], idx[0], 1
+    for i in idx[1:]:
+        if i - prev > 80:
+            runs.append((start, prev, n)); start, n = i, 0
+        n += 1; prev = i
+    runs.append((start, prev, n))
+    body = max(runs, key=lambda r: r[2])
+    assert body[2] == mfmas, runs
+    opcode = "v_mfma_f32_32x32x16_f16" if parts == 2 else "v_mfma_f32_32x32x16_bf16"
+    assert all(opcode in lines[i] for i in idx if body[0] <= i <= body[1])
+    waits = [t for t in _instr(lines[body[0] - 60:body[0]]) if t.startswith("s_waitcnt") and "vmcnt" in t]
+    assert waits, "the chunk's first fragments wait for their weights"
+    assert "vmcnt(0)" not in waits[-1], "every chunk would begin by waiting for ALL requests in flight: %s" % waits
+
+
+def test_wide_inline_assembly_stores_are_followed_by_two_wait_states(wino_isa):
+    kernels, _ = wino_isa
+    for key, lines in kernels.items():
+        ins = list(_instr(lines))
+        stores = [i for i, t in enumerate(ins) if t.startswith("global_store_dwordx4")]
+        assert stores, key
+        for i in stores:
+            nxt = ins[i + 1]
+            assert nxt.startswith("s_nop") and int(nxt.split()[1]) >= 1, "conv_wino_kernel<%d, %s>: %s / %s" % (key + (ins[i], nxt))

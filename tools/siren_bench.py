@@ -42,10 +42,9 @@ def main():
         l0i = ops.conv2d(net.imnet.l0_plan(0, 64), feat)
         l0f = ops.conv2d(net.flow_imnet.l0_plan(0, 64), feat)
         l0s = ops.conv2d(net.synth_net.l0_plan(133, 197), res)
-        for pre, name in ((1, "fp32 pre"), (2, "split")):
-            bf = net.flow_imnet.packed_split(ops.SIREN_FLOW) if pre == 2 else net.flow_imnet.packed()
-            bs = net.synth_net.packed_split(ops.SIREN_SYNTH) if pre == 2 else net.synth_net.packed()
-            bi = net.imnet.packed_split(ops.SIREN_IMNET) if pre == 2 else net.imnet.packed()
+        for pre, name in ((1, "fp32 pre"), (2, "three bf16 parts"), (3, "two fp16 parts")):
+            pk = (lambda kind, m: ops.siren_pack_split(kind, m.linears(), pre=pre)) if pre >= 2 else (lambda kind, m: m.packed())
+            bf, bs, bi = pk(ops.SIREN_FLOW, net.flow_imnet), pk(ops.SIREN_SYNTH, net.synth_net), pk(ops.SIREN_IMNET, net.imnet)
             ms = t(lambda: ops.siren_flow(bf, l0f, iy, ix, ry, rx, times, N, HH, WW, pre=pre), reps)
             print("[%s] flow_imnet N=3: %.3f ms  %.1f TFLOP/s" % (name, ms, 2 * 25536 * 2 * B * N * Q / ms / 1e9))
             ms = t(lambda: ops.siren_synth(bs, acc, l0s, iy, ix, times, B, N, HH, WW, pre=pre), reps)
