@@ -293,6 +293,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 
     // ---- load plan of the tile the row-piece requests currently target -----------------------------------------------------
+    constexpr bool POFF = NP == 2;                       // the ten request offsets of the target tile held in registers (the three-part form has none to spare)
+    int po[POFF ? NLD : 1] = {};
     unsigned vmask = 0;                                  // bit i: row piece i lies inside the image
     int origin = 0;                                      // byte offset of the tile's first staged pixel within a plane (uniform)
     const float* in0n = nullptr; const float* in1n = nullptr;
@@ -318,13 +320,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int rlo = iy0 < 0 ? -iy0 : 0, rhi = valid ? (a.H - iy0 < 4 ? a.H - iy0 : 4) : 0;
         const int qlo = x0 < 0 ? 1 : 0, qhi = (a.W - x0) >> 2;         // W % 4 == 0, x0 % 4 == 0
         origin = (iy0 * a.W + x0) * 4;
-        if (valid && iy0 >= 0 && iy0 + 4 <= a.H && x0 >= 0 && x0 + 40 <= a.W) { vmask = 0x3ffu; return; }   // interior tile: every piece inside
-        vmask = 0;
+        if (valid && iy0 >= 0 && iy0 + 4 <= a.H && x0 >= 0 && x0 + 40 <= a.W) vmask = 0x3ffu;   // interior tile: every piece inside
+        else {
+            vmask = 0;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const unsigned f6 = ((i < 5 ? rx0 >> (6 * i) : rx1 >> (6 * (i - 5)))) & 63u;
-            const int row = (int)(f6 & 3u), xq = (int)(f6 >> 2);
-            vmask |= (row >= rlo && row < rhi && xq >= qlo && xq < qhi) ? 1u << i : 0u;
+            for (int i = 0; i < NLD; ++i) {
+                const unsigned f6 = ((i < 5 ? rx0 >> (6 * i) : rx1 >> (6 * (i - 5)))) & 63u;
+                const int row = (int)(f6 & 3u), xq = (int)(f6 >> 2);
+                vmask |= (row >= rlo && row < rhi && xq >= qlo && xq < qhi) ? 1u << i : 0u;
+            }
+        }
+        if constexpr (POFF) {                            // once per tile instead of four vector instructions per request and chunk
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) po[i] = (vmask >> i) & 1u ? pl[i] + origin : (int)0x80000000;
         }
     };
     // ---- the requests and pieces of staging one 16-channel chunk -----------------------------------------------------------
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int nchv = (first && in1n) ? a.C0 - c0 : a.Cin_g - c0;          // channels from c0 to the end of the group / of the first source
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nchv * HW * 4, 0x00020000);
         // BYTE offset from the chunk's first plane; 2^31 = "outside the image": beyond any descriptor's range, the load returns 0
-        const int off = (vmask >> i) & 1u ? pl[i] + origin : (int)0x80000000;
+        const int off = POFF ? po[POFF ? i : 0] : ((vmask >> i) & 1u ? pl[i] + origin : (int)0x80000000);
         gq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     };
     auto st_park = [&](int i) __attribute__((always_inline)) { *(f32x4*)(land + i * 64 + lane) = gq[i]; };
