@@ -219,3 +219,6 @@ int motif_conv_split_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStrea
 // conv_direct.hip: narrow layers (<= 32 couts, 1x1 / 3x3) on large maps, vector ALU, reads conv_igemm's packed weights
 bool motif_conv_direct_eligible(const MotifConvDesc* d, const ConvArgs& a, int P);
 int motif_conv_direct_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s);
+// round-4 kernel (conv_pw.hip): 1x1 layers on the fp16 matrix cores (two-part split, mma = 7), reading the fp32 engine's packed block
+bool motif_conv_pw_eligible(const MotifConvDesc* d, const ConvArgs& a, int P);
+int motif_conv_pw_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s);

@@ -381,6 +381,7 @@ extern "C" int motif_conv2d_fwd_multi(const MotifConvDesc* d, int P, const float
     a.C0 = d->C0; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
     a.act = d->act; a.act2 = d->act2; a.act_split = d->act_split; a.res_mode = d->res_mode;
     if (motif_conv_direct_eligible(d, a, P)) return motif_conv_direct_launch(d, a, P, (hipStream_t)stream);      // narrow layer, large map
+    if (motif_conv_pw_eligible(d, a, P)) return motif_conv_pw_launch(d, a, P, (hipStream_t)stream);              // 1x1 layer, mma = 7: conv_pw.hip
     // 16-byte staging (conv_igemm_kernel VEC) where the layout allows it: rows of whole quads, aligned inputs, zero padding
     bool vec = (d->W & 3) == 0 && d->pad_mode == 0 && !motif_opt(MOTIF_OPT_CONV_NOVEC);
     for (int i = 0; i < P && vec; ++i)

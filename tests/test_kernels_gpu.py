@@ -336,6 +336,49 @@ def test_conv_wino_same_bits_whatever_the_batch_and_the_run(case, parts, keep_mm
         ops.set_option("conv_engine", 0)
 
 
+PW_CASES = [  # N, Cin, Cout, H, W, first-source channels (0 = one source), act, res_mode
+    (2, 128, 64, 45, 80, 0, "lrelu", 0),          # the fusion layers' shape class
+    (1, 196, 96, 23, 37, 0, "none", 1),           # PWC / RAFT feature head: three cout tiles, ragged last pixel group, Cin % 16 != 0
+    (2, 24, 96, 30, 40, 0, "relu", 2),            # two k-steps, the second half empty past channel 24
+    (3, 128, 64, 16, 24, 64, "lrelu", 0),         # two concatenated sources
+    (1, 64, 128, 18, 32, 0, "none", 0),           # four cout tiles
+    (2, 16, 40, 33, 31, 0, "relu", 1),            # one k-step, partial second cout tile, odd plane size
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_pw_pointwise_layers_match_fp64_and_the_fp32_engine(case, keep_mma):
+    """conv_pw.hip (1x1 layers under mma = 7: two fp16 parts on the matrix cores, weights split in the kernel from the fp32 packed
+    block) against an fp64 convolution -- error not above the fp32-MFMA engine's, as for the other split kernels -- and against that engine."""
+    from motif_amd import ops
+    from motif_amd.models.modules.layers import Conv2d
+    n, cin, cout, H, W, c0, actn, rm = case
+    act = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU}[actn]
+    m = Conv2d(cin, cout, 1, 1, 0)
+    with torch.no_grad():
+        m.weight.copy_(rnd(*m.weight.shape, seed=1, scale=1.0 / math.sqrt(cin)))
+        m.bias.copy_(rnd(cout, seed=2, scale=0.1))
+    x, res = rnd(n, cin, H, W, seed=3), rnd(n, cout, H, W, seed=4)
+    y = F.conv2d(x.double(), m.weight.double(), m.bias.double())
+    f = {"none": lambda v: v, "relu": F.relu, "lrelu": lambda v: F.leaky_relu(v, 0.1)}[actn]
+    ref = f(y + res.double()) if rm == 1 else f(y) + res.double() if rm == 2 else f(y)
+    m = m.to(dev())
+    xd, rd = x.to(dev()), res.to(dev())
+    args = (xd[:, :c0].contiguous(), xd[:, c0:].contiguous()) if c0 else (xd, None)
+    kw = dict(act=act) if rm == 0 else dict(act=act, res=rd, res_mode=rm)
+    outs = {}
+    for mode in (ops.MMA_FP32, ops.MMA_F16X2):
+        ops.set_conv_mma(mode)
+        outs[mode] = m(*args, **kw).double().cpu()
+    e32, e16 = float((outs[ops.MMA_FP32] - ref).abs().max()), float((outs[ops.MMA_F16X2] - ref).abs().max())
+    scale = float(ref.abs().max())
+    assert not torch.equal(outs[ops.MMA_FP32], outs[ops.MMA_F16X2]), "the two engines are different kernels"
+    assert e32 < 2e-6 * scale and e16 <= 1.25 * e32 + 1e-7 * scale, (e32, e16, scale)
+    # same bits whatever the batch: a pixel group's arithmetic does not depend on which wave picks it up
+    again = m(*(t[:1].contiguous() if t is not None else None for t in args), **(dict(act=act) if rm == 0 else dict(act=act, res=rd[:1].contiguous(), res_mode=rm)))
+    assert torch.equal(again.double().cpu(), outs[ops.MMA_F16X2][:1])
+
+
 def test_conv_two_part_form_is_loud_outside_fp16_range_and_three_part_form_is_not(keep_mma):
     """mma = 7 (two fp16 parts) has fp16's range: a transformed activation beyond 65504 must give inf / NaN in the outputs it
     touches -- never a silently clamped finite value -- and leave every other output untouched; mma = 6 (three bf16 parts, fp32's

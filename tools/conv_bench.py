@@ -26,7 +26,16 @@ SHAPES = [  # N, Cin, Cout, k, stride, H, W
     (8, 64, 216, 3, 1, 90, 160),
 ]
 
+PW_SHAPES = [  # the clip's 1x1 layers (conv_pw.hip under MMA=7, the fp32 engine under MMA=0): PW=1 selects this list
+    (4, 128, 64, 1, 1, 180, 320), (2, 196, 96, 1, 1, 90, 160), (1, 128, 64, 1, 1, 180, 320), (2, 24, 96, 1, 1, 90, 160),
+    (2, 16, 64, 1, 1, 180, 320), (2, 64, 64, 1, 1, 180, 320), (2, 64, 96, 1, 1, 90, 160), (2, 8, 32, 1, 1, 360, 640),
+]
+
+
 def main():
+    global SHAPES
+    if os.environ.get("PW"):
+        SHAPES = PW_SHAPES
     reps = int(os.environ.get("REPS", "20"))
     only = os.environ.get("ONLY")
     from motif_amd import ops
