@@ -222,7 +222,9 @@ int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, const long* i
                                  float* const* out, int B, int C, int H, int W, int Cout, int deformable_groups,
                                  long offset_bs, long mask_bs, int act, int mma, void* stream);
 /* mma = 0: `packed3x3` as above, fp32 MFMA.  mma = 6: the GEMM on the bf16 matrix cores with the fp32-equivalent 3-way split
- * (MotifConvDesc.mma), `packed3x3` from motif_dcn_split_pack (size query with packed = NULL; returns floats). */
+ * (MotifConvDesc.mma), `packed3x3` from motif_dcn_split_pack (size query with packed = NULL; returns floats).  mma = 7: the two-part
+ * fp16 form (three products, weights x 2^8: MotifConvDesc.mma = 7) in the window kernel, mma = 6 where that kernel does not apply; the
+ * blob of motif_dcn_split_pack holds both fragment blocks. */
 long motif_dcn_split_pack(const float* weight /*[Cout,C,3,3]*/, float* packed, int Cout, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

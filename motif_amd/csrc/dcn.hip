@@ -152,15 +152,36 @@ __device__ __forceinline__ void dcn_split8(const float (&v)[8], dcn_u32x4 (&out)
     }
 }
 
+
+// Two-part fp16 form of the window kernel's GEMM (round 4, MotifConvDesc.mma = 7 semantics: conv_wino.hip's header): hi = rne_fp16(x),
+// lo = rne_fp16(x - hi), three products instead of six; the weights are packed times 2^8, the epilogue multiplies by 2^-8.  The sampled
+// values are bilinear blends of feature values times a sigmoid mask: the range of the features.
+typedef _Float16 dcn_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 dcn_f16x8 __attribute__((ext_vector_type(8)));
+constexpr float kDcnF16Scale = 256.f;
+__device__ constexpr int DCN_PW2[3] = {1, 0, 0};
+__device__ constexpr int DCN_PX2[3] = {0, 1, 0};
+__device__ __forceinline__ unsigned dcn_pk_f16(float a, float b) { const dcn_f16x2 h = {(_Float16)a, (_Float16)b}; return __builtin_bit_cast(unsigned, h); }
+__device__ __forceinline__ float dcn_sub_lo(float x, unsigned pk) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x)); return r; }
+__device__ __forceinline__ float dcn_sub_hi(float x, unsigned pk) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x)); return r; }
+__device__ __forceinline__ void dcn_split8_f16(const float (&v)[8], dcn_u32x4 (&out)[2]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        out[0][q] = dcn_pk_f16(v[2 * q], v[2 * q + 1]);
+        out[1][q] = dcn_pk_f16(dcn_sub_lo(v[2 * q], out[0][q]), dcn_sub_hi(v[2 * q + 1], out[0][q]));
+    }
+}
+
 // weight [Cout, C, 3, 3] fp32 -> per cout group of 64 and per 4-channel chunk: A fragments [k-step 3][part 3][tile 2][lane][8]
 // bf16 of the chunk's K-rows R = 16s + 8*(lane>>5) + e, R = ((cl>>1)*9 + tap)*2 + (cl&1) (the im2col row order of the fused
 // kernel), rows 36..47 zero.
+template <int NP>
 __global__ void dcn_split_pack_kernel(const float* w, unsigned short* wp, int Cout, int C, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), t = (int)((i >> 9) & 1);
     long r = i >> 10;
-    const int part = (int)(r % 3); r /= 3;
+    const int part = (int)(r % NP); r /= NP;
     const int ks = (int)(r % 3); r /= 3;
     const int nch = C / DF_CH;
     const int chunk = (int)(r % nch);
@@ -174,10 +195,19 @@ __global__ void dcn_split_pack_kernel(const float* w, unsigned short* wp, int Co
         v = w[((long)col * C + c) * 9 + tap];
     }
     unsigned short out = 0;
-    for (int p = 0; p <= part; ++p) {
-        const unsigned pk = dcn_pk_bf16(v, 0.f);
-        out = (unsigned short)(pk & 0xffffu);
-        v -= __builtin_bit_cast(float, pk << 16);
+    if constexpr (NP == 2) {
+        double vd = (double)v * (double)kDcnF16Scale;
+        for (int p = 0; p <= part; ++p) {
+            const _Float16 h = (_Float16)(float)vd;
+            out = __builtin_bit_cast(unsigned short, h);
+            vd -= (double)(float)h;
+        }
+    } else {
+        for (int p = 0; p <= part; ++p) {
+            const unsigned pk = dcn_pk_bf16(v, 0.f);
+            out = (unsigned short)(pk & 0xffffu);
+            v -= __builtin_bit_cast(float, pk << 16);
+        }
     }
     wp[i] = out;
 }
@@ -185,11 +215,12 @@ __global__ void dcn_split_pack_kernel(const float* w, unsigned short* wp, int Co
 extern "C" long motif_dcn_split_pack(const float* weight, float* packed, int Cout, int C, void* stream) {
     if (Cout < 1 || C < DF_CH || C % DF_CH) return MOTIF_EINVAL;
     const long ncg = (Cout + 63) / 64, nch = C / DF_CH;
-    const long floats = ncg * nch * 3 * 3 * 2 * 64 * 4;
+    // blob = [three-part bf16 block | two-part fp16 block]: the kernel and arithmetic are chosen per launch (mma = 6 / 7)
+    const long floats3 = ncg * nch * 3 * 3 * 2 * 64 * 4, floats2 = ncg * nch * 3 * 2 * 2 * 64 * 4, floats = floats3 + floats2;
     if (!packed) return floats;
     if (!weight) return MOTIF_EINVAL;
-    const long total = floats * 2;                                   // bf16 elements
-    dcn_split_pack_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(weight, (unsigned short*)packed, Cout, C, total);
+    dcn_split_pack_kernel<3><<<cdiv(floats3 * 2, 256), 256, 0, (hipStream_t)stream>>>(weight, (unsigned short*)packed, Cout, C, floats3 * 2);   // 16-bit elements
+    dcn_split_pack_kernel<2><<<cdiv(floats2 * 2, 256), 256, 0, (hipStream_t)stream>>>(weight, (unsigned short*)(packed + floats3), Cout, C, floats2 * 2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(long)e - 1000;
     return floats;
@@ -429,12 +460,12 @@ extern "C" int motif_debug_dcn_trace(long long* host, int n) { return (int)hipMe
 #else
 #define DT(i)
 #endif
-template <int WAVES>
+template <int WAVES, int NP>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void dcn_win_kernel(DcnFusedArgs a) {
     constexpr int NPX = 32 * WAVES, NT = 64 * WAVES, TH = WAVES;
     constexpr int WWD = 32 + 2 * DW_R, WHT = TH + 2 * DW_R, WSZ = WHT * WWD;      // window of one channel
     constexpr int NWU = DF_CH * WSZ / 4, NWL = (NWU + NT - 1) / NT;                // 16-byte units per chunk, per thread
-    constexpr int WCH = 3 * 3 * 2 * 64 * 4;
+    constexpr int WCH = 3 * NP * 2 * 64 * 4;            // [k-step 3][part NP][tile 2][lane 64] x 16 bytes
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* col0 = smem;                                  // [2][DF_ROWS][NPX]
     float* win0 = col0 + 2 * DF_ROWS * NPX;              // [2][DF_CH][WSZ]
@@ -450,7 +481,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
     const float* imb = a.im[pz] + (long)b * a.im_bs[pz];
     const float* offb = a.offset[pz] + (long)b * a.offset_bs;
     const float* mskb = a.mask[pz] + (long)b * a.mask_bs;
-    const float* wbase = a.wp[pz] + (long)cg * (a.C / DF_CH) * WCH;
+    // the blob holds the three-part block of ALL cout groups first, then the two-part block
+    const float* wbase = a.wp[pz] + (NP == 2 ? (long)a.ncg * (a.C / DF_CH) * (3 * 3 * 2 * 64 * 4) : 0L) + (long)cg * (a.C / DF_CH) * WCH;
     const int cpg = a.C / a.dg;
     const int wy0 = ty * TH - DW_R, wx0 = tx * 32 - DW_R;
 
@@ -685,19 +717,22 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
                         v[e] = (ks < 2 || r < DF_ROWS) ? colp[(r < DF_ROWS ? r : 0) * NPX] : 0.f;
                         if (ks == 2 && r >= DF_ROWS) v[e] = 0.f;
                     }
-                    dcn_u32x4 x[3];
-                    dcn_split8(v, x);
-                    dcn_u32x4 w[2][3];
+                    dcn_u32x4 x[NP];
+                    if constexpr (NP == 2) dcn_split8_f16(v, x); else dcn_split8(v, x);
+                    dcn_u32x4 w[2][NP];
 #pragma unroll
-                    for (int part = 0; part < 3; ++part)
+                    for (int part = 0; part < NP; ++part)
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) w[t][part] = wfr[((ks * 3 + part) * 2 + t) * 64];
+                        for (int t = 0; t < 2; ++t) w[t][part] = wfr[((ks * NP + part) * 2 + t) * 64];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k)
+                    for (int k = 0; k < (NP == 2 ? 3 : 6); ++k)
 #pragma unroll
-                        for (int t = 0; t < 2; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dcn_bf16x8, w[t][DCN_PW[k]]),
-                                                                              __builtin_bit_cast(dcn_bf16x8, x[DCN_PX[k]]), acc[t], 0, 0, 0);
+                        for (int t = 0; t < 2; ++t) {
+                            if constexpr (NP == 2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dcn_f16x8, w[t][DCN_PW2[k]]),
+                                                                                                   __builtin_bit_cast(dcn_f16x8, x[DCN_PX2[k]]), acc[t], 0, 0, 0);
+                            else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dcn_bf16x8, w[t][DCN_PW[k]]),
+                                                                                   __builtin_bit_cast(dcn_bf16x8, x[DCN_PX[k]]), acc[t], 0, 0, 0);
+                        }
                 }
             }
         };
@@ -733,7 +768,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int col = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = acc[i][r] + bias_s[col];
+            float v = (NP == 2 ? acc[i][r] * (1.f / kDcnF16Scale) : acc[i][r]) + bias_s[col];
             if (a.act == MOTIF_ACT_LRELU) v = v > 0.f ? v : 0.1f * v;
             else if (a.act == MOTIF_ACT_RELU) v = v > 0.f ? v : 0.f;
             if (col < climit) op[(long)col * HW] = v;
@@ -745,7 +780,7 @@ extern "C" int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, co
                                             float* const* out, int B, int C, int H, int W, int Cout, int deformable_groups,
                                             long offset_bs, long mask_bs, int act, int mma, void* stream) {
     if (P < 1 || P > 4 || !input || !offset || !mask || !packed3x3 || !out || B < 1) return MOTIF_EINVAL;
-    if (mma != 0 && mma != 6) return MOTIF_EINVAL;
+    if (mma != 0 && mma != 6 && mma != 7) return MOTIF_EINVAL;      // 7: two fp16 parts in the window kernel, three bf16 parts in the fallback form
     if (deformable_groups < 1 || C % deformable_groups || (C / deformable_groups) % DF_CH || (long)H * W >= (1L << 30)) return MOTIF_ELIMIT;
     if (act != MOTIF_ACT_NONE && act != MOTIF_ACT_LRELU && act != MOTIF_ACT_RELU) return MOTIF_ELIMIT;
     if ((long)H * W < 2) return MOTIF_ELIMIT;        // the corner-pair loads of the non-window form need two elements per plane
@@ -774,7 +809,8 @@ extern "C" int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, co
     // and the model-level run-to-run test keep watching it.  MOTIF_DCN_WAVES=8 / 4 forces a form.
     // window form (dcn_win_kernel): bf16x3 engine, rows of whole 16-byte units, 32-bit offsets over 4 planes; one 8-wave block
     // per CU (147 KB of LDS)
-    const bool win_ok = mma == 6 && (W & 3) == 0 && W >= 4 && (long)DF_CH * HW < (1L << 30) && !motif_opt(MOTIF_OPT_DCN_NOWIN) &&
+    const bool split = mma == 6 || mma == 7;
+    const bool win_ok = split && (W & 3) == 0 && W >= 4 && (long)DF_CH * HW < (1L << 30) && !motif_opt(MOTIF_OPT_DCN_NOWIN) &&
                         (((unsigned long long)a.im[0] | (unsigned long long)a.im[1] | (unsigned long long)a.im[2] | (unsigned long long)a.im[3]) & 15) == 0 &&
                         ((a.im_bs[0] | a.im_bs[1] | a.im_bs[2] | a.im_bs[3]) & 3) == 0;
     // Non-window path (fp32 engine, W % 4 != 0, unaligned views): 8-wave blocks by default.  The 4-wave form (11 % faster on the
@@ -784,21 +820,22 @@ extern "C" int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, co
     if (const int wv = motif_opt(MOTIF_OPT_DCN_WAVES)) waves = wv == 4 ? 4 : 8;
     a.front_pad = motif_opt(MOTIF_OPT_DCN_FRONT_PAD);
     const int back_pad = motif_opt(MOTIF_OPT_DCN_BACK_PAD);
-    const int wch = mma == 6 ? 3 * 3 * 2 * 64 * 4 : DF_ROWS * 64;
+    const int wch = split ? 3 * 3 * 2 * 64 * 4 : DF_ROWS * 64;
     const size_t lds = (size_t)(2 * DF_ROWS * 32 * waves + 2 * wch + 64 + a.front_pad + back_pad) * 4;
     dim3 grid(a.tiles_x * ((H + waves - 1) / waves), a.ncg, P * B);
     hipError_t e = hipSuccess;
     if (win_ok) {
-        const size_t wlds = (size_t)(2 * DF_ROWS * 32 * waves + 2 * DF_CH * (waves + 2 * DW_R) * (32 + 2 * DW_R) + 2 * 3 * 3 * 2 * 64 * 4 + 64) * 4;
-        if (waves == 8) {
-            e = hipFuncSetAttribute((const void*)dcn_win_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
-            if (e != hipSuccess) return (int)e;
-            dcn_win_kernel<8><<<grid, 512, wlds, (hipStream_t)stream>>>(a);
-        } else {
-            e = hipFuncSetAttribute((const void*)dcn_win_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
-            if (e != hipSuccess) return (int)e;
-            dcn_win_kernel<4><<<grid, 256, wlds, (hipStream_t)stream>>>(a);
-        }
+        const int np = mma == 7 ? 2 : 3;
+        const size_t wlds = (size_t)(2 * DF_ROWS * 32 * waves + 2 * DF_CH * (waves + 2 * DW_R) * (32 + 2 * DW_R) + 2 * 3 * np * 2 * 64 * 4 + 64) * 4;
+#define MOTIF_LAUNCH_DCNW(WV, NPV)                                                                                        \
+    do {                                                                                                                  \
+        e = hipFuncSetAttribute((const void*)dcn_win_kernel<WV, NPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds); \
+        if (e != hipSuccess) return (int)e;                                                                               \
+        dcn_win_kernel<WV, NPV><<<grid, 64 * WV, wlds, (hipStream_t)stream>>>(a);                                        \
+    } while (0)
+        if (waves == 8) { if (np == 2) MOTIF_LAUNCH_DCNW(8, 2); else MOTIF_LAUNCH_DCNW(8, 3); }
+        else { if (np == 2) MOTIF_LAUNCH_DCNW(4, 2); else MOTIF_LAUNCH_DCNW(4, 3); }
+#undef MOTIF_LAUNCH_DCNW
         MOTIF_LAUNCH_CHECK();
         return MOTIF_OK;
     }
@@ -808,8 +845,8 @@ extern "C" int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, co
         if (e != hipSuccess) return (int)e;                                                                               \
         dcn_fused_kernel<WV, SP><<<grid, 64 * WV, lds, (hipStream_t)stream>>>(a);                                        \
     } while (0)
-    if (waves == 8) { if (mma == 6) MOTIF_LAUNCH_DCN(8, true); else MOTIF_LAUNCH_DCN(8, false); }
-    else { if (mma == 6) MOTIF_LAUNCH_DCN(4, true); else MOTIF_LAUNCH_DCN(4, false); }
+    if (waves == 8) { if (split) MOTIF_LAUNCH_DCN(8, true); else MOTIF_LAUNCH_DCN(8, false); }
+    else { if (split) MOTIF_LAUNCH_DCN(4, true); else MOTIF_LAUNCH_DCN(4, false); }
 #undef MOTIF_LAUNCH_DCN
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;

@@ -215,7 +215,7 @@ def dcn_v2_multi(dplans, xs, oms, dg=8, act=ACT_NONE, kh=3, kw=3, stride=1, pad=
         bs = oms[0].stride(0)
         check(lib.motif_dcn_v2_fused_fwd_multi(P, _ptr_array(xs), (ctypes.c_long * P)(*[x.stride(0) for x in xs]), _ptr_array(oms), masks,
                                                _ptr_array(packs), _ptr_array(biases), _ptr_array(outs), b, c, h, w, co, dg, bs, bs, act,
-                                               MMA_BF16X3 if split else MMA_FP32, _stream()), "motif_dcn_v2_fused_fwd_multi")
+                                               (_conv_mma if split else MMA_FP32), _stream()), "motif_dcn_v2_fused_fwd_multi")     # 6: three bf16 parts, 7: two fp16 parts in the window kernel
         return out
     cols = workspace(P * b * c * t * ho * wo, xs[0].device, "dcn_cols")
     plans = [dp.plan() for dp in dplans]
