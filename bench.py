@@ -15,8 +15,8 @@ bf16 matrix cores with every fp32 operand split exactly into three bf16 parts an
 fp32-equivalent (error below an fp32 FMA chain, tests/test_kernels_gpu.py::test_conv_split_engine_is_fp32_equivalent);
 "f16x2" (default, round 4) is the same except that the 3x3 stride-1 convolutions served by conv_wino.hip and the three MLPs
 (siren_split.hip) split every operand into TWO fp16 parts (hi = rne(x), lo = rne(x - hi): 22+ bits) and take three products -- half
-the matrix instructions, error against fp64 at or below the three-part form's (same tests); the fused DCN and the 3x3 layers
-conv_wino.hip does not take stay three-part.  "fp32" runs everything on v_mfma_f32_32x32x2_f32.  The line carries the
+the matrix instructions, error against fp64 at or below the three-part form's (same tests); so do the fused DCN's window kernel and
+the 1x1 layers (conv_pw.hip); the few 3x3 layers conv_wino.hip does not take stay three-part.  "fp32" runs everything on v_mfma_f32_32x32x2_f32.  The line carries the
 bf16x3 and fp32-MFMA numbers of the same run as `bf16x3` and `fp32_mfma`.
 
 Extra objects on the JSON line:
@@ -218,8 +218,8 @@ def instrumented_clip(model, sample):
         model.use_graph = use_graph
     mfma_peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
     conv3_peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if ops.get_conv_mma() == ops.MMA_F16X2 else mfma_peak      # two fp16 parts: 3 products per fp32 MAC
-    siren_peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if ops.get_siren_mma() == ops.MMA_F16X2 else mfma_peak     # (the fused DCN stays three-part: 6 products)
-    three = {"conv3x3": conv3_peak, "imnet": siren_peak, "flow_imnet": siren_peak, "synth_net": siren_peak}
+    siren_peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if ops.get_siren_mma() == ops.MMA_F16X2 else mfma_peak
+    three = {"conv3x3": conv3_peak, "dcn": conv3_peak, "imnet": siren_peak, "flow_imnet": siren_peak, "synth_net": siren_peak}     # the fused DCN's window kernel follows the conv mode
     bounds = {"conv3x3": "mfma", "conv_other": "mfma", "dcn": "mfma", "imnet": "mfma", "flow_imnet": "mfma", "synth_net": "mfma", "splat": "hbm"}
     stages = {}
     for stage, e0, e1, work, _ in rec:
@@ -571,8 +571,8 @@ def main():
         "config": {"arithmetic": ("fp32-equivalent on the bf16 matrix cores: every fp32 operand = 3 exact bf16 parts, 6 products, fp32 "
                                   "accumulate (3x3 convolutions, fused DCN and the three MLPs); everything else fp32" if a.mma == "bf16x3"
                                   else "fp32-equivalent on the 16-bit matrix cores: 3x3 stride-1 convolutions (conv_wino.hip) and the three MLPs with every "
-                                  "fp32 operand = 2 fp16 parts (22+ bits), 3 products, fp32 accumulate; fused DCN and the remaining split "
-                                  "convolutions with 3 exact bf16 parts, 6 products; everything else fp32" if a.mma == "f16x2"
+                                  "fp32 operand = 2 fp16 parts (22+ bits), 3 products, fp32 accumulate, as do the fused DCN's GEMM and the 1x1 layers (conv_pw.hip); "
+                                  "the few remaining split convolutions with 3 exact bf16 parts, 6 products; everything else fp32" if a.mma == "f16x2"
                                   else "fp32 MFMA (v_mfma_f32_32x32x2_f32) and fp32 VALU"),
                    "workload": ("c2" if world == 1 else "c4 (independent c2 clips sharded over %d GPUs as the reference's DistIterSampler strides them: "
                                 "%d clips per GPU in the timed region, %d in total; 8 GPUs x 8 clips = BASELINE configs[3])" % (world, a.steps * a.batch, world * a.steps * a.batch))
