@@ -85,3 +85,42 @@ def test_wide_inline_assembly_stores_are_followed_by_two_wait_states(wino_isa):
         for i in stores:
             nxt = ins[i + 1]
             assert nxt.startswith("s_nop") and int(nxt.split()[1]) >= 1, "conv_wino_kernel<%d, %s>: %s / %s" % (key + (ins[i], nxt))
+
+
+@pytest.fixture(scope="module")
+def other_isa(tmp_path_factory):
+    """Device assembly of the other two-part kernels (compiled side by side)."""
+    if not shutil.which("hipcc"):
+        pytest.skip("hipcc not on PATH")
+    from concurrent.futures import ThreadPoolExecutor
+    d = tmp_path_factory.mktemp("isa2")
+
+    def comp(name):
+        out = d / (name + ".s")
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-value", "-Wno-pass-failed",
+               "-I", CSRC, "-I", os.path.join(ROOT, "include"), "--cuda-device-only", "-S", os.path.join(CSRC, name + ".hip"), "-o", str(out)]
+        subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+        return out.read_text()
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        texts = dict(zip(("conv_pw", "dcn", "siren_split"), ex.map(comp, ("conv_pw", "dcn", "siren_split"))))
+    meta = {}
+    for text in texts.values():
+        for m in re.finditer(r"\.name:\s+(\S+)\s", text):
+            blk = text[max(0, m.start() - 1500):m.end() + 1500]
+            sp, vg = re.search(r"\.vgpr_spill_count:\s+(\d+)", blk), re.search(r"\.vgpr_count:\s+(\d+)", blk)
+            if sp and vg:
+                meta[m.group(1)] = (int(vg.group(1)), int(sp.group(1)))
+    return meta
+
+
+def test_the_shipped_two_part_kernels_do_not_spill(other_isa):
+    """conv_pw_kernel (all cout-tile counts; its first version needed 242 registers and spilled), the window DCN and the three SIREN
+    networks in their two-part forms: no vector-register spills, and the pointwise kernel within the 128 registers that let two
+    8-wave workgroups share a CU."""
+    want = ["_Z14conv_pw_kernelILi%dEEv8ConvArgsiiil" % t for t in (1, 2, 3, 4)] + ["_Z14dcn_win_kernelILi8ELi2EEv12DcnFusedArgs"] + \
+           ["_Z18siren_split_kernelILi%dELi1ELi2EEv9SirenArgs" % m for m in (0, 1, 2, 3)]
+    for k in want:
+        assert k in other_isa, (k, sorted(other_isa)[:40])
+        assert other_isa[k][1] == 0, (k, other_isa[k])
+    for t in (1, 2, 3):
+        assert other_isa["_Z14conv_pw_kernelILi%dEEv8ConvArgsiiil" % t][0] <= 128, other_isa
