@@ -71,6 +71,7 @@ _SIGS = {
     "motif_flow_roundtrip": (c_int, [P, P, c_int, c_long, c_float, c_float, P]),
     "motif_deconv4x4s2": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
 }
+ABI_VERSION = 6          # include/motif_hip.h / api.hip: motif_abi_version()
 EXPORTS = tuple(_SIGS)
 
 

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported_and_bound(lib):
     for s in syms:
         assert hasattr(lib, s), "libmotif_hip.so does not export %s" % s
     assert sorted(_lib.EXPORTS) == syms, "ctypes binding and header disagree: %s" % (set(_lib.EXPORTS) ^ set(syms))
-    assert lib.motif_abi_version() == 6
+    assert lib.motif_abi_version() == 6 == _lib.ABI_VERSION
 
 
 def test_library_is_gfx950_only():
@@ -63,3 +63,10 @@ def test_product_fails_loudly_without_gpu():
     s = synthetic_sample(32, 32, 4, 1)
     with pytest.raises(RuntimeError):
         LunaTokis().eval()(s["LQs"], None, s["time"], s["scale"], use_GT=False, iter=4)
+
+
+def test_graft_entry_build_checks_the_library_it_built():
+    """`__graft_entry__.build()` (the driver's "does it build" step) compiles every kernel source in-tree, loads the library and checks
+    its ABI version and exports against the binding -- it once asserted a stale version number and failed for a whole round unnoticed."""
+    import __graft_entry__ as g
+    g.build()
