@@ -156,7 +156,24 @@ class VideoSRBaseModel(BaseModel):
     def get_current_log(self):
         return self.log_dict
 
+    def ensure_finite(self):
+        """Range guard of the default arithmetic.  "f16x2" has fp16's operand range (|activation| < 3e4): outside it the
+        frames come out NaN / inf -- never silently wrong -- and this renders the clip again with three bf16 parts (fp32's exponent
+        range; the mode stays switched: such data will not fit the next time either).  Costs one device reduction plus the host
+        synchronisation the caller is about to pay anyway (`get_current_visuals`, the PSNR of `motif_amd.test`); the timed loop of
+        bench.py does not call it.  -> True when the clip was re-rendered."""
+        from motif_amd import ops
+        if ops.get_mma() != "f16x2" or bool(torch.isfinite(self.fake_H).all()):
+            return False
+        logger.warning("non-finite frames under the f16x2 arithmetic (operands beyond fp16's range): rendering the clip again with bf16x3")
+        ops.set_mma("bf16x3")
+        if hasattr(self.netG, "clear_cache"):
+            self.netG.clear_cache()
+        self.test()
+        return True
+
     def get_current_visuals(self, need_GT=True):
+        self.ensure_finite()
         out = OrderedDict()
         out["LQ"] = self.var_L.detach()[0].float().cpu()
         out["restore"] = self.fake_H.detach()[0].float().cpu()

@@ -87,6 +87,7 @@ def main():
         model.test()
         nfr = model.real_H.shape[1] - 2
         real_H = model.real_H[:, 1:-1].reshape(b * nfr, 3, H, W)
+        model.ensure_finite()                # f16x2's range guard (VideoSRBaseModel.ensure_finite): a clip beyond fp16's range is rendered again with bf16x3
         fake_H = model.fake_H[:, :, :, 0:H, 0:W].permute(1, 0, 2, 3, 4).reshape(b * nfr, 3, H, W)
         p = util.y_psnr_per_frame(real_H, fake_H)
         psnrs.append(p)

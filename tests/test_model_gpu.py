@@ -774,3 +774,34 @@ def test_generator_matches_oracle_on_odd_shapes(cfg, mma_mode):
     assert out.shape == ref.shape == (T, B, 3, h * scale, w * scale)
     assert psnr(out.cpu(), ref) >= 60.0, psnr(out.cpu(), ref)
     assert float((flow.cpu() - rflow).abs().max()) < 2e-3
+
+
+def test_range_guard_renders_an_out_of_range_clip_again_with_bf16x3(mma_mode):
+    """The default arithmetic has fp16's operand range.  A clip whose activations leave it (here: LR frames scaled by 1e6) must come out
+    non-finite under f16x2 -- loud, never a clamped finite frame -- and `VideoSRBaseModel.ensure_finite()` (called by
+    `get_current_visuals` and by the evaluation driver) must render it again with three bf16 parts, giving exactly the frames a
+    bf16x3 run gives; an ordinary clip is left alone."""
+    if mma_mode != DEFAULT_MMA:
+        pytest.skip("the guard belongs to the default arithmetic")
+    from motif_amd import ops
+    from motif_amd.data.synthetic import synthetic_sample
+    from motif_amd.models import create_model
+    from motif_amd.option import default_opt
+    from motif_amd.utils.synth_weights import fill_state_dict
+    model = create_model(default_opt(scale=4, gpu_ids=[0], mma="f16x2"))
+    fill_state_dict(model.netG)
+    smp = synthetic_sample(32, 48, 4, 3, seed=5)
+    data = {"LQs": smp["LQs"].cuda(), "GT": smp["GT"][:, :1].cuda(), "time": [t.cuda() for t in smp["time"]], "scale": smp["scale"]}
+    try:
+        model.feed_data(data); model.test()
+        assert model.ensure_finite() is False and ops.get_mma() == "f16x2"
+        big = dict(data, LQs=data["LQs"] * 1.0e6)
+        model.feed_data(big); model.test()
+        assert not bool(torch.isfinite(model.fake_H).all()), "activations of 1e5 .. 1e6 must not pass silently through the two-part form"
+        assert model.ensure_finite() is True and ops.get_mma() == "bf16x3"
+        got = model.fake_H.clone()
+        assert bool(torch.isfinite(got).all())
+        model.feed_data(big); model.test()                   # a plain bf16x3 render of the same clip
+        assert torch.equal(model.fake_H, got)
+    finally:
+        ops.set_mma(DEFAULT_MMA)
