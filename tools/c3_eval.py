@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 3 (Vimeo-7 septuplet shape: 7 LR frames 256x448, x4 spatial, x8 temporal = 9 timestamps):
-output agreement and speed of the arithmetic modes (fp32 MFMA, bf16x3 split, bf16x2, plain bf16 convolutions)."""
+output agreement and speed of the arithmetic modes (fp32 MFMA, bf16x3 split, f16x2 split, bf16x2, plain bf16 convolutions)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -27,7 +27,7 @@ def main():
     data = {"LQs": smp["LQs"].cuda(), "GT": smp["GT"][:, :1].cuda(), "time": [t.cuda() for t in smp["time"]], "scale": smp["scale"]}
     print("LQs", tuple(data["LQs"].shape), "timestamps", len(data["time"]))
     outs = {}
-    for mode in ("fp32", "bf16x3", "bf16x2", "bf16"):
+    for mode in ("fp32", "bf16x3", "f16x2", "bf16x2", "bf16"):
         ops.set_mma(mode)
         for _ in range(2):
             model.feed_data(data); model.test()
