@@ -46,6 +46,18 @@ int motif_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 int motif_set_option(const char* name, int value);
 int motif_get_option(const char* name, int* value);
 
+/* Range status word (no reference counterpart: the reference is fp32 end to end, models/modules/Ours.py:419, and asserts where it
+ * matters, models/softsplat_cp.py:25-26).  The two-part fp16 arithmetic (MotifConvDesc.mma = 7, `pre` = 3, DCN mma = 7) has fp16's
+ * operand range: an activation, a transformed activation (up to 2 |x| in the Winograd kernel) or 2^8 x a weight of 65520 or more is
+ * packed as inf, and inf times any weight part -- zero included -- is non-finite, so EVERY output of the affected pixel comes out
+ * inf / NaN.  Downstream stages can launder such values (the fused splat clamps its plane values and drops sources with a
+ * non-finite flow), so the kernels that run the form report it at the source instead: `status` is a caller-owned device uint32
+ * (NULL = no report) into which they atomically OR bit 0 when an accumulator is non-finite.  The word is sticky -- the caller
+ * zeroes it before a clip and reads it after (one 4-byte copy); a set bit means "render this clip again with mma = 6", which has
+ * fp32's exponent range.  Small magnitudes need no report: the low activation part is stored times 2^11 (see mma = 7 below), so the
+ * form is fp32-equivalent for tensors whose magnitude is anywhere from ~3e-5 to 3e4 (tests/test_kernels_gpu.py sweeps 1 .. 1e-4)
+ * and degrades gracefully below that (absolute operand error <= 2^-36). */
+
 /* ------------------------------------------------------------------------------------------------
  * A1-A3  fused soft-splat forward.
  * Replaces the three cupy launches of kernel_Softsplat_updateOutput:
@@ -134,14 +146,17 @@ int motif_siren_flow_fwd(const float* packed, const float* flowfeat_lr, const in
  * -> synth_net -> clamp(0,1) -> frames [N,B,3,HH,WW].  acc as produced by motif_splat_motif_fwd. */
 int motif_siren_synth_fwd(const float* packed, const float* acc, const float* residual_lr,
                           const int32_t* iy, const int32_t* ix, const float* times, float* frames,
-                          int B, int N, int H, int W, int HH, int WW, int pre, void* stream);
+                          int B, int N, int H, int W, int HH, int WW, int pre, uint32_t* status, void* stream);
+/* status (both synth forms; may be NULL): range status word, see above.  Only the first layer of synth_net reads data of
+ * unbounded magnitude (the splat's max plane, its normalised sums); imnet / flow_imnet read coordinates, t and fp32 LR partials,
+ * and every hidden activation is a sine -- they cannot leave fp16's range and take no status argument. */
 /* synth on the pre-contracted accumulator of motif_splat_motif_pre_fwd: pre-activation of the first layer =
  * residual_l0 (the LR partial W0[:, 133:197] . residual + b0, as with pre = 1/2) + acc[0:64] / warped_z +
  * W0[:, 130:133] . extra + W0[:, 197] t, with the exact-equality patches of Ours.py:811-830 on warped_z / count;
  * `packed` from motif_siren_pack_split(kind = 3 [+ 8]).  Split arithmetic only: pre = 2 (three bf16 parts) or 3 (two fp16 parts). */
 int motif_siren_synth_pre_fwd(const float* packed, const float* acc67, const float* residual_l0,
                               const int32_t* iy, const int32_t* ix, const float* times, float* frames,
-                              int B, int N, int H, int W, int HH, int WW, int pre, void* stream);
+                              int B, int N, int H, int W, int HH, int WW, int pre, uint32_t* status, void* stream);
 /* debugging/parity aid: materialise the 198-channel synth input [B*N,198,HH,WW] (Ours.py:839-844). */
 int motif_synth_input_fwd(const float* acc, const float* residual_lr, const int32_t* iy, const int32_t* ix,
                           const float* times, float* out, int B, int N, int H, int W, int HH, int WW, void* stream);
@@ -173,13 +188,23 @@ typedef struct MotifConvDesc {
                                  direct form by one fp32 addition per operand and a three-term output sum (measured
                                  against fp64: not larger than the direct form's error).
                                  7 = as 6, except that the Winograd block and kernel use the TWO-PART fp16 form: every
-                                 operand = hi + lo, hi = rne_fp16(x), lo = rne_fp16(x - hi) (|x - hi - lo| <= 2^-23 |x| while
-                                 both parts are normal fp16 numbers, an absolute 2^-25 below that), three products per
-                                 fp32 MAC instead of six; the weights are packed times 2^8 (so that the low parts of
-                                 everyday weights are normal) and the epilogue multiplies by 2^-8, both exact.  Range:
-                                 |2 x| and 2^8 |1.5 w| must stay below 65504 (fp16), beyond that the result is inf / NaN,
-                                 never a silently clamped value; measured against fp64 its error is at or below mode 6's
-                                 (tests/test_kernels_gpu.py).  Layers the Winograd kernel does not take run as mode 6. */
+                                 operand = hi + lo, hi = rne_fp16(x), three products per fp32 MAC instead of six.  Weights:
+                                 lo = rne_fp16(2^8 w - hi), packed times 2^8 (so that the low parts of everyday weights,
+                                 |w| >= 5e-4, are normal numbers); the epilogue multiplies by 2^-8; both exact.  Activations
+                                 (since ABI 7): the low part is stored times 2^11, lo_s = rne_fp16((x - hi) * 2^11) -- a
+                                 number of hi's own magnitude, hence normal whenever hi is -- and multiplied by 2^-11 x the
+                                 high weight part (exact while normal): |x - hi - 2^-11 lo_s| <= 2^-22 |x| for every
+                                 |x| >= 2^-14, an absolute 2^-36 below that.  Domain: fp32-equivalent (error at or below an
+                                 fp32 MFMA's, tests/test_kernels_gpu.py: activation scales 1 .. 1e-4, weight scales 1/24,
+                                 1e-2) for tensors of magnitude ~3e-5 .. 3e4.  Above: |2 x| or 2^8 |1.5 w| >= 65520 gives
+                                 inf / NaN in every cout of the pixel, never a clamped value, AND sets `status` (below).
+                                 Which layers run the form: 3x3 / stride-1 / zero-pad layers the Winograd kernel takes
+                                 (conv_wino.hip: > 16 input channels per group, W % 4 == 0, aligned tensors) and 1x1 /
+                                 stride-1 / groups-1 layers with 17 .. 128 couts and >= 8 input channels (conv_pw.hip, same
+                                 arithmetic, reads the fp32 blob); option conv_engine = 6 disables both.  Every other layer
+                                 of a mode-7 network runs as mode 6 (3x3 split-eligible) or mode 0. */
+    uint32_t* status;         /* device word (may be NULL), see "Range status word" below: kernels running the two-part fp16
+                                 form OR bit 0 into it when an accumulator comes out non-finite (an operand beyond fp16's range) */
 } MotifConvDesc;
 
 long motif_conv2d_packed_size(const MotifConvDesc* d);
@@ -220,11 +245,11 @@ int motif_dcn_v2_fwd_multi(int P, const float* const* input, const long* input_b
 int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, const long* input_bs, const float* const* offset,
                                  const float* const* mask, const float* const* packed3x3, const float* const* bias,
                                  float* const* out, int B, int C, int H, int W, int Cout, int deformable_groups,
-                                 long offset_bs, long mask_bs, int act, int mma, void* stream);
+                                 long offset_bs, long mask_bs, int act, int mma, uint32_t* status, void* stream);
 /* mma = 0: `packed3x3` as above, fp32 MFMA.  mma = 6: the GEMM on the bf16 matrix cores with the fp32-equivalent 3-way split
  * (MotifConvDesc.mma), `packed3x3` from motif_dcn_split_pack (size query with packed = NULL; returns floats).  mma = 7: the two-part
- * fp16 form (three products, weights x 2^8: MotifConvDesc.mma = 7) in the window kernel, mma = 6 where that kernel does not apply; the
- * blob of motif_dcn_split_pack holds both fragment blocks. */
+ * fp16 form (three products, weights x 2^8, low activation part x 2^11: MotifConvDesc.mma = 7) in the window kernel, mma = 6 where that
+ * kernel does not apply; the blob of motif_dcn_split_pack holds both fragment blocks.  status: range status word (may be NULL). */
 long motif_dcn_split_pack(const float* weight /*[Cout,C,3,3]*/, float* packed, int Cout, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@ class MotifConvDesc(Structure):
                 ("Cout", c_int), ("KH", c_int), ("KW", c_int),
                 ("stride", c_int), ("pad", c_int), ("dil", c_int), ("groups", c_int),
                 ("pad_mode", c_int), ("act", c_int), ("act2", c_int), ("act_split", c_int), ("res_mode", c_int),
-                ("in0_bs", c_long), ("in1_bs", c_long), ("res_bs", c_long), ("out_bs", c_long), ("mma", c_int)]
+                ("in0_bs", c_long), ("in1_bs", c_long), ("res_bs", c_long), ("out_bs", c_long), ("mma", c_int), ("status", c_void_p)]
 
 
 P = c_void_p
@@ -31,7 +31,7 @@ _SIGS = {
     "motif_splat_motif_fwd": (c_int, [P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_splat_motif_acc_fwd": (c_int, [P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_splat_motif_pre_fwd": (c_int, [P, P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "motif_siren_synth_pre_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "motif_siren_synth_pre_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "motif_reliability_pairs_fwd": (c_int, [P, c_long, c_long, P, P, POINTER(c_int), POINTER(c_float), c_int, c_int, P, P, c_int, c_int, c_int, P]),
     "motif_siren_pack": (c_long, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), c_int, P, P]),
     "motif_frames_u8_to_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
@@ -40,7 +40,7 @@ _SIGS = {
     "motif_siren_imnet_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_siren_imnet_add_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_siren_flow_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "motif_siren_synth_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "motif_siren_synth_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "motif_synth_input_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_conv2d_packed_size": (c_long, [POINTER(MotifConvDesc)]),
     "motif_conv2d_pack": (c_int, [POINTER(MotifConvDesc), P, P, P]),
@@ -50,7 +50,7 @@ _SIGS = {
                                + [c_int] * 11 + [c_long, c_long, c_int, P]),
     "motif_dcn_v2_fwd": (c_int, [P, P, P, P, P, P, P] + [c_int] * 11 + [c_long, c_long, c_int, P]),
     "motif_dcn_v2_fused_fwd_multi": (c_int, [c_int, POINTER(c_void_p), POINTER(c_long)] + [POINTER(c_void_p)] * 5
-                                     + [c_int] * 6 + [c_long, c_long, c_int, c_int, P]),
+                                     + [c_int] * 6 + [c_long, c_long, c_int, c_int, P, P]),
     "motif_dcn_split_pack": (c_long, [P, P, c_int, c_int, P]),
     "motif_raft_corr_lookup": (c_int, [P, P, P, c_float, P] + [c_int] * 7 + [c_int, c_int, c_float, P]),
     "motif_raft_corr_lookup_pyramid": (c_int, [P, POINTER(c_void_p), POINTER(c_int), POINTER(c_int), c_int, P, P] + [c_int] * 6 + [c_float, P]),
@@ -71,7 +71,7 @@ _SIGS = {
     "motif_flow_roundtrip": (c_int, [P, P, c_int, c_long, c_float, c_float, P]),
     "motif_deconv4x4s2": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
 }
-ABI_VERSION = 6          # include/motif_hip.h / api.hip: motif_abi_version()
+ABI_VERSION = 7          # include/motif_hip.h / api.hip: motif_abi_version()
 EXPORTS = tuple(_SIGS)
 
 

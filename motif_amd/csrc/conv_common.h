@@ -16,6 +16,7 @@ struct ConvArgs {
     int CK, PH, PW, Kpad, tiles_x, ncg;
     int xoff;  // conv_igemm VEC staging: the LDS patch rows start xoff pixels left of the patch (16-byte aligned loads), PW = their pitch
     int dbg;   // tuning aid: 1 = skip staging, 2 = skip MFMA loop
+    unsigned* status;   // MotifConvDesc.status: the fp16-form kernels OR bit 0 into it on a non-finite accumulator (may be null)
 };
 
 // Limits of one reduction chunk (host planner keeps to them): patch elements <= PATCH_MAX, packed weight

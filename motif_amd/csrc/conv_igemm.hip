@@ -372,6 +372,7 @@ extern "C" int motif_conv2d_fwd_multi(const MotifConvDesc* d, int P, const float
     }
     a.N = d->N;
     a.dbg = motif_opt(MOTIF_OPT_CONV_DBG);
+    a.status = d->status;
     if (split) {
         a.C0 = d->C0; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
         a.KH = 3; a.KW = 3; a.stride = 1; a.pad = d->pad; a.dil = 1; a.pad_mode = d->pad_mode;

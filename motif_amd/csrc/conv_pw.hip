@@ -8,7 +8,11 @@
 // step's 8 loads in flight, splits the values into two fp16 parts (4 instructions per pair) and issues 3 MFMAs per cout tile and step.
 // The weights are read from the layer's ordinary fp32 packed block (motif_conv2d_pack: nothing new in the blob), multiplied by 2^8,
 // split and laid out as A fragments in LDS once per workgroup (<= 80 KB); 8 waves per workgroup, two workgroups per CU, so that other
-// waves' loads cover a wave's latency.  Arithmetic, range and the 2^-8 in the epilogue: see conv_wino.hip.
+// waves' loads cover a wave's latency.  Arithmetic, range and the 2^-8 in the epilogue: see conv_wino.hip -- including the round-5 form of
+// the low ACTIVATION part (stored times 2^11, multiplied by the high weight part times 2^-11, so that it is a normal fp16 number whenever
+// the high part is) and the range status word (a non-finite accumulator ORs bit 0 into MotifConvDesc.status).
+// Every per-plane byte offset of a buffer access is part of the VECTOR offset: the scalar offset operand is outside the hardware range
+// check, and the kernel relies on that check for channels past Cin, couts past Cout and the masked lanes of a ragged last group.
 #include "conv_common.h"
 
 typedef _Float16 pw_f16x2 __attribute__((ext_vector_type(2)));
@@ -17,11 +21,24 @@ typedef unsigned pw_u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 constexpr int PW_WAVES = 8, PW_MAXT = 4;                // waves per workgroup, cout tiles of 32 per wave
-constexpr float kPwScale = 256.f;
+constexpr float kPwScale = 256.f, kPwLoScale = 2048.f;
 
 __device__ __forceinline__ unsigned pw_pk(float a, float b) { const pw_f16x2 h = {(_Float16)a, (_Float16)b}; return __builtin_bit_cast(unsigned, h); }
 __device__ __forceinline__ float pw_sub_lo(float x, unsigned pk) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x)); return r; }
 __device__ __forceinline__ float pw_sub_hi(float x, unsigned pk) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x)); return r; }
+// activations: hi = rne(x), lo = rne((x - hi) * 2^11) -- one rounding (v_fma_mixlo / mixhi_f16)
+__device__ __forceinline__ void pw_split8_act(const float (&v)[8], pw_u32x4& hi, pw_u32x4& lo, float s) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        hi[q] = pw_pk(v[2 * q], v[2 * q + 1]);
+        const float r0 = pw_sub_lo(v[2 * q], hi[q]), r1 = pw_sub_hi(v[2 * q + 1], hi[q]);
+        unsigned d;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(d) : "v"(r0), "s"(s));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(r1), "s"(s));
+        lo[q] = d;
+    }
+}
+__device__ __forceinline__ unsigned pw_pk_mul(unsigned a, pw_f16x2 c) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(pw_f16x2, a) * c); }
 __device__ __forceinline__ void pw_split8(const float (&v)[8], pw_u32x4& hi, pw_u32x4& lo) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -67,6 +84,9 @@ __global__ __launch_bounds__(64 * PW_WAVES) void conv_pw_kernel(ConvArgs a, int 
     float* out = a.out[pz];
     const pw_u32x4* wl = pw_lds + lane;
     const unsigned HW4 = (unsigned)HW * 4u;
+    float lo_scale = kPwLoScale;
+    asm volatile("" : "+s"(lo_scale));
+    const pw_f16x2 ws_c = {(_Float16)(1.f / kPwLoScale), (_Float16)(1.f / kPwLoScale)};
     for (long g = (long)blockIdx.x * PW_WAVES + wave; g < ngroups; g += (long)gridDim.x * PW_WAVES) {
         const int img = (int)(g / groups_per_img);
         const long p0 = (g - (long)img * groups_per_img) * 32;
@@ -83,7 +103,7 @@ __global__ __launch_bounds__(64 * PW_WAVES) void conv_pw_kernel(ConvArgs a, int 
             const __amdgpu_buffer_rsrc_t rs = first ? r0 : r1;
             const unsigned vo = poff + (unsigned)(first ? c : c - C0) * HW4;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vo, (int)((unsigned)e * HW4), 0));
+            for (int e = 0; e < 8; ++e) v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(vo + (unsigned)e * HW4), 0, 0));
         };
         f32x16 acc[MT];
 #pragma unroll
@@ -95,13 +115,16 @@ __global__ __launch_bounds__(64 * PW_WAVES) void conv_pw_kernel(ConvArgs a, int 
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + 1 < KS) fetch(ks + 1, nxt);
             pw_u32x4 hi, lo;
-            pw_split8(cur, hi, lo);
+            pw_split8_act(cur, hi, lo, lo_scale);
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 const pw_u32x4 whi = wl[((ks * 2 + 0) * MT + t) * 64], wlo = wl[((ks * 2 + 1) * MT + t) * 64];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pw_f16x8, whi), __builtin_bit_cast(pw_f16x8, lo), acc[t], 0, 0, 0);
+                pw_u32x4 whs;                            // 2^-11 x the high weight part (exact while normal): the partner of the scaled low activation part
+#pragma unroll
+                for (int q = 0; q < 4; ++q) whs[q] = pw_pk_mul(whi[q], ws_c);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pw_f16x8, wlo), __builtin_bit_cast(pw_f16x8, hi), acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pw_f16x8, whi), __builtin_bit_cast(pw_f16x8, hi), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pw_f16x8, whs), __builtin_bit_cast(pw_f16x8, lo), acc[t], 0, 0, 0);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) cur[e] = nxt[e];
@@ -113,6 +136,9 @@ __global__ __launch_bounds__(64 * PW_WAVES) void conv_pw_kernel(ConvArgs a, int 
         const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(res ? res + (long)img * res_bs : out), 0, res ? Cout * (int)HW4 : 0, 0x00020000);
         const unsigned eoff = valid ? (unsigned)p * 4u + (unsigned)(4 * hf) * HW4 : 0x80000000u;
         const int rm = a.res_mode, act = a.act;
+        // range status word: an operand beyond fp16's range is packed as inf and makes EVERY cout of its pixel non-finite (inf x 0 = NaN):
+        // register 0 of tile 0 (couts 0 / 4 x the group's 32 pixels) sees them all
+        if (a.status && __builtin_amdgcn_class(acc[0][0], 0x207)) atomicOr(a.status, 1u);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             __builtin_amdgcn_sched_barrier(0);           // one cout tile at a time (keeps the other tiles' residual values out of the registers)
@@ -120,7 +146,7 @@ __global__ __launch_bounds__(64 * PW_WAVES) void conv_pw_kernel(ConvArgs a, int 
             if (rm) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)eoff, (int)((unsigned)(32 * t + (r & 3) + 8 * (r >> 2)) * HW4), 0));
+                    rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)(eoff + (unsigned)(32 * t + (r & 3) + 8 * (r >> 2)) * HW4), 0, 0));
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -130,7 +156,7 @@ __global__ __launch_bounds__(64 * PW_WAVES) void conv_pw_kernel(ConvArgs a, int 
                 if (act == MOTIF_ACT_RELU) v = v > 0.f ? v : 0.f;
                 else if (act == MOTIF_ACT_LRELU) v = v > 0.f ? v : 0.1f * v;
                 if (rm == 2) v += rv[r];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, (int)eoff, (int)((unsigned)(32 * t + (r & 3) + 8 * (r >> 2)) * HW4), 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, (int)(eoff + (unsigned)(32 * t + (r & 3) + 8 * (r >> 2)) * HW4), 0, 0);
             }
         }
     }

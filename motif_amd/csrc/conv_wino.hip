@@ -75,10 +75,13 @@ template <> struct WOrder<3> {
     static constexpr int w[6] = {0, 1, 0, 2, 1, 0};
     static constexpr int x[6] = {2, 1, 1, 0, 0, 0};
 };
+//         Round 5: the low activation part is stored times 2^11 (lo_s = rne((x - hi) * 2^11): a number of hi's own magnitude, so it is a
+//         NORMAL fp16 number whenever hi is -- unscaled it was a subnormal, an absolute 2^-25, for every |x| < 0.25) and multiplied by the
+//         high weight part times 2^-11 (weight "part" 2: formed in registers by four v_pk_mul_f16 per fragment, exact while normal).
 template <> struct WOrder<2> {
     static constexpr int n = 3;
-    static constexpr int w[3] = {0, 1, 0};
-    static constexpr int x[3] = {1, 0, 0};
+    static constexpr int w[3] = {1, 0, 2};
+    static constexpr int x[3] = {0, 0, 1};
 };
 
 enum { WP_PARK = 2, WP_READ = 3, WP_X = 4, WP_W = 5, WP_HREAD = 6, WP_HX = 7, WP_HW = 8, WP_READ2 = 9 };
@@ -101,14 +104,14 @@ enum { WP_PARK = 2, WP_READ = 3, WP_X = 4, WP_W = 5, WP_HREAD = 6, WP_HX = 7, WP
 template <int NP>
 struct WSched {
     static constexpr int SS = 6, M = 4 * WOrder<NP>::n, S = SS * M, NLD = 10;
-    static constexpr int XS = NP == 3 ? 13 : 6;          // transform / split stages per position (st_x)
+    static constexpr int XS = NP == 3 ? 13 : 7;          // transform / split stages per position (st_x)
     static constexpr int HXS = NP == 3 ? 4 : 3;          // ... of the halo item (st_hx)
     int rb[S], ra[S], rl[S], ext[S], used, clash;
     constexpr WSched() : rb(), ra(), rl(), ext(), used(0), clash(0) {
         using O = WOrder<NP>;
         for (int s = 0; s < S; ++s) { rb[s] = -1; ra[s] = -1; rl[s] = -1; ext[s] = 0; }
         int lastx[NP] = {}, lastw[NP] = {};                                   // last product reading activation / weight part p
-        for (int k = 0; k < O::n; ++k) { lastx[O::x[k]] = k; lastw[O::w[k]] = k; }
+        for (int k = 0; k < O::n; ++k) { lastx[O::x[k]] = k; if (O::w[k] < NP) lastw[O::w[k]] = k; }
         for (int ss = 0; ss < SS; ++ss) {
             if (ss + 1 < SS)
                 for (int p = 0; p < NP; ++p)
@@ -176,6 +179,11 @@ __device__ __forceinline__ float sub_f16_hi(float x, unsigned pk) { float r; asm
 // the weights of the two-part form are packed times 2^8 (a weight of everyday magnitude 1e-3 .. 1 then has BOTH its parts in fp16's
 // normal range; 2^8 |U| must stay below 65504, U = the transformed kernel rows of the header), the epilogue multiplies by 2^-8 (exact)
 constexpr float kWinoF16Scale = 256.f;
+// (a, b) * s -> packed fp16 pair, ONE rounding each (v_fma_mixlo / mixhi_f16: fp32 a * fp32 s + 0 -> fp16): the low activation part times 2^11
+__device__ __forceinline__ void pk_f16_scaled_lo(unsigned& d, float a, float s) { asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(d) : "v"(a), "s"(s)); }
+__device__ __forceinline__ void pk_f16_scaled_hi(unsigned& d, float b, float s) { asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(b), "s"(s)); }
+constexpr float kWinoLoScale = 2048.f;                  // 2^11: |x - hi| <= 2^-11 |x|, so the scaled low part never exceeds |x|
+__device__ __forceinline__ unsigned pk_mul_f16(unsigned a, f16x2v c) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2v, a) * c); }
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) -- every slot of the schedule is its own
 // instantiation (the loop unroller's size estimate, taken before the dispatch on the slot's piece is folded, refuses 144 slots)
@@ -354,6 +362,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         sv[row][q] = landf[mrd + ((row * 2) * 8 + q) * 40];
         sv[row][q + 1] = landf[mrd + ((row * 2) * 8 + q + 1) * 40];
     };
+    float lo_scale = kWinoLoScale;                      // in a scalar register (the mix instructions take no literal)
+    asm volatile("" : "+s"(lo_scale));
     float xv[8] = {}, xe[8] = {};
     unsigned xpk[4] = {};
     u32x4 sparts[NP] = {};
@@ -380,7 +390,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (st == 3 || st == 4) {                     // remainder after the first part: one mixed-precision FMA per value
 #pragma unroll
                 for (int q = 2 * (st - 3); q < 2 * (st - 3) + 2; ++q) { xv[2 * q] = sub_f16_lo(xv[2 * q], xpk[q]); xv[2 * q + 1] = sub_f16_hi(xv[2 * q + 1], xpk[q]); }
-            } else if (st == 5) pack(1);
+            } else if (st == 5) {                         // low part times 2^11, one rounding (see WOrder<2>)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pk_f16_scaled_lo(xpk[q], xv[2 * q], lo_scale);
+            } else if (st == 6) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { pk_f16_scaled_hi(xpk[q], xv[2 * q + 1], lo_scale); sparts[1][q] = xpk[q]; }
+            }
         } else {
             if (st == 3 || st == 4) expand(st - 3);
             else if (st == 5 || st == 6) sub(st - 5);
@@ -408,7 +424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 hparts[0] = hpk;
             } else if (h == 1) {
                 hv0 = sub_f16_lo(hv0, hpk); hv1 = sub_f16_hi(hv1, hpk);
-            } else hparts[1] = pk_f16(hv0, hv1);
+            } else { pk_f16_scaled_lo(hpk, hv0, lo_scale); pk_f16_scaled_hi(hpk, hv1, lo_scale); hparts[1] = hpk; }
         } else if (h == 0) {
             hv0 = __builtin_fmaf(h_sgn, hb0, ha0); hv1 = __builtin_fmaf(h_sgn, hb1, ha1);   // a +- b: the product by +-1 is exact
             hpk = pk_bf16(hv0, hv1);
@@ -440,6 +456,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int WB = 3;                                // weight fragment sets: a set is refilled for three super-steps ahead while in use
     u32x4 wf[WB][2][NP];                                 // [set][position of the pair][weight part]
     u32x4 bfr[NP][4];                                    // [activation part][position of the pair * 2 + row pair]: ONE copy
+    u32x4 ws[2] = {};                                    // two-part form: 2^-11 x the high weight fragment of the current super-step, per position of the pair
+    f16x2v ws_c = {(_Float16)(1.f / kWinoLoScale), (_Float16)(1.f / kWinoLoScale)};
+    asm volatile("" : "+v"(ws_c));
     __amdgpu_buffer_rsrc_t wbase, wnext;
     auto wks = [](int ss, int pi) __attribute__((always_inline)) { return (2 * (ss / 3) + pi) * 3 + ss % 3; };   // packed k-step (position, kx) within a chunk
     auto loadw = [&](__amdgpu_buffer_rsrc_t wb, int ss, u32x4 (&dst)[2][NP]) __attribute__((always_inline)) {
@@ -478,11 +497,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
             if constexpr (!(WINO_ABL & 1024) && (!(WINO_ABL & 512) || (k & 1)))
             {
-                if constexpr (NP == 2) acc[tl][pos] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[ss % WB][pi][WO::w[k]]),
+                if constexpr (NP == 2) acc[tl][pos] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, WO::w[k] == 2 ? ws[pi] : wf[ss % WB][pi][WO::w[k] & 1]),
                                                                                             __builtin_bit_cast(f16x8, bfr[WO::x[k]][j]), acc[tl][pos], 0, 0, 0);
                 else acc[tl][pos] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ss % WB][pi][WO::w[k]]),
                                                                             __builtin_bit_cast(bf16x8, bfr[WO::x[k]][j]), acc[tl][pos], 0, 0, 0);
             }
+            // two-part form: quad m & 3 of the scaled high weight fragment of position m >> 2, one v_pk_mul_f16 per slot, in front of the
+            // request that refills the fragment's registers (slots 5 / 7) and of the products that read it (MFMAs 8 .. 11)
+            if constexpr (NP == 2 && m < 8) ws[m >> 2][m & 3] = pk_mul_f16(wf[ss % WB][m >> 2][0][m & 3], ws_c);
             if constexpr (kWSchedOf<NP>.rb[s] >= 0 && !(WINO_ABL & 64)) loadb(ss + 1, kWSchedOf<NP>.rb[s] >> 2, kWSchedOf<NP>.rb[s] & 3);
             if constexpr (kWSchedOf<NP>.ra[s] >= 0 && !(WINO_ABL & 128)) {
                 constexpr int qi = kWSchedOf<NP>.ra[s] / NP, p = kWSchedOf<NP>.ra[s] % NP;
@@ -584,6 +606,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr int AC = decltype(ac_tag)::value, RM = decltype(rm_tag)::value;
             const int rmv = RM >= 0 ? RM : rm;
             const unsigned long long obq = obp;
+            const unsigned long long stp = (unsigned long long)a.status;
             write_pass(0);
             EPSTAMP();
             // every residual quad is waited for BEFORE the first (uncounted) store: behind a store the counted wait of a later quad
@@ -596,6 +619,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 f32x4 v[4];
 #pragma unroll
                 for (int it = 0; it < 4; ++it) v[it] = *(const f32x4*)(scr + (pass & 1) * 1024 + er + it * 256);
+                if constexpr (NP == 2) {
+                    // Range status word (MotifConvDesc.status).  An operand beyond fp16's range is packed as inf, and inf times ANY weight
+                    // (0 included) is non-finite: every cout of the pixel comes out inf / NaN, so item 0 of pass 0 (couts 0 / 1 x the wave's
+                    // 4 rows x 32 pixels) sees every pixel of the tile.  Fire-and-forget atomic as inline assembly (invisible to the
+                    // wait-count pass, like the stores below); the branch is not taken on in-range data.
+                    if (pass == 0 && stp) {
+                        const bool bad = __builtin_amdgcn_class(v[0][0], 0x207) | __builtin_amdgcn_class(v[0][1], 0x207) |
+                                         __builtin_amdgcn_class(v[0][2], 0x207) | __builtin_amdgcn_class(v[0][3], 0x207);
+                        // s_nop: the pointer may have just been written to its scalar registers by a vector instruction (v_readlane of a spilled
+                        // value): five wait states before a memory instruction may read it -- hipcc counts them for its own instructions only
+                        if (bad) asm volatile("s_nop 5\n\tglobal_atomic_or %0, %1, %2" :: "v"(0u), "v"(1u), "s"(stp) : "memory");
+                    }
+                }
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     if constexpr (NP == 2) v[it] *= 1.f / kWinoF16Scale;

@@ -123,6 +123,7 @@ struct DcnFusedArgs {
     long offset_bs, mask_bs;
     int B, C, H, W, Cout, dg, act, ncg, Kpad, tiles_x;
     int front_pad;
+    unsigned* status;        // range status word (include/motif_hip.h): the two-part fp16 form ORs bit 0 into it on a non-finite accumulator
 };
 
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
@@ -155,7 +156,8 @@ __device__ __forceinline__ void dcn_split8(const float (&v)[8], dcn_u32x4 (&out)
 
 // Two-part fp16 form of the window kernel's GEMM (round 4, MotifConvDesc.mma = 7 semantics: conv_wino.hip's header): hi = rne_fp16(x),
 // lo = rne_fp16(x - hi), three products instead of six; the weights are packed times 2^8, the epilogue multiplies by 2^-8.  The sampled
-// values are bilinear blends of feature values times a sigmoid mask: the range of the features.
+// values are bilinear blends of feature values times a sigmoid mask: the range of the features.  Round 5: the low activation part is
+// stored times 2^11 and multiplied by 2^-11 x the high weight part (conv_wino.hip, WOrder<2>): a normal fp16 number whenever hi is one.
 typedef _Float16 dcn_f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 dcn_f16x8 __attribute__((ext_vector_type(8)));
 constexpr float kDcnF16Scale = 256.f;
@@ -164,11 +166,17 @@ __device__ constexpr int DCN_PX2[3] = {0, 1, 0};
 __device__ __forceinline__ unsigned dcn_pk_f16(float a, float b) { const dcn_f16x2 h = {(_Float16)a, (_Float16)b}; return __builtin_bit_cast(unsigned, h); }
 __device__ __forceinline__ float dcn_sub_lo(float x, unsigned pk) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x)); return r; }
 __device__ __forceinline__ float dcn_sub_hi(float x, unsigned pk) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x)); return r; }
-__device__ __forceinline__ void dcn_split8_f16(const float (&v)[8], dcn_u32x4 (&out)[2]) {
+constexpr float kDcnLoScale = 2048.f;
+__device__ __forceinline__ unsigned dcn_pk_mul(unsigned a, dcn_f16x2 c) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(dcn_f16x2, a) * c); }
+__device__ __forceinline__ void dcn_split8_f16(const float (&v)[8], dcn_u32x4 (&out)[2], float s) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         out[0][q] = dcn_pk_f16(v[2 * q], v[2 * q + 1]);
-        out[1][q] = dcn_pk_f16(dcn_sub_lo(v[2 * q], out[0][q]), dcn_sub_hi(v[2 * q + 1], out[0][q]));
+        const float r0 = dcn_sub_lo(v[2 * q], out[0][q]), r1 = dcn_sub_hi(v[2 * q + 1], out[0][q]);
+        unsigned d;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(d) : "v"(r0), "s"(s));      // rne((x - hi) * 2^11), one rounding
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(r1), "s"(s));
+        out[1][q] = d;
     }
 }
 
@@ -485,6 +493,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
     const float* wbase = a.wp[pz] + (NP == 2 ? (long)a.ncg * (a.C / DF_CH) * (3 * 3 * 2 * 64 * 4) : 0L) + (long)cg * (a.C / DF_CH) * WCH;
     const int cpg = a.C / a.dg;
     const int wy0 = ty * TH - DW_R, wx0 = tx * 32 - DW_R;
+    float lo_scale = kDcnLoScale;                        // scalar register: the mix instructions take no literal
+    asm volatile("" : "+s"(lo_scale));
+    const dcn_f16x2 ws_c = {(_Float16)(1.f / kDcnLoScale), (_Float16)(1.f / kDcnLoScale)};
 
     const int pxl = tid % NPX;
     const int oy = ty * TH + (pxl >> 5), ox = tx * 32 + (pxl & 31);
@@ -718,17 +729,24 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
                         if (ks == 2 && r >= DF_ROWS) v[e] = 0.f;
                     }
                     dcn_u32x4 x[NP];
-                    if constexpr (NP == 2) dcn_split8_f16(v, x); else dcn_split8(v, x);
+                    if constexpr (NP == 2) dcn_split8_f16(v, x, lo_scale); else dcn_split8(v, x);
                     dcn_u32x4 w[2][NP];
 #pragma unroll
                     for (int part = 0; part < NP; ++part)
 #pragma unroll
                         for (int t = 0; t < 2; ++t) w[t][part] = wfr[((ks * NP + part) * 2 + t) * 64];
+                    dcn_u32x4 whs[2];                     // two-part form: 2^-11 x the high weight part, the partner of the scaled low activation part
+                    if constexpr (NP == 2) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) whs[t][q] = dcn_pk_mul(w[t][0][q], ws_c);
+                    }
 #pragma unroll
                     for (int k = 0; k < (NP == 2 ? 3 : 6); ++k)
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
-                            if constexpr (NP == 2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dcn_f16x8, w[t][DCN_PW2[k]]),
+                            if constexpr (NP == 2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dcn_f16x8, DCN_PX2[k] == 1 ? whs[t] : w[t][DCN_PW2[k]]),
                                                                                                    __builtin_bit_cast(dcn_f16x8, x[DCN_PX2[k]]), acc[t], 0, 0, 0);
                             else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dcn_bf16x8, w[t][DCN_PW[k]]),
                                                                                    __builtin_bit_cast(dcn_bf16x8, x[DCN_PX[k]]), acc[t], 0, 0, 0);
@@ -761,6 +779,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 
     const int eox = tx * 32 + l31, eoy = ty * TH + wave;
     if (eox >= W || eoy >= H) return;
+    // range status word: an operand beyond fp16's range is packed as inf and makes every cout of its pixel non-finite
+    if constexpr (NP == 2) { if (a.status && __builtin_amdgcn_class(acc[0][0], 0x207)) atomicOr(a.status, 1u); }
     float* op = a.out[pz] + ((long)b * a.Cout + (long)cg * 64) * HW + (long)eoy * W + eox;
     const int climit = a.Cout - cg * 64;
 #pragma unroll
@@ -778,7 +798,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 extern "C" int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, const long* input_bs, const float* const* offset,
                                             const float* const* mask, const float* const* packed3x3, const float* const* bias,
                                             float* const* out, int B, int C, int H, int W, int Cout, int deformable_groups,
-                                            long offset_bs, long mask_bs, int act, int mma, void* stream) {
+                                            long offset_bs, long mask_bs, int act, int mma, uint32_t* status, void* stream) {
     if (P < 1 || P > 4 || !input || !offset || !mask || !packed3x3 || !out || B < 1) return MOTIF_EINVAL;
     if (mma != 0 && mma != 6 && mma != 7) return MOTIF_EINVAL;      // 7: two fp16 parts in the window kernel, three bf16 parts in the fallback form
     if (deformable_groups < 1 || C % deformable_groups || (C / deformable_groups) % DF_CH || (long)H * W >= (1L << 30)) return MOTIF_ELIMIT;
@@ -799,6 +819,7 @@ extern "C" int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, co
     a.ncg = (Cout + 63) / 64;
     a.Kpad = 2 * 9 * ((C + 1) / 2);
     a.tiles_x = (W + 31) / 32;
+    a.status = status;
     // 4-wave blocks (two 74 KB blocks per CU whose gather latencies and MFMA stretches overlap; 11 % faster than one 8-wave
     // block on the 180x320 maps) where the map is large enough to fill the chip that way, else 8-wave blocks.
     // History: in round 1 the 4-wave form was seen to produce sporadic wrong tile rows beside conv_split blocks of another

@@ -505,18 +505,20 @@ extern "C" int motif_siren_flow_fwd(const float* packed, const float* flowfeat_l
 
 extern "C" int motif_siren_synth_fwd(const float* packed, const float* acc, const float* residual_lr,
                                      const int32_t* iy, const int32_t* ix, const float* times, float* frames,
-                                     int B, int N, int H, int W, int HH, int WW, int pre, void* stream) {
+                                     int B, int N, int H, int W, int HH, int WW, int pre, uint32_t* status, void* stream) {
     if (!packed || !acc || !residual_lr || !iy || !ix || !times || !frames || B < 1 || N < 1) return MOTIF_EINVAL;
     SirenArgs a{packed, residual_lr, acc, iy, ix, nullptr, nullptr, times, frames, B * N, N, B, H, W, HH, WW};
+    a.status = status;
     if (pre == 2 || pre == 3) return motif_siren_split_launch(MODE_SYNTH, a, stream, pre == 3 ? 2 : 3);
     return pre ? launch_siren<MODE_SYNTH, SIREN_TP_SYNTH, true>(a, stream) : launch_siren<MODE_SYNTH, SIREN_TP_SYNTH, false>(a, stream);
 }
 
 extern "C" int motif_siren_synth_pre_fwd(const float* packed, const float* acc, const float* residual_l0,
                                          const int32_t* iy, const int32_t* ix, const float* times, float* frames,
-                                         int B, int N, int H, int W, int HH, int WW, int pre, void* stream) {
+                                         int B, int N, int H, int W, int HH, int WW, int pre, uint32_t* status, void* stream) {
     if (!packed || !acc || !residual_l0 || !iy || !ix || !times || !frames || B < 1 || N < 1 || (pre != 2 && pre != 3)) return MOTIF_EINVAL;
     SirenArgs a{packed, residual_l0, acc, iy, ix, nullptr, nullptr, times, frames, B * N, N, B, H, W, HH, WW};
+    a.status = status;
     return motif_siren_split_launch(MODE_SYNTHC, a, stream, pre == 3 ? 2 : 3);
 }
 

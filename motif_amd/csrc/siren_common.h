@@ -86,6 +86,7 @@ struct SirenArgs {
     int stagger;                  // start offset of the second wave per SIMD, in s_sleep(127) units (~8k cycles)
     const float* add_lr;          // imnet, split engine: optional LR tensor [NB,64,H,W] gathered like src_lr and ADDED to the output planes
                                   // (the pre-contracted splat's G term: motif_siren_imnet_add_fwd); last so that older initialisers leave it null
+    unsigned* status;             // synth, two-part fp16 form: range status word (include/motif_hip.h), bit 0 ORed in when a frame value is non-finite
 };
 
 enum { MODE_IMNET = 0, MODE_FLOW = 1, MODE_SYNTH = 2, MODE_SYNTHC = 3 };   // SYNTHC: first layer pre-contracted into the splat (siren_split.hip)

@@ -156,11 +156,50 @@ __device__ __forceinline__ void mfma_step(const u32x4 (&w)[MT][NP], const u32x4 
                 acc[p][t] = mfma16<NP>(w[t][SProd<NP>::w[k]], x[p][SProd<NP>::x[k]], acc[p][t]);
 }
 
+// First-layer k-steps: their inputs are not sines but network data of any magnitude (coordinates, t, splat statistics, in the literal
+// synth form the normalised feature sums), so the two-part form uses the scaled low part of conv_wino.hip (round 5): the activation is
+// split by split8_in (lo_s = rne((x - hi) * 2^11): a normal fp16 number whenever hi is one) and lo_s meets 2^-11 x the high weight part,
+// formed here by four v_pk_mul_f16 per fragment (exact while normal).  The hidden layers keep the plain split: their inputs are sines,
+// |x| <= 1, and the plain low part's absolute error of 2^-25 is then below fp32's own rounding of the operand.
+constexpr float kSirenLoScale = 2048.f;
+__device__ __forceinline__ unsigned pk_mul_f16(unsigned a, f16x2v c) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2v, a) * c); }
+template <int NP>
+__device__ __forceinline__ void split8_in(const float (&v)[8], u32x4 (&out)[NP]) {
+    if constexpr (NP == 2) {
+        float s = kSirenLoScale;
+        asm volatile("" : "+s"(s));                      // scalar register: the mix instructions take no literal
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned hi = pk_f16(v[2 * q], v[2 * q + 1]);
+            const float r0 = sub_f16_lo(v[2 * q], hi), r1 = sub_f16_hi(v[2 * q + 1], hi);
+            unsigned d;
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(d) : "v"(r0), "s"(s));
+            asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(r1), "s"(s));
+            out[0][q] = hi;
+            out[1][q] = d;
+        }
+    } else split8<NP>(v, out);
+}
+
 template <int MT, int MTW, int TP, int NP>
 __device__ __forceinline__ void split_step(const u32x4 (&x)[TP][NP], f32x16 (&acc)[TP][MT], const u32x4* wk, int t0) {
     u32x4 w[MT][NP];
     load_w<MT, MTW, NP>(w, wk, t0);
-    mfma_step<MT, TP, NP>(w, x, acc);
+    if constexpr (NP == 2) {                             // x from split8_in: (w lo, x hi), (w hi, x hi), (2^-11 w hi, 2^11 x lo)
+        const f16x2v c = {(_Float16)(1.f / kSirenLoScale), (_Float16)(1.f / kSirenLoScale)};
+        u32x4 whs[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) whs[t][q] = pk_mul_f16(w[t][0][q], c);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int p = 0; p < TP; ++p)
+                    acc[p][t] = mfma16<2>(k == 0 ? w[t][1] : k == 1 ? w[t][0] : whs[t], x[p][k == 2 ? 1 : 0], acc[p][t]);
+    } else mfma_step<MT, TP, NP>(w, x, acc);
 }
 
 // KS k-steps; `wfirst` holds the fragments of k-step 0 (requested by the caller before the preceding sine stretch),
@@ -415,7 +454,7 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
                 if constexpr (MODE == MODE_FLOW) { v[0] = a.times[img % (a.B * a.N)]; v[1] = a.rel_y[Y[p]]; v[2] = a.rel_x[X[p]]; }
                 else { v[0] = a.rel_y[Y[p]]; v[1] = a.rel_x[X[p]]; }
                 if (hf) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; }
-                split8<NP>(v, x[p]);
+                split8_in<NP>(v, x[p]);
             }
             split_step<2, 2, TP, NP>(x, acc0, w0, 0);
         } else if constexpr (MODE == MODE_SYNTHC) {
@@ -445,7 +484,7 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
                     for (int r = 0; r < 16; ++r) acc0[p][t][r] = fmaf(sv[t][r], iw, acc0[p][t][r]);
                 float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (!hf) { d[0] = zmax; d[1] = cnt / 16.0f; d[2] = wz_ / cnt_; d[3] = tval; }
-                split8<NP>(d, x[p]);
+                split8_in<NP>(d, x[p]);
             }
             split_step<2, 2, TP, NP>(x, acc0, w0, 0);
         } else {
@@ -487,7 +526,7 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
                     float d[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) d[e] = v[p][e] / wz[p];
-                    split8<NP>(d, x[p]);
+                    split8_in<NP>(d, x[p]);
                 }
                 split_step<2, 2, TP, NP>(x, acc0, w0 + (long)ks * NP * 2 * 64, 0);
 #pragma unroll
@@ -508,7 +547,7 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
                         d[4] = wz_[p] / cnt_[p];
                         d[5] = tval;
                     }
-                    split8<NP>(d, x[p]);
+                    split8_in<NP>(d, x[p]);
                 }
                 split_step<2, 2, TP, NP>(x, acc0, w0 + 8L * NP * 2 * 64, 0);
             }
@@ -613,6 +652,12 @@ __global__ __launch_bounds__(SIREN_THREADS) __attribute__((amdgpu_waves_per_eu(2
                         for (int o = 0; o < 3; ++o) a.out[((long)img * 3 + o) * Q + cur.pp[p]] = sum[p][o];
                     } else {
                         const int b = img / a.N, n = img % a.N;
+                        // range status word: a first-layer input beyond fp16's range (the max plane under a large alpha) is packed as inf
+                        // and reaches every output as NaN
+                        if constexpr (NP == 2) {
+                            if (a.status && (__builtin_amdgcn_class(sum[p][0], 0x207) | __builtin_amdgcn_class(sum[p][1], 0x207) | __builtin_amdgcn_class(sum[p][2], 0x207)))
+                                atomicOr(a.status, 1u);
+                        }
 #pragma unroll
                         for (int o = 0; o < 3; ++o) {
                             float v = sum[p][o];

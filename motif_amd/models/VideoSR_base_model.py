@@ -38,6 +38,10 @@ class VideoSRBaseModel(BaseModel):
         self.use_graph = bool(opt.get("hip_graph"))
         self._graphs = OrderedDict()                     # configuration -> "warm" | recorded graph with its static tensors
         self._time_key = None
+        # arithmetic of THIS instance (None: the process-wide selection of ops.set_mma) and its range status word
+        # (include/motif_hip.h: kernels of the two-part fp16 arithmetic OR bit 0 into it when an operand left fp16's range)
+        self.mma = opt.get("mma")
+        self._status = torch.zeros(1, dtype=torch.int32, device=self.device) if torch.device(self.device).type == "cuda" else None
         if self.is_train:
             self.netG.train()
             train_opt = opt["train"]
@@ -66,7 +70,7 @@ class VideoSRBaseModel(BaseModel):
 
     def test(self, output=False):
         self.netG.eval()
-        with torch.no_grad():
+        with torch.no_grad(), ops.arithmetic(self.mma), ops.range_status(self._status):
             if self.times is None or "Ours" not in self.net_base:
                 raise NotImplementedError("only the 'Ours' generator is on the hot path")
             if not (self.use_graph and self._test_graph()):
@@ -103,7 +107,7 @@ class VideoSRBaseModel(BaseModel):
         net = self.netG
         scale = self.scale if not isinstance(self.scale, (list, tuple)) else tuple(tuple(int(v) for v in r) for r in self.scale)
         return (tuple(self.var_L.shape), self.var_L.dtype, self._time_key or tuple(tuple(t.shape) for t in self.times), scale,
-                self.net_base, ops.get_conv_mma(), ops.get_siren_mma(), getattr(net, "_weights_epoch", 0),
+                self.net_base, self.mma, ops.get_conv_mma(), ops.get_siren_mma(), getattr(net, "_weights_epoch", 0),
                 sum(p._version for p in net.parameters()),      # in-place weight edits re-pack on the next eager call: never replay over them
                 getattr(net, "precontract", None), getattr(net, "overlap_raft", None), getattr(net, "band", None) is None)
 
@@ -156,20 +160,34 @@ class VideoSRBaseModel(BaseModel):
     def get_current_log(self):
         return self.log_dict
 
+    def range_status(self):
+        """Read AND clear this instance's range status word (one 4-byte copy + the host synchronisation): non-zero = some kernel of the
+        two-part fp16 arithmetic met an operand beyond fp16's range since the last read."""
+        if self._status is None:
+            return 0
+        v = int(self._status.item())
+        if v:
+            self._status.zero_()
+        return v
+
     def ensure_finite(self):
-        """Range guard of the default arithmetic.  "f16x2" has fp16's operand range (|activation| < 3e4): outside it the
-        frames come out NaN / inf -- never silently wrong -- and this renders the clip again with three bf16 parts (fp32's exponent
-        range; the mode stays switched: such data will not fit the next time either).  Costs one device reduction plus the host
-        synchronisation the caller is about to pay anyway (`get_current_visuals`, the PSNR of `motif_amd.test`); the timed loop of
-        bench.py does not call it.  -> True when the clip was re-rendered."""
-        from motif_amd import ops
-        if ops.get_mma() != "f16x2" or bool(torch.isfinite(self.fake_H).all()):
+        """Range guard of the default arithmetic.  "f16x2" has fp16's operand range (|activation| < 3e4).  An operand
+        outside it makes the accumulators of its pixel non-finite IN THE KERNEL THAT MEETS IT, and that kernel sets this instance's
+        status word (`MotifConvDesc.status`) -- the guard does not depend on the value surviving to the frames (the fused splat clamps
+        its plane values and drops sources with a non-finite flow).  A set word renders the clip again with three bf16 parts (fp32's
+        exponent range); THIS instance stays switched (such data will not fit the next time either), other instances and the
+        process-wide selection are untouched.  Costs a 4-byte copy plus the host synchronisation the caller is about to pay anyway
+        (`get_current_visuals`, the PSNR of `motif_amd.test`); the timed loop of bench.py does not call it.  -> True when re-rendered."""
+        with ops.arithmetic(self.mma):
+            two_part = ops.get_mma() == "f16x2"
+        if not self.range_status() or not two_part:
             return False
-        logger.warning("non-finite frames under the f16x2 arithmetic (operands beyond fp16's range): rendering the clip again with bf16x3")
-        ops.set_mma("bf16x3")
+        logger.warning("an operand left fp16's range under the f16x2 arithmetic (range status word set): rendering the clip again with bf16x3")
+        self.mma = "bf16x3"
         if hasattr(self.netG, "clear_cache"):
             self.netG.clear_cache()
         self.test()
+        self.range_status()
         return True
 
     def get_current_visuals(self, need_GT=True):

@@ -78,6 +78,59 @@ def get_conv_mma():
     return _conv_mma
 
 
+# ----------------------------------------------------------------------------------------- range status word
+# include/motif_hip.h "Range status word": the kernels of the two-part fp16 arithmetic OR bit 0 into a caller-owned device word when an
+# operand left fp16's range.  The word belongs to a MODEL INSTANCE (VideoSRBaseModel owns one and reads it in ensure_finite()); while
+# that instance launches kernels it is the current word here.  Python issues the launches of a forward sequentially, so a plain
+# module-level "current" is exact also with several instances and several streams in one process.
+_status = None
+
+
+class range_status:
+    """with ops.range_status(word): every launch inside reports into `word` (int32[1] on the GPU; None = no report)."""
+
+    def __init__(self, word):
+        if word is not None and not (word.is_cuda and word.dtype == torch.int32 and word.numel() >= 1):
+            raise RuntimeError("the range status word is a CUDA(ROCm) int32 tensor")
+        self.word = word
+
+    def __enter__(self):
+        global _status
+        self._saved, _status = _status, self.word
+        return self.word
+
+    def __exit__(self, *exc):
+        global _status
+        _status = self._saved
+        return False
+
+
+def _status_ptr():
+    return ctypes.c_void_p(_status.data_ptr()) if _status is not None else None
+
+
+class arithmetic:
+    """with ops.arithmetic("bf16x3"): the launches inside use that arithmetic (None = whatever set_mma selected) -- a per-call
+    override for one model instance; the process-wide selection is untouched."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global _conv_mma, _siren_mma
+        self._saved = (_conv_mma, _siren_mma)
+        if self.name is not None:
+            mode = _MMA_NAMES[self.name]
+            _conv_mma = mode
+            _siren_mma = MMA_FP32 if mode == MMA_FP32 else MMA_F16X2 if mode == MMA_F16X2 else MMA_BF16X3
+        return self
+
+    def __exit__(self, *exc):
+        global _conv_mma, _siren_mma
+        _conv_mma, _siren_mma = self._saved
+        return False
+
+
 def set_option(name, value):
     """Tuning / test switch of the device library (include/motif_hip.h: motif_set_option); 0 = library default."""
     check(_lib.load().motif_set_option(name.encode(), int(value)), "motif_set_option(%s)" % name)
@@ -136,6 +189,7 @@ def conv2d(plan, x, x2=None, act=ACT_NONE, res=None, res_mode=0, act2=ACT_NONE, 
     c1 = x2.shape[1] if x2 is not None else 0
     d = plan.desc(n, h, w, c0, c1)
     d.act, d.act2, d.act_split, d.res_mode = act, act2, act_split, res_mode
+    d.status = _status_ptr()
     kh, kw = plan.weight.shape[2:]
     ho = (h + 2 * plan.pad - (plan.dil * (kh - 1) + 1)) // plan.stride + 1
     wo = (w + 2 * plan.pad - (plan.dil * (kw - 1) + 1)) // plan.stride + 1
@@ -175,6 +229,7 @@ def conv2d_multi(plans, xs, x2s=None, act=ACT_NONE, ress=None, res_mode=0, act2=
     p0 = plans[0]
     d = p0.desc(n, h, w, c0, c1)
     d.act, d.act2, d.act_split, d.res_mode = act, act2, act_split, res_mode
+    d.status = _status_ptr()
     kh, kw = p0.weight.shape[2:]
     ho = (h + 2 * p0.pad - (p0.dil * (kh - 1) + 1)) // p0.stride + 1
     wo = (w + 2 * p0.pad - (p0.dil * (kw - 1) + 1)) // p0.stride + 1
@@ -215,7 +270,7 @@ def dcn_v2_multi(dplans, xs, oms, dg=8, act=ACT_NONE, kh=3, kw=3, stride=1, pad=
         bs = oms[0].stride(0)
         check(lib.motif_dcn_v2_fused_fwd_multi(P, _ptr_array(xs), (ctypes.c_long * P)(*[x.stride(0) for x in xs]), _ptr_array(oms), masks,
                                                _ptr_array(packs), _ptr_array(biases), _ptr_array(outs), b, c, h, w, co, dg, bs, bs, act,
-                                               (_conv_mma if split else MMA_FP32), _stream()), "motif_dcn_v2_fused_fwd_multi")     # 6: three bf16 parts, 7: two fp16 parts in the window kernel
+                                               (_conv_mma if split else MMA_FP32), _status_ptr(), _stream()), "motif_dcn_v2_fused_fwd_multi")     # 6: three bf16 parts, 7: two fp16 parts in the window kernel
         return out
     cols = workspace(P * b * c * t * ho * wo, xs[0].device, "dcn_cols")
     plans = [dp.plan() for dp in dplans]
@@ -446,7 +501,7 @@ def siren_synth(blob, acc, residual_lr, iy, ix, times, B, N, HH, WW, pre=False):
     _, _, h, w = residual_lr.shape
     frames = torch.empty(N, B, 3, HH, WW, dtype=torch.float32, device=acc.device)
     check(lib.motif_siren_synth_fwd(_p(blob), _p(acc), _p(residual_lr), _p(iy), _p(ix), _p(_c(times)), _p(frames),
-                                    B, N, h, w, HH, WW, int(pre), _stream()), "motif_siren_synth_fwd")
+                                    B, N, h, w, HH, WW, int(pre), _status_ptr(), _stream()), "motif_siren_synth_fwd")
     return frames
 
 
@@ -458,7 +513,7 @@ def siren_synth_pre(blob, acc67, residual_l0, iy, ix, times, B, N, HH, WW, pre=N
     _, _, h, w = residual_l0.shape
     frames = torch.empty(N, B, 3, HH, WW, dtype=torch.float32, device=acc67.device)
     check(lib.motif_siren_synth_pre_fwd(_p(blob), _p(acc67), _p(residual_l0), _p(iy), _p(ix), _p(_c(times)), _p(frames),
-                                        B, N, h, w, HH, WW, int(pre), _stream()), "motif_siren_synth_pre_fwd")
+                                        B, N, h, w, HH, WW, int(pre), _status_ptr(), _stream()), "motif_siren_synth_pre_fwd")
     return frames
 
 

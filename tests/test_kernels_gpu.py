@@ -379,6 +379,31 @@ def test_conv_pw_pointwise_layers_match_fp64_and_the_fp32_engine(case, keep_mma)
     assert torch.equal(again.double().cpu(), outs[ops.MMA_F16X2][:1])
 
 
+def test_conv_pw_guard_bands_channels_past_cin_and_couts_past_cout_touch_nothing(keep_mma):
+    """conv_pw.hip relies on the buffer range check for channels past Cin (a ragged last 16-channel step), couts past
+    Cout (a partial cout tile) and the masked lanes of a ragged pixel group.  The plane offsets are therefore part of the VECTOR
+    offset (the scalar offset operand is outside the check).  Guard bands: NaN planes right behind every image's input and residual
+    channels, canary planes right behind every image's output channels, Cin % 8 != 0, Cout % 32 != 0, N > 1, odd plane size."""
+    from motif_amd import ops
+    from motif_amd.models.modules.layers import Conv2d
+    n, cin, cout, H, W, pad_planes = 2, 20, 40, 19, 33, 4
+    m = Conv2d(cin, cout, 1, 1, 0)
+    with torch.no_grad():
+        m.weight.copy_(rnd(*m.weight.shape, seed=1, scale=0.2))
+        m.bias.copy_(rnd(cout, seed=2, scale=0.1))
+    x, res = rnd(n, cin, H, W, seed=3), rnd(n, cout, H, W, seed=4)
+    ref = F.relu(F.conv2d(x.double(), m.weight.double(), m.bias.double()) + res.double())
+    m = m.to(dev())
+    xb = torch.full((n, cin + pad_planes, H, W), float("nan"), device=dev()); xb[:, :cin] = x.to(dev())
+    rb = torch.full((n, cout + pad_planes, H, W), float("nan"), device=dev()); rb[:, :cout] = res.to(dev())
+    ob = torch.full((n, cout + pad_planes, H, W), 123.0, device=dev())
+    ops.set_conv_mma(ops.MMA_F16X2)
+    m(xb[:, :cin], act=ops.ACT_RELU, res=rb[:, :cout], res_mode=1, out=ob[:, :cout])
+    assert bool((ob[:, cout:] == 123.0).all()), "a cout past Cout was stored"
+    assert bool(torch.isfinite(ob[:, :cout]).all()), "a channel past Cin / a residual plane past Cout was read"
+    close(ob[:, :cout], ref.float(), 2e-5, 2e-5, "guard-banded 1x1 layer")
+
+
 def test_conv_two_part_form_is_loud_outside_fp16_range_and_three_part_form_is_not(keep_mma):
     """mma = 7 (two fp16 parts) has fp16's range: a transformed activation beyond 65504 must give inf / NaN in the outputs it
     touches -- never a silently clamped finite value -- and leave every other output untouched; mma = 6 (three bf16 parts, fp32's
@@ -409,6 +434,123 @@ def test_conv_two_part_form_is_loud_outside_fp16_range_and_three_part_form_is_no
     near = torch.zeros_like(bad)
     near[:, :, 8:13, 19:22] = True
     close(o7[~near], ref.float()[~near], 2e-5, 2e-5, "outputs the value does not reach")
+
+
+def _dcn_fp64(x, weight, bias, offset, mask, dg):
+    """DCNv2 forward (3x3, pad 1) from its definition in fp64: tap k of output pixel p samples the input bilinearly at
+    p - 1 + k + offset_k(p) (zero outside the image), times mask_k(p); then the dense contraction (dcn_v2_im2col_cuda.cu:125-194)."""
+    x, weight, bias, offset, mask = (t.double() for t in (x, weight, bias, offset, mask))
+    B, C, H, W = x.shape
+    co = weight.shape[0]
+    ys = torch.arange(H, dtype=torch.float64).view(1, H, 1)
+    xs = torch.arange(W, dtype=torch.float64).view(1, 1, W)
+    out = bias.view(1, co, 1, 1).expand(B, co, H, W).clone()
+    cg = C // dg
+    for g in range(dg):
+        xg = x[:, g * cg:(g + 1) * cg]
+        for k in range(9):
+            py = ys - 1 + k // 3 + offset[:, g * 18 + 2 * k]
+            px = xs - 1 + k % 3 + offset[:, g * 18 + 2 * k + 1]
+            grid = torch.stack((2.0 * px / (W - 1) - 1.0, 2.0 * py / (H - 1) - 1.0), -1)
+            smp = F.grid_sample(xg, grid, mode="bilinear", padding_mode="zeros", align_corners=True) * mask[:, g * 9 + k].unsqueeze(1)
+            out += torch.einsum("oc,bchw->bohw", weight[:, g * cg:(g + 1) * cg, k // 3, k % 3], smp)
+    return out
+
+
+@pytest.mark.parametrize("ws", [1.0 / 24, 1e-2], ids=["w1/24", "w1e-2"])
+@pytest.mark.parametrize("xs", [1.0, 1e-2, 1e-3, 1e-4], ids=["x1", "x1e-2", "x1e-3", "x1e-4"])
+@pytest.mark.parametrize("layer", ["wino3x3", "pw1x1", "dcn"])
+def test_two_part_fp16_form_is_fp32_equivalent_at_every_activation_scale(layer, xs, ws, keep_mma):
+    """the two-part fp16 form must not depend on the activations being of O(1).  The low activation part is stored
+    times 2^11 (a normal fp16 number whenever the high part is one) and meets 2^-11 x the high weight part -- conv_wino.hip,
+    conv_pw.hip, the DCN window kernel.  Against fp64, for activation scales 1 .. 1e-4 and weight scales 1/24, 1e-2, the error of
+    mma = 7 stays within the bound the other split kernels are held to: 1.25 x the fp32-MFMA engine's (+ 1e-7 of the output scale)."""
+    from motif_amd import ops
+    from motif_amd.models.modules.layers import Conv2d
+    modes = (ops.MMA_FP32, ops.MMA_BF16X3, ops.MMA_F16X2)
+    err = {}
+    if layer == "dcn":
+        B, C, H, W, dg = 1, 64, 24, 40, 8
+        x = rnd(B, C, H, W, seed=1, scale=xs)
+        w = rnd(64, C, 3, 3, seed=2, scale=ws)
+        bias = rnd(64, seed=3, scale=2.0 * xs * ws)
+        off = rnd(B, 2 * dg * 9, H, W, seed=4, scale=3.0)
+        mask = torch.sigmoid(rnd(B, dg * 9, H, W, seed=5, scale=2.0))
+        ref = _dcn_fp64(x, w, bias, off, mask, dg)
+        plan = ops.DcnPlan(w.to(dev()), bias.to(dev()))
+        om = torch.cat([off, mask], 1).to(dev())
+        for mode in modes:
+            ops.set_conv_mma(mode)
+            err[mode] = float((ops.dcn_v2_multi([plan], [x.to(dev())], [om], dg)[0].double().cpu() - ref).abs().max())
+    else:
+        cin, k = (64, 3) if layer == "wino3x3" else (128, 1)
+        m = Conv2d(cin, 64, k, 1, k // 2)
+        with torch.no_grad():
+            m.weight.copy_(rnd(*m.weight.shape, seed=1, scale=ws))
+            m.bias.copy_(rnd(64, seed=2, scale=2.0 * xs * ws))
+        x = rnd(2, cin, 45, 80, seed=3, scale=xs)
+        ref = F.conv2d(x.double(), m.weight.double(), m.bias.double(), 1, k // 2)
+        m = m.to(dev())
+        outs = {}
+        for mode in modes:
+            ops.set_conv_mma(mode)
+            outs[mode] = m(x.to(dev())).double().cpu()
+            err[mode] = float((outs[mode] - ref).abs().max())
+        assert not torch.equal(outs[ops.MMA_F16X2], outs[ops.MMA_BF16X3]) and not torch.equal(outs[ops.MMA_F16X2], outs[ops.MMA_FP32]), "mma = 7 ran its own kernel"
+    scale = float(ref.abs().max())
+    assert err[ops.MMA_FP32] < 3e-6 * scale, (err, scale)
+    assert err[ops.MMA_BF16X3] <= 1.25 * err[ops.MMA_FP32] + 1e-7 * scale, (err, scale)
+    assert err[ops.MMA_F16X2] <= 1.25 * err[ops.MMA_FP32] + 1e-7 * scale, (err, scale)
+
+
+def test_range_status_word_is_set_by_the_kernel_that_meets_an_out_of_range_operand(keep_mma):
+    """include/motif_hip.h "Range status word": every kernel of the two-part fp16 form ORs bit 0 into the caller's word when an
+    operand of its own launch left fp16's range -- at the source, whatever later stages do with the value -- and leaves the word
+    alone on in-range data, with no word given, and under mma = 6."""
+    from motif_amd import ops
+    from motif_amd.models.modules.layers import Conv2d
+    word = torch.zeros(1, dtype=torch.int32, device=dev())
+
+    def fired(fn):
+        word.zero_()
+        with ops.range_status(word):
+            out = fn()
+        return int(word.item()), out
+
+    # 3x3 (conv_wino.hip): one activation of 1e5 in a corner tile of a ragged map; 4e4 overflows through the row transform (d1 + d2)
+    m3 = Conv2d(64, 64, 3, 1, 1)
+    m1 = Conv2d(128, 40, 1, 1, 0)                         # conv_pw.hip, partial second cout tile
+    with torch.no_grad():
+        m3.weight.copy_(rnd(*m3.weight.shape, seed=1, scale=1.0 / 24)); m3.bias.zero_()
+        m1.weight.copy_(rnd(*m1.weight.shape, seed=2, scale=0.05)); m1.bias.zero_()
+    m3, m1 = m3.to(dev()), m1.to(dev())
+    x3 = rnd(2, 64, 37, 52, seed=3).to(dev())
+    x1 = rnd(2, 128, 19, 33, seed=4).to(dev())
+    ops.set_conv_mma(ops.MMA_F16X2)
+    assert fired(lambda: m3(x3))[0] == 0 and fired(lambda: m1(x1))[0] == 0
+    for val, where in ((1.0e5, (1, 63, 36, 51)), (-7.0e4, (0, 0, 0, 0)), (float("inf"), (1, 17, 20, 31))):
+        xb = x3.clone(); xb[where] = val
+        flag, out = fired(lambda: m3(xb))
+        assert flag == 1 and not bool(torch.isfinite(out).all()), (val, where)
+    xb = x3.clone(); xb[0, 5, 10, 20] = 4.0e4; xb[0, 5, 11, 20] = 4.0e4          # each fits fp16, their Winograd sum d1 + d2 does not
+    assert fired(lambda: m3(xb))[0] == 1
+    xb = x1.clone(); xb[1, 127, 18, 32] = 7.0e4
+    assert fired(lambda: m1(xb))[0] == 1
+    # no word: nothing to write, nothing breaks; mma = 6 computes the same layers in range
+    xb = x3.clone(); xb[0, 3, 3, 3] = 1.0e5
+    m3(xb)
+    ops.set_conv_mma(ops.MMA_BF16X3)
+    flag, out = fired(lambda: m3(xb))
+    assert flag == 0 and bool(torch.isfinite(out).all())
+    # DCN window kernel
+    ops.set_conv_mma(ops.MMA_F16X2)
+    B, C, H, W, dg = 1, 64, 24, 40, 8
+    xd = rnd(B, C, H, W, seed=5).to(dev())
+    plan = ops.DcnPlan(rnd(64, C, 3, 3, seed=6, scale=0.05).to(dev()), torch.zeros(64, device=dev()))
+    om = torch.cat([rnd(B, 2 * dg * 9, H, W, seed=7, scale=2.0), torch.sigmoid(rnd(B, dg * 9, H, W, seed=8, scale=2.0)) * 0.5 + 0.5], 1).to(dev())
+    assert fired(lambda: ops.dcn_v2_multi([plan], [xd], [om], dg))[0] == 0
+    xb = xd.clone(); xb[0, 9, 12, 17] = 1.0e6           # blended and masked it still exceeds fp16's range somewhere
+    assert fired(lambda: ops.dcn_v2_multi([plan], [xb], [om], dg))[0] == 1
 
 
 # ------------------------------------------------------------------------------------------- DCNv2

@@ -776,32 +776,94 @@ def test_generator_matches_oracle_on_odd_shapes(cfg, mma_mode):
     assert float((flow.cpu() - rflow).abs().max()) < 2e-3
 
 
-def test_range_guard_renders_an_out_of_range_clip_again_with_bf16x3(mma_mode):
-    """The default arithmetic has fp16's operand range.  A clip whose activations leave it (here: LR frames scaled by 1e6) must come out
-    non-finite under f16x2 -- loud, never a clamped finite frame -- and `VideoSRBaseModel.ensure_finite()` (called by
-    `get_current_visuals` and by the evaluation driver) must render it again with three bf16 parts, giving exactly the frames a
-    bf16x3 run gives; an ordinary clip is left alone."""
-    if mma_mode != DEFAULT_MMA:
-        pytest.skip("the guard belongs to the default arithmetic")
-    from motif_amd import ops
+def _guard_model():
     from motif_amd.data.synthetic import synthetic_sample
     from motif_amd.models import create_model
     from motif_amd.option import default_opt
     from motif_amd.utils.synth_weights import fill_state_dict
-    model = create_model(default_opt(scale=4, gpu_ids=[0], mma="f16x2"))
+    model = create_model(default_opt(scale=4, gpu_ids=[0]))
     fill_state_dict(model.netG)
     smp = synthetic_sample(32, 48, 4, 3, seed=5)
     data = {"LQs": smp["LQs"].cuda(), "GT": smp["GT"][:, :1].cuda(), "time": [t.cuda() for t in smp["time"]], "scale": smp["scale"]}
+    return model, data
+
+
+def test_range_guard_renders_an_out_of_range_clip_again_with_bf16x3(mma_mode):
+    """The default arithmetic has fp16's operand range.  A clip whose activations leave it (here: LR frames scaled by 1e6) must set
+    the instance's range status word, and `VideoSRBaseModel.ensure_finite()` (called by `get_current_visuals` and by the evaluation
+    driver) must render it again with three bf16 parts, giving exactly the frames a bf16x3 run gives; an ordinary clip is left
+    alone; the process-wide selection and other instances are untouched."""
+    if mma_mode != DEFAULT_MMA:
+        pytest.skip("the guard belongs to the default arithmetic")
+    from motif_amd import ops
+    model, data = _guard_model()
+    other, _ = _guard_model()
+    model.feed_data(data); model.test()
+    assert model.ensure_finite() is False and model.mma is None and ops.get_mma() == "f16x2"
+    ordinary = model.fake_H.clone()
+    big = dict(data, LQs=data["LQs"] * 1.0e6)
+    model.feed_data(big); model.test()
+    assert model.ensure_finite() is True and model.mma == "bf16x3"
+    assert ops.get_mma() == "f16x2" and other.mma is None, "the switch belongs to the instance that met the data"
+    got = model.fake_H.clone()
+    assert bool(torch.isfinite(got).all())
+    model.feed_data(big); model.test()                   # a plain bf16x3 render of the same clip
+    assert torch.equal(model.fake_H, got) and model.ensure_finite() is False
+    other.feed_data(data); other.test()                  # the other instance still runs the two-part form
+    assert torch.equal(other.fake_H, ordinary) and other.ensure_finite() is False
+
+
+@pytest.mark.parametrize("where", ["encoder", "flow_branch", "imnet_input"])
+def test_range_guard_trips_on_a_single_out_of_range_feature_the_splat_would_launder(mma_mode, where):
+    """VERDICT r4 #2 / ADVICE r4: ONE feature of 1e5 -- after `conv_first`, inside `flow_process`, or in the encoder output the MLPs'
+    LR partials read -- overflows the fp16 operand of the next two-part kernel.  Everything reaches the frames through the fused
+    splat, which clamps plane values to +-2^17 and drops sources with a non-finite flow, so the frames may well come out finite: the
+    guard must not depend on them.  The kernel that meets the value sets the status word; `ensure_finite()` re-renders with bf16x3
+    and gives the frames of a bf16x3 instance under the same injection."""
+    if mma_mode != DEFAULT_MMA:
+        pytest.skip("the guard belongs to the default arithmetic")
+    model, data = _guard_model()
+    ref_model, _ = _guard_model()
+    ref_model.mma = "bf16x3"
+
+    def inject(net):
+        mod = {"encoder": net.encoder.conv_first, "flow_branch": net.flow_process[0], "imnet_input": net.encoder.recon_trunk[39].conv2}[where]
+        orig = mod.forward
+
+        def fwd(*a, **k):
+            y = orig(*a, **k)
+            y[0, 3, 5, 7] = 1.0e5
+            return y
+        mod.forward = fwd
+
+    from motif_amd import ops
+    inject(model.netG); inject(ref_model.netG)
     try:
+        ops.set_option("conv_engine", 5)                 # the Winograd kernel wherever it applies: on this small map the library would give some layers to the three-part direct kernel
         model.feed_data(data); model.test()
-        assert model.ensure_finite() is False and ops.get_mma() == "f16x2"
-        big = dict(data, LQs=data["LQs"] * 1.0e6)
-        model.feed_data(big); model.test()
-        assert not bool(torch.isfinite(model.fake_H).all()), "activations of 1e5 .. 1e6 must not pass silently through the two-part form"
-        assert model.ensure_finite() is True and ops.get_mma() == "bf16x3"
+        assert model.ensure_finite() is True and model.mma == "bf16x3", "the out-of-range operand went unreported"
         got = model.fake_H.clone()
-        assert bool(torch.isfinite(got).all())
-        model.feed_data(big); model.test()                   # a plain bf16x3 render of the same clip
-        assert torch.equal(model.fake_H, got)
+        ref_model.feed_data(data); ref_model.test()
+        assert ref_model.ensure_finite() is False
+        assert torch.equal(got, ref_model.fake_H)
     finally:
-        ops.set_mma(DEFAULT_MMA)
+        ops.set_option("conv_engine", 0)
+
+
+def test_small_magnitude_clip_matches_the_oracle(mma_mode):
+    """a clip scaled by 1e-3 (LR frames of magnitude 1e-3: the first layers' activations are then far below 0.25,
+    where the plain two-part split kept only an absolute 2^-25) against the CPU oracle, stage by stage and in the frames."""
+    from oracle.motif_ref import MotifRef
+    from motif_amd.data.synthetic import synthetic_sample
+    from motif_amd.utils.synth_weights import fill_state_dict
+    s = synthetic_sample(32, 48, 4, 3, seed=9)
+    lq = s["LQs"] * 1.0e-3
+    net = build_net()
+    st, rst = {}, {}
+    with torch.no_grad():
+        out, flow, _ = net(lq.cuda(), None, [t.cuda() for t in s["time"]], s["scale"], use_GT=False, iter=4, stages=st)
+        ref, rflow, _ = fill_state_dict(MotifRef().eval())(lq, None, s["time"], s["scale"], use_GT=False, iter=4, stages=rst)
+    assert psnr(out.cpu(), ref) >= 60.0, psnr(out.cpu(), ref)
+    assert float((flow.cpu() - rflow).abs().max()) < 2e-3
+    feat, rfeat = st["feat"].cpu(), rst["encoder"]
+    assert float((feat - rfeat).abs().max()) <= 2e-4 * float(rfeat.abs().max()), (float((feat - rfeat).abs().max()), float(rfeat.abs().max()))

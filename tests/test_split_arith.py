@@ -23,6 +23,57 @@ def f16_parts(x, scale=1.0):
     return [hi.astype(np.float64) / scale, lo.astype(np.float64) / scale]
 
 
+def f16_act_parts(x):
+    """The shipped activation split (round 5): hi = rne(x), lo_s = rne((x - hi) * 2^11); represents hi + 2^-11 lo_s."""
+    x = x.astype(np.float32)
+    hi = x.astype(np.float16)
+    lo_s = ((x - hi.astype(np.float32)) * np.float32(2048)).astype(np.float16)
+    return hi.astype(np.float64), lo_s.astype(np.float64)
+
+
+def f16x2_contract(x, w):
+    """out = 2^-8 (hi Whi + hi Wlo + lo_s (2^-11 Whi)) with W = 2^8 w -- what conv_wino.hip / conv_pw.hip / dcn.hip issue (products exact, fp64 sums)."""
+    hi, lo_s = f16_act_parts(x)
+    W = w.astype(np.float32) * np.float32(256)
+    whi = W.astype(np.float16)
+    wlo = (W - whi.astype(np.float32)).astype(np.float16)
+    whs = (whi.astype(np.float32) * np.float32(2.0 ** -11)).astype(np.float16)          # v_pk_mul_f16: one rounding, exact while normal
+    f = lambda a: a.astype(np.float64)
+    return (hi @ f(whi) + hi @ f(wlo) + lo_s @ f(whs)) / 256.0
+
+
+def test_scaled_low_part_is_normal_whenever_the_high_part_is_and_never_overflows():
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(400000) * np.exp(rng.uniform(-12, 10, 400000))).astype(np.float32)
+    x = x[(np.abs(x) >= 2.0 ** -14) & (np.abs(x) < 65504)]
+    hi, lo_s = f16_act_parts(x)
+    assert np.all(np.isfinite(lo_s)) and np.all(np.abs(lo_s) <= np.abs(x) * (1 + 2.0 ** -10)), "|x - hi| <= 2^-11 |x|: the scaled low part never exceeds |x|"
+    assert np.all(np.abs(x.astype(np.float64) - hi - lo_s / 2048) <= 2.0 ** -22 * np.abs(x)), "hi + 2^-11 lo_s holds x to 2^-22 for EVERY |x| >= 2^-14"
+    tiny = (rng.uniform(-1, 1, 100000) * 2.0 ** -15).astype(np.float32)
+    hi, lo_s = f16_act_parts(tiny)
+    assert np.all(np.abs(tiny.astype(np.float64) - hi - lo_s / 2048) <= 2.0 ** -36), "below fp16's normal range: an absolute 2^-36"
+
+
+def test_shipped_two_part_contraction_is_fp32_equivalent_from_1e_minus_4_to_1e4():
+    """VERDICT r4 #1: activation scales 1 .. 1e-4 (and up to 1e4), weight scales 1/24 and 1e-2, the bound of the device tests."""
+    rng = np.random.default_rng(0)
+    K, M, N = 576, 192, 192
+    for xs in (1.0, 1e-2, 1e-3, 1e-4, 30.0, 1e4):
+        for ws in (1 / 24, 1e-2):
+            x = ((rng.random((M, K)) * 2 - 1) * xs).astype(np.float32)
+            w = ((rng.random((K, N)) * 2 - 1) * ws).astype(np.float32)
+            ref = x.astype(np.float64) @ w.astype(np.float64)
+            e32 = np.abs((x @ w).astype(np.float64) - ref)
+            e3 = np.abs(f16x2_contract(x, w) - ref)
+            rms = lambda e: float(np.sqrt((e ** 2).mean()))
+            assert rms(e3) < rms(e32) and e3.max() <= 1.25 * e32.max(), (xs, ws, rms(e32), rms(e3), e32.max(), e3.max())
+            # the round-4 form (plain low part) for contrast: it leaves the bound as soon as the activations are small
+            a, b = f16_parts(x), f16_parts(w, 256.0)
+            e_old = np.abs(a[0] @ b[0] + a[0] @ b[1] + a[1] @ b[0] - ref)
+            if xs <= 1e-2:
+                assert rms(e_old) > 5 * rms(e32), "the test must be able to see the defect it guards against"
+
+
 def test_two_fp16_parts_hold_22_bits_and_three_bf16_parts_hold_all_24():
     rng = np.random.default_rng(1)
     x = (rng.standard_normal(200000) * np.exp(rng.uniform(-2, 8, 200000))).astype(np.float32)      # |x| from ~0.1 to a few thousand
