@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE          # where fixtures are written (--check: a temporary directory that is then compared with the committed files)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
@@ -213,7 +214,7 @@ def run_case(net, name, h, w, scale, n_times, batch=1, seed=0, n_frames=4, pad_t
     pack(store, "flow_lr", ost["flow_lr"])     # reference-internal tensors without a module hook:
     pack(store, "psies", ost["psies"])         # taken from the restatement, which the report above
     pack(store, "rel_coord", ost["rel_coord"])  # shows equal to the reference downstream
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), **store)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
     return report
 
 
@@ -238,7 +239,7 @@ def shell_case(net, net_base="Ours", fname="shell_T7_lr32_s4.npz", numeric_scale
     store = {"LQs": sample["LQs"].numpy(), "GT": sample["GT"].numpy(), "times": torch.stack(sample["time"], 0).numpy(),
              "scale": np.array([sample["scale"][0][0], sample["scale"][1][0]], dtype=np.int64)}
     pack(store, "fake_H", me.fake_H, limit=10_000_000)
-    np.savez_compressed(os.path.join(HERE, fname), **store)
+    np.savez_compressed(os.path.join(OUT, fname), **store)
     print("shell", net_base, "fake_H", tuple(me.fake_H.shape))
 
 
@@ -255,8 +256,8 @@ def pwc_case():
         flow = net(frames[:, 0], frames[:, 1])
     store = {"first": frames[:, 0].numpy(), "second": frames[:, 1].numpy(), "torch_version": np.array(torch.__version__)}
     pack(store, "flow", flow)
-    np.savez_compressed(os.path.join(HERE, "pwc_96x128.npz"), **store)
-    json.dump({k: list(v.shape) for k, v in net.state_dict().items()}, open(os.path.join(HERE, "pwc_state_dict_keys.json"), "w"), indent=0)
+    np.savez_compressed(os.path.join(OUT, "pwc_96x128.npz"), **store)
+    json.dump({k: list(v.shape) for k, v in net.state_dict().items()}, open(os.path.join(OUT, "pwc_state_dict_keys.json"), "w"), indent=0)
     print("pwc flow", tuple(flow.shape), float(flow.abs().mean()))
 
 
@@ -282,7 +283,7 @@ def corr_case():
         out = CorrBlock(f1, f2, num_levels=4, radius=r)(coords)
     store = {"fmap1": f1.numpy(), "fmap2": f2.numpy(), "coords": coords.numpy(), "radius": np.array(r), "torch_version": np.array(torch.__version__)}
     pack(store, "corr", out, limit=10_000_000)
-    np.savez_compressed(os.path.join(HERE, "corrblock_16x24.npz"), **store)
+    np.savez_compressed(os.path.join(OUT, "corrblock_16x24.npz"), **store)
     print("CorrBlock", tuple(out.shape), float(out.abs().mean()))
 
     args = argparse.Namespace(small=True, mixed_precision=False, alternate_corr=False)
@@ -297,7 +298,7 @@ def corr_case():
     store = {"image1": im1.numpy(), "image2": im2.numpy(), "iters": np.array(4), "torch_version": np.array(torch.__version__)}
     pack(store, "flow_lr", flow_lr, limit=10_000_000)
     pack(store, "flow_up", flow_up, limit=10_000_000)
-    np.savez_compressed(os.path.join(HERE, "raft_corrblock_128x160.npz"), **store)
+    np.savez_compressed(os.path.join(OUT, "raft_corrblock_128x160.npz"), **store)
     print("RAFT (CorrBlock path) flow_up", tuple(flow_up.shape), float(flow_up.abs().mean()))
 
 
@@ -305,7 +306,7 @@ def host_side_case():
     """Rows H and (f)3, reference-run data for the host-side numerics: (i) the per-frame Y-PSNR vector and its summary numbers,
     produced by exec'ing the reference's own lines (test.py:212-238) on the shell golden's frames; (ii) the LR generator
     data/util.py:imresize_np on seeded images (shrink x1/4, x1/2 with antialiasing, a non-divisible size, x2 up)."""
-    g = dict(np.load(os.path.join(HERE, "shell_T7_lr32_s4.npz"), allow_pickle=False))
+    g = dict(np.load(os.path.join(OUT if os.path.exists(os.path.join(OUT, "shell_T7_lr32_s4.npz")) else HERE, "shell_T7_lr32_s4.npz"), allow_pickle=False))
     GT = torch.from_numpy(g["GT"])
     fake = torch.zeros(*[int(v) for v in g["fake_H__shape"]])
     fake.reshape(-1)[:] = torch.from_numpy(g["fake_H"]).reshape(-1)
@@ -345,7 +346,7 @@ def host_side_case():
         store["imresize_in_" + tag] = img
         store["imresize_scale_" + tag] = np.array(sc)
         store["imresize_out_" + tag] = du.imresize_np(img.copy(), sc, True)
-    np.savez_compressed(os.path.join(HERE, "host_side.npz"), **store)
+    np.savez_compressed(os.path.join(OUT, "host_side.npz"), **store)
     print("imresize_np fixtures", {k: v.shape for k, v in store.items() if k.startswith("imresize_out")})
 
 
@@ -353,15 +354,15 @@ def variants():
     """the 4-frame generators, goldens + restatement check (writes its own report file)."""
     rep = {}
     n4 = build_variant("Ours_4")
-    json.dump({k: list(v.shape) for k, v in n4.state_dict().items()}, open(os.path.join(HERE, "ours4_state_dict_keys.json"), "w"), indent=0)
+    json.dump({k: list(v.shape) for k, v in n4.state_dict().items()}, open(os.path.join(OUT, "ours4_state_dict_keys.json"), "w"), indent=0)
     rep["ours4_lr32_s4_n3"] = run_case(n4, "ours4_lr32_s4_n3", 32, 32, 4, 3, seed=4, oracle_cls=MotifRef4)
     rep["ours4_lr32x48_s4_n2_b2"] = run_case(n4, "ours4_lr32x48_s4_n2_b2", 32, 48, 4, 2, batch=2, seed=5, oracle_cls=MotifRef4)
     n44 = build_variant("Ours_44")
-    json.dump({k: list(v.shape) for k, v in n44.state_dict().items()}, open(os.path.join(HERE, "ours44_state_dict_keys.json"), "w"), indent=0)
+    json.dump({k: list(v.shape) for k, v in n44.state_dict().items()}, open(os.path.join(OUT, "ours44_state_dict_keys.json"), "w"), indent=0)
     rep["ours44_lr32_s4_t3of6"] = run_case(n44, "ours44_lr32_s4_t3of6", 32, 32, 4, 7, seed=6, oracle_cls=MotifRef44, time_idx=[3], numeric_scale=True)
     rep["ours44_lr32_s4_t5of6"] = run_case(n44, "ours44_lr32_s4_t5of6", 32, 32, 4, 7, seed=6, oracle_cls=MotifRef44, time_idx=[5], numeric_scale=True)
     shell_case(n44, net_base="Ours_44", fname="shell44_T7_lr32_s4.npz", numeric_scale=True)
-    json.dump(rep, open(os.path.join(HERE, "restatement_vs_reference_4frame.json"), "w"), indent=1)
+    json.dump(rep, open(os.path.join(OUT, "restatement_vs_reference_4frame.json"), "w"), indent=1)
 
 
 def round4_cases(net, reports):
@@ -377,7 +378,7 @@ def main():
     torch.set_num_threads(8)
     net, Ours = build_reference()
     json.dump({k: list(v.shape) for k, v in net.state_dict().items()},
-              open(os.path.join(HERE, "state_dict_keys.json"), "w"), indent=0)
+              open(os.path.join(OUT, "state_dict_keys.json"), "w"), indent=0)
     reports = {}
     reports["lr32_s4_n3"] = run_case(net, "lr32_s4_n3", 32, 32, 4, 3)
     reports["lr64_s2_n3"] = run_case(net, "lr64_s2_n3", 64, 64, 2, 3, seed=1)        # BASELINE config 1
@@ -388,10 +389,46 @@ def main():
     corr_case()
     host_side_case()
     variants()
-    json.dump(reports, open(os.path.join(HERE, "restatement_vs_reference.json"), "w"), indent=1)
+    json.dump(reports, open(os.path.join(OUT, "restatement_vs_reference.json"), "w"), indent=1)
+
+
+def check():
+    """--check: regenerate EVERY fixture into a temporary directory and compare it with the committed file of the same name -- the
+    committed bytes must be what this script produces (same keys, same arrays bit for bit; json reports equal).  Exit code 1 on any
+    difference.  tests/test_oracle.py runs it when /root/reference is present."""
+    global OUT
+    import tempfile
+    OUT = tempfile.mkdtemp(prefix="motif_golden_check_")
+    main()
+    bad = []
+    names = sorted(f for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
+    made = sorted(f for f in os.listdir(OUT) if f.endswith((".npz", ".json")))
+    if names != made:
+        bad.append("file sets differ: committed only %s, generated only %s" % (sorted(set(names) - set(made)), sorted(set(made) - set(names))))
+    for f in sorted(set(names) & set(made)):
+        a, b = os.path.join(HERE, f), os.path.join(OUT, f)
+        if f.endswith(".json"):
+            if json.load(open(a)) != json.load(open(b)):
+                bad.append(f + ": json differs")
+            continue
+        x, y = dict(np.load(a, allow_pickle=False)), dict(np.load(b, allow_pickle=False))
+        if sorted(x) != sorted(y):
+            bad.append("%s: keys differ (%s)" % (f, sorted(set(x) ^ set(y))))
+            continue
+        for k in x:
+            if x[k].dtype != y[k].dtype or x[k].shape != y[k].shape or x[k].tobytes() != y[k].tobytes():
+                bad.append("%s[%s] differs" % (f, k))
+    import shutil
+    shutil.rmtree(OUT, ignore_errors=True)
+    print("golden check: %d files compared, %d differences" % (len(set(names) & set(made)), len(bad)))
+    for b_ in bad:
+        print("  " + b_)
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":
+    if "--check" in sys.argv:
+        sys.exit(check())
     if "--host-only" in sys.argv:
         install_stubs()
         host_side_case()
@@ -406,7 +443,7 @@ if __name__ == "__main__":
         net, _ = build_reference()
         rep = json.load(open(os.path.join(HERE, "restatement_vs_reference.json")))
         round4_cases(net, rep)
-        json.dump(rep, open(os.path.join(HERE, "restatement_vs_reference.json"), "w"), indent=1)
+        json.dump(rep, open(os.path.join(OUT, "restatement_vs_reference.json"), "w"), indent=1)
     elif "--variants-only" in sys.argv:
         torch.manual_seed(0)
         torch.set_num_threads(8)

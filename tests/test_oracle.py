@@ -338,3 +338,17 @@ def test_corr81_restatement_equals_an_unfold_formulation():
     patches = F.unfold(f2, kernel_size=9, padding=4).view(b, c, 81, h, w)
     want = (f1.unsqueeze(2) * patches).mean(1)
     assert float((native.corr81(f1, f2) - want).abs().max()) < 1e-5
+
+
+def test_committed_goldens_are_what_make_golden_produces_from_the_reference():
+    """Fixture hygiene: `make_golden.py --check` regenerates every fixture from the imported reference into a
+    temporary directory and compares keys and arrays bit for bit with the committed files.  Needs /root/reference, which exists in the
+    build container only (never on the GPU box): skipped elsewhere."""
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("/root/reference is not present (the reference never travels to the GPU box)")
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py")
+    r = subprocess.run([sys.executable, script, "--check"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 differences" in r.stdout
