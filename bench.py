@@ -198,7 +198,7 @@ def instrumented_clip(model, sample):
     for name in ("reliability_pairs", "backwarp"):
         hook(name, lambda out, *a, **k: ("reliability", 0.0, None))
     # the small element-wise / layout kernels between the stages above (ConvLSTM gates, GRU update, flow scaling, pooling, layout)
-    for name in ("lstm_gates", "gru_update", "axpby", "flow_roundtrip", "avg_pool2", "nchw_to_nhwc", "frames_u8_to_f32", "frames_f32_to_u8"):
+    for name in ("lstm_gates", "gru_update", "axpby", "axpby_into", "flow_roundtrip", "avg_pool2", "nchw_to_nhwc", "frames_u8_to_f32", "frames_f32_to_u8"):
         hook(name, lambda out, *a, **k: ("elementwise", 0.0, None))
     net = model.netG
     overlap = getattr(net, "overlap_raft", False)

@@ -266,7 +266,10 @@ int motif_raft_corr_lookup(const float* fmap1, const float* fmap2, const float* 
  * fmap2[i] [B,H2[i],W2[i],C] at coords/2^i and writes channels [49*i, 49*i+49) of out [B,out_C,H1,W1]. */
 int motif_raft_corr_lookup_pyramid(const float* fmap1, const float* const* fmap2, const int* H2, const int* W2, int levels,
                                    const float* coords, float* out, int B, int H1, int W1, int C, int r,
-                                   int out_C, float div, void* stream);
+                                   int out_C, float div, const int32_t* index1_host, const int32_t* index2_host, void* stream);
+/* index1_host / index2_host (HOST int32 [B], may be NULL = identity; B <= 16 when given): pair b correlates fmap1[index1[b]] with
+ * fmap2[.][index2[b]] -- MoTIF feeds the pairs (a,b) and (b,a) of one frame stack (Ours.py:544), so the encoders run once per frame
+ * and the pairing is an index, not a gathered copy of five feature maps. */
 
 /* C4  PWC-Net 9x9 cost volume.  Replaces kernel_Correlation_rearrange + kernel_Correlation_updateOutput
  * (OpticalFlow/correlation.py:17-112,294-348): out[b,(dy+4)*9+(dx+4),y,x] = mean_c f1*f2(y+dy,x+dx). */
@@ -276,9 +279,11 @@ int motif_corr81_fwd(const float* first, const float* second, float* out, int B,
 /* ------------------------------------------------------------------------------------------------
  * Pointwise / resampling kernels of the path (E1, F1 and RAFT/encoder glue).
  * ---------------------------------------------------------------------------------------------- */
-/* F.interpolate(mode='bilinear') (Ours.py:540,548; PCD_Align 123-167; utils.py:80-82), out *= mul */
+/* F.interpolate(mode='bilinear') (Ours.py:540,548; PCD_Align 123-167; utils.py:80-82), out *= mul.
+ * post: 0 = nothing more; 1 = the result is additionally normalised as RAFT's input, 2 * ((v * 255) / 255) - 1 with the roundings of the
+ * reference's four element-wise operations (Ours.py:544 `* 255`, raft.py:90-91) -- the HR frames feed nothing else. */
 int motif_resize_bilinear(const float* in, float* out, int NC, int H, int W, int Ho, int Wo,
-                          int align_corners, float mul, void* stream);
+                          int align_corners, float mul, int post, void* stream);
 /* BackWarp.forward (Ours.py:899-923): (x/w)*2-1 grid, grid_sample(bilinear, align_corners=True, border);
  * sign multiplies `img` (the -flow case at Ours.py:565). */
 int motif_backwarp(const float* img, const float* flow, float* out, int N, int C, int H, int W, float sign, void* stream);
@@ -318,6 +323,8 @@ int motif_gru_update(const float* z, const float* q, const float* h, float* out,
 int motif_lstm_gates(const float* cc, const float* c_cur, float* h_next, float* c_next, int B, int hid, int HW, void* stream);
 /* out = a*x + b*y (y may be NULL) */
 int motif_axpby(const float* x, const float* y, float a, float b, float* out, long n, void* stream);
+/* the same for B items of n elements, item i written at out + i * out_bs (a channel slice of a wider tensor) */
+int motif_axpby_bs(const float* x, const float* y, float a, float b, float* out, int B, long n, long out_bs, void* stream);
 /* The flow LunaTokis.forward returns (Ours.py:794 scales the prediction up, (p*20)*ratio, :858 scales it back, /20 /ratio):
  * pred [N,3,Q] -> out [N,2,Q] = (((p*a)*b)/a)/b with the four roundings of the four torch operations. */
 int motif_flow_roundtrip(const float* pred, float* out, int N, long Q, float a, float b, void* stream);

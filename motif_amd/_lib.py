@@ -53,9 +53,9 @@ _SIGS = {
                                      + [c_int] * 6 + [c_long, c_long, c_int, c_int, P, P]),
     "motif_dcn_split_pack": (c_long, [P, P, c_int, c_int, P]),
     "motif_raft_corr_lookup": (c_int, [P, P, P, c_float, P] + [c_int] * 7 + [c_int, c_int, c_float, P]),
-    "motif_raft_corr_lookup_pyramid": (c_int, [P, POINTER(c_void_p), POINTER(c_int), POINTER(c_int), c_int, P, P] + [c_int] * 6 + [c_float, P]),
+    "motif_raft_corr_lookup_pyramid": (c_int, [P, POINTER(c_void_p), POINTER(c_int), POINTER(c_int), c_int, P, P] + [c_int] * 6 + [c_float, POINTER(c_int), POINTER(c_int), P]),
     "motif_corr81_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "motif_resize_bilinear": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    "motif_resize_bilinear": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     "motif_backwarp": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "motif_pwc_backward_warp": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "motif_reliability_fwd": (c_int, [P, P, c_long, P, P, P, P, c_int, c_int, c_int, P]),
@@ -68,6 +68,7 @@ _SIGS = {
     "motif_gru_update": (c_int, [P, P, P, P, c_long, P]),
     "motif_lstm_gates": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "motif_axpby": (c_int, [P, P, c_float, c_float, P, c_long, P]),
+    "motif_axpby_bs": (c_int, [P, P, c_float, c_float, P, c_int, c_long, c_long, P]),
     "motif_flow_roundtrip": (c_int, [P, P, c_int, c_long, c_float, c_float, P]),
     "motif_deconv4x4s2": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
 }

@@ -13,6 +13,7 @@ struct LookupArgs {
     float coord_scale[4]; float* out;
     int H1, W1, H2[4], W2[4], C, out_C, ch_off[4];
     float div;
+    int idx1[16], idx2[16];   // pair b reads fmap1[idx1[b]] and fmap2[.][idx2[b]] (identity unless the caller pairs maps of a shared stack)
 };
 
 // grid: x = 64-query tiles, y = batch, z = pyramid level (all levels of AlternateCorrBlock in one launch)
@@ -32,6 +33,7 @@ __global__ __launch_bounds__(256) void raft_lookup_kernel(LookupArgs a) {
     __shared__ float tile[49][65];
     __shared__ float dots[4][64];
     const int b = blockIdx.y, lv = blockIdx.z;
+    const int b1 = a.idx1[b & 15], b2 = a.idx2[b & 15];
     const float* __restrict__ fmap2 = a.fmap2[lv];
     const int H2 = a.H2[lv], W2 = a.W2[lv], C = a.C;
     const float cs = a.coord_scale[lv];
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void raft_lookup_kernel(LookupArgs a) {
         const float dx = x - fx, dy = y - fy;
         float s = 0.f;
         if (C == 128) {
-            const f32x4* f1 = (const f32x4*)(a.fmap1 + ((long)b * HW1 + q) * 128) + sub * 2;
+            const f32x4* f1 = (const f32x4*)(a.fmap1 + ((long)b1 * HW1 + q) * 128) + sub * 2;
             const f32x4 u0 = f1[0], u1 = f1[1];
             // the 16 neighbour rows of this 16-lane group in two batches of 8: UNCONDITIONAL loads from the clamped position
             // (out-of-range neighbours are zeroed afterwards), all of a batch in flight together -- predicated loads put each
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void raft_lookup_kernel(LookupArgs a) {
                     const int h2 = (int)fy - 3 + (nb >> 3), w2 = (int)fx - 3 + (nb & 7);
                     okn[i] = h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2;
                     const int hc = h2 < 0 ? 0 : (h2 > H2 - 1 ? H2 - 1 : h2), wc = w2 < 0 ? 0 : (w2 > W2 - 1 ? W2 - 1 : w2);
-                    const f32x4* f2 = (const f32x4*)(fmap2 + (((long)b * H2 + hc) * W2 + wc) * 128) + sub * 2;
+                    const f32x4* f2 = (const f32x4*)(fmap2 + (((long)b2 * H2 + hc) * W2 + wc) * 128) + sub * 2;
                     v0[i] = f2[0]; v1[i] = f2[1];
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -87,8 +89,8 @@ __global__ __launch_bounds__(256) void raft_lookup_kernel(LookupArgs a) {
         } else {
             const int h2 = (int)fy - 3 + gy, w2 = (int)fx - 3 + gx;
             if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
-                const f32x4* f1 = (const f32x4*)(a.fmap1 + ((long)b * HW1 + q) * C);
-                const f32x4* f2 = (const f32x4*)(fmap2 + (((long)b * H2 + h2) * W2 + w2) * C);
+                const f32x4* f1 = (const f32x4*)(a.fmap1 + ((long)b1 * HW1 + q) * C);
+                const f32x4* f2 = (const f32x4*)(fmap2 + (((long)b2 * H2 + h2) * W2 + w2) * C);
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 8
                 for (int c = 0; c < C / 4; ++c) {
@@ -115,12 +117,21 @@ __global__ __launch_bounds__(256) void raft_lookup_kernel(LookupArgs a) {
     }
 }
 
+static int motif_raft_corr_lookup_pyramid_big(const float* fmap1, const float* const* fmap2, const int* H2, const int* W2, int levels, const float* coords,
+                                              float* out, int B, int H1, int W1, int C, int r, int out_C, float div, void* stream);
 extern "C" int motif_raft_corr_lookup_pyramid(const float* fmap1, const float* const* fmap2, const int* H2, const int* W2, int levels,
                                               const float* coords, float* out, int B, int H1, int W1, int C, int r,
-                                              int out_C, float div, void* stream) {
+                                              int out_C, float div, const int32_t* index1_host, const int32_t* index2_host, void* stream) {
     if (!fmap1 || !fmap2 || !coords || !out || !H2 || !W2 || B < 1 || levels < 1 || levels > 4) return MOTIF_EINVAL;
     if (r != 3 || (C & 3)) return MOTIF_ELIMIT;
+    if ((index1_host || index2_host) && B > 16) return MOTIF_ELIMIT;
     LookupArgs a;
+    for (int i = 0; i < 16; ++i) {
+        a.idx1[i] = (index1_host && i < B) ? index1_host[i] : i;
+        a.idx2[i] = (index2_host && i < B) ? index2_host[i] : i;
+        if (a.idx1[i] < 0 || a.idx2[i] < 0) return MOTIF_EINVAL;
+    }
+    if (B > 16) return motif_raft_corr_lookup_pyramid_big(fmap1, fmap2, H2, W2, levels, coords, out, B, H1, W1, C, r, out_C, div, stream);
     a.fmap1 = fmap1; a.coords = coords; a.out = out; a.H1 = H1; a.W1 = W1; a.C = C; a.out_C = out_C; a.div = div;
     for (int i = 0; i < 4; ++i) {
         const int j = i < levels ? i : 0;
@@ -140,7 +151,17 @@ extern "C" int motif_raft_corr_lookup(const float* fmap1, const float* fmap2, co
                                       int out_C, int ch_off, float div, void* stream) {
     if (!fmap1 || !fmap2 || !coords || !out || B < 1) return MOTIF_EINVAL;
     if (r != 3 || (C & 3)) return MOTIF_ELIMIT;
+    if (B > 16) {                                        // the kernel's batch index maps hold 16 entries: larger batches in slices
+        for (int b0 = 0; b0 < B; b0 += 16) {
+            const int nb = B - b0 < 16 ? B - b0 : 16;
+            const int rc = motif_raft_corr_lookup(fmap1 + (long)b0 * H1 * W1 * C, fmap2 + (long)b0 * H2 * W2 * C, coords + (long)b0 * 2 * H1 * W1, coord_scale,
+                                                  out + (long)b0 * out_C * H1 * W1, nb, H1, W1, H2, W2, C, r, out_C, ch_off, div, stream);
+            if (rc != MOTIF_OK) return rc;
+        }
+        return MOTIF_OK;
+    }
     LookupArgs a;
+    for (int i = 0; i < 16; ++i) a.idx1[i] = a.idx2[i] = i;
     a.fmap1 = fmap1; a.coords = coords; a.out = out; a.H1 = H1; a.W1 = W1; a.C = C; a.out_C = out_C; a.div = div;
     for (int i = 0; i < 4; ++i) { a.fmap2[i] = fmap2; a.H2[i] = H2; a.W2[i] = W2; a.coord_scale[i] = coord_scale; a.ch_off[i] = ch_off; }
     dim3 grid(cdiv((long)H1 * W1, 64), B, 1);
@@ -296,5 +317,22 @@ extern "C" int motif_corr81_fwd(const float* first, const float* second, float* 
         corr81_small_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(first, second, out, C, H, W, act);
     }
     MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}
+
+// batches beyond the kernel's 16-entry index maps (identity maps only): slices of 16
+extern "C" int motif_raft_corr_lookup_pyramid(const float* fmap1, const float* const* fmap2, const int* H2, const int* W2, int levels,
+                                              const float* coords, float* out, int B, int H1, int W1, int C, int r,
+                                              int out_C, float div, const int32_t* index1_host, const int32_t* index2_host, void* stream);
+static int motif_raft_corr_lookup_pyramid_big(const float* fmap1, const float* const* fmap2, const int* H2, const int* W2, int levels, const float* coords,
+                                              float* out, int B, int H1, int W1, int C, int r, int out_C, float div, void* stream) {
+    for (int b0 = 0; b0 < B; b0 += 16) {
+        const int nb = B - b0 < 16 ? B - b0 : 16;
+        const float* f2[4];
+        for (int i = 0; i < levels; ++i) f2[i] = fmap2[i] + (long)b0 * H2[i] * W2[i] * C;
+        const int rc = motif_raft_corr_lookup_pyramid(fmap1 + (long)b0 * H1 * W1 * C, f2, H2, W2, levels, coords + (long)b0 * 2 * H1 * W1,
+                                                      out + (long)b0 * out_C * H1 * W1, nb, H1, W1, C, r, out_C, div, nullptr, nullptr, stream);
+        if (rc != MOTIF_OK) return rc;
+    }
     return MOTIF_OK;
 }

@@ -23,9 +23,18 @@ __device__ __forceinline__ float resize_sample(const float* __restrict__ p, int 
 // UP2: exactly x2 up-sampling with align_corners = False (the PCD pyramid's 8x64-plane maps: 0.65 ms per clip).  The four outputs
 // 4k..4k+3 of a row read input columns 2k-1..2k+2 only: 8 loads (clamped, issued together) instead of 16, the same
 // interpolation expression on the same values.
+// post = 1: the value is RAFT's input normalisation of the resized frame, 2 * ((v * 255) / 255) - 1 with the roundings of the four torch
+// operations the reference spends on it (Ours.py:544 `* 255`, raft.py:90-91 `2 * (image / 255.0) - 1.0`; IEEE division, and 2 t - 1
+// contracted to one FMA is the same number because 2 t is exact) -- one pass instead of the resize plus four element-wise kernels.
+__device__ __forceinline__ float resize_fin(float v, float mul, int post) {
+    v *= mul;
+    if (post == 1) { v = v * 255.f; v = v / 255.f; v = 2.f * v - 1.f; }
+    return v;
+}
+
 template <int VEC, bool UP2>
 __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
-                                                               int Ho, int Wo, float sh, float sw, int align, float mul) {
+                                                               int Ho, int Wo, float sh, float sw, int align, float mul, int post) {
     const int gpr = Wo / VEC + (Wo % VEC ? 1 : 0);                    // column groups per row
     const int gi = blockIdx.x * 256 + threadIdx.x;
     if (gi >= Ho * gpr) return;
@@ -53,22 +62,22 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
             const float lx = sx - x0, hx = 1.f - lx;
             constexpr int i0[4] = {0, 1, 1, 2};                       // x0 - xb of outputs 4k..4k+3 (the left edge clamps to the same value)
             const float a = r0[i0[u]], b = r0[i0[u] + 1], c = r1[i0[u]], d = r1[i0[u] + 1];
-            v[u] = (hy * (hx * a + lx * b) + ly * (hx * c + lx * d)) * mul;
+            v[u] = resize_fin(hy * (hx * a + lx * b) + ly * (hx * c + lx * d), mul, post);
         }
         *(f32x4*)o = v;
     } else if constexpr (VEC == 4) {
         f32x4 v;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = resize_sample(p, H, W, oy, ox + u, sh, sw, align) * mul;
+        for (int u = 0; u < 4; ++u) v[u] = resize_fin(resize_sample(p, H, W, oy, ox + u, sh, sw, align), mul, post);
         *(f32x4*)o = v;
     } else {
-        *o = resize_sample(p, H, W, oy, ox, sh, sw, align) * mul;
+        *o = resize_fin(resize_sample(p, H, W, oy, ox, sh, sw, align), mul, post);
     }
 }
 
 extern "C" int motif_resize_bilinear(const float* in, float* out, int NC, int H, int W, int Ho, int Wo,
-                                     int align_corners, float mul, void* stream) {
-    if (!in || !out || NC < 1 || H < 1 || W < 1 || Ho < 1 || Wo < 1) return MOTIF_EINVAL;
+                                     int align_corners, float mul, int post, void* stream) {
+    if (!in || !out || NC < 1 || H < 1 || W < 1 || Ho < 1 || Wo < 1 || post < 0 || post > 1) return MOTIF_EINVAL;
     if (NC > 65535 || (long)Ho * Wo >= (1L << 31)) return MOTIF_ELIMIT;
     float sh, sw;
     if (align_corners) { sh = Ho > 1 ? (float)(H - 1) / (Ho - 1) : 0.f; sw = Wo > 1 ? (float)(W - 1) / (Wo - 1) : 0.f; }
@@ -77,12 +86,12 @@ extern "C" int motif_resize_bilinear(const float* in, float* out, int NC, int H,
     if (Wo % 4 == 0 && ((uintptr_t)out & 15) == 0) {
         dim3 grid(cdiv((long)Ho * (Wo / 4), 256), NC);
         if (!align_corners && Ho == 2 * H && Wo == 2 * W && W >= 2)
-            resize_bilinear_kernel<4, true><<<grid, 256, 0, s>>>(in, out, H, W, Ho, Wo, sh, sw, align_corners, mul);
+            resize_bilinear_kernel<4, true><<<grid, 256, 0, s>>>(in, out, H, W, Ho, Wo, sh, sw, align_corners, mul, post);
         else
-            resize_bilinear_kernel<4, false><<<grid, 256, 0, s>>>(in, out, H, W, Ho, Wo, sh, sw, align_corners, mul);
+            resize_bilinear_kernel<4, false><<<grid, 256, 0, s>>>(in, out, H, W, Ho, Wo, sh, sw, align_corners, mul, post);
     } else {
         dim3 grid(cdiv((long)Ho * Wo, 256), NC);
-        resize_bilinear_kernel<1, false><<<grid, 256, 0, s>>>(in, out, H, W, Ho, Wo, sh, sw, align_corners, mul);
+        resize_bilinear_kernel<1, false><<<grid, 256, 0, s>>>(in, out, H, W, Ho, Wo, sh, sw, align_corners, mul, post);
     }
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
@@ -640,6 +649,22 @@ extern "C" int motif_axpby(const float* x, const float* y, float a, float b, flo
     if (!x || !out || n < 1) return MOTIF_EINVAL;
     const int v4 = ((((unsigned long long)x | (unsigned long long)y | (unsigned long long)out)) & 15) == 0;
     axpby_kernel<<<cdiv(v4 ? cdiv(n, 4) : n, 256), 256, 0, (hipStream_t)stream>>>(x, y, a, b, out, n, v4);
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}
+
+// a*x + b*y of B items of n elements each, written to a batch-strided destination (out + i * out_bs): RAFT's flow = coords1 - coords0
+// goes straight into channels 144..145 of the GRU input buffer (raft.py:117-120 concatenates it there)
+__global__ void axpby_bs_kernel(const float* __restrict__ x, const float* __restrict__ y, float a, float b, float* __restrict__ out, long n, long out_bs) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long i = blockIdx.y;
+    if (t < n) out[i * out_bs + t] = y ? a * x[i * n + t] + b * y[i * n + t] : a * x[i * n + t];
+}
+
+extern "C" int motif_axpby_bs(const float* x, const float* y, float a, float b, float* out, int B, long n, long out_bs, void* stream) {
+    if (!x || !out || n < 1 || B < 1) return MOTIF_EINVAL;
+    if (B > 65535) return MOTIF_ELIMIT;
+    axpby_bs_kernel<<<dim3(cdiv(n, 256), B), 256, 0, (hipStream_t)stream>>>(x, y, a, b, out, n, out_bs);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

@@ -22,23 +22,24 @@ def alt_cuda_corr_forward(fmap1, fmap2, coords, r):
 
 class AlternateCorrBlock:
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4, index1=None, index2=None):
-        """index1 / index2 (LongTensors): the maps of pair i are fmap1[index1[i]] and fmap2[index2[i]] -- the channels-last
-        copies and the avg-pool pyramid are built once per distinct map and gathered per pair afterwards."""
+        """index1 / index2 (host int lists): the maps of pair i are fmap1[index1[i]] and fmap2[index2[i]] -- the channels-last
+        copies and the avg-pool pyramid are built once per distinct map; the look-up kernel takes the pairing as two index maps
+        (no gathered copies)."""
         self.num_levels = num_levels
         self.radius = radius
         self.dim = fmap1.shape[1]
-        pick1 = (lambda t: t.index_select(0, index1)) if index1 is not None else (lambda t: t)
-        pick2 = (lambda t: t.index_select(0, index2)) if index2 is not None else (lambda t: t)
-        self.f1 = pick1(ops.nchw_to_nhwc(fmap1))
+        self.index1 = [int(v) for v in index1] if index1 is not None else None
+        self.index2 = [int(v) for v in index2] if index2 is not None else None
+        self.f1 = ops.nchw_to_nhwc(fmap1)
         self.f2 = []
         for i in range(self.num_levels):
-            self.f2.append(pick2(ops.nchw_to_nhwc(fmap2)))
+            self.f2.append(ops.nchw_to_nhwc(fmap2))
             if i + 1 < self.num_levels:
                 fmap2 = ops.avg_pool2(fmap2)
+        self._div = float(torch.sqrt(torch.tensor(self.dim).float()))      # corr.py:87, once per block (a host computation)
 
     def __call__(self, coords):
         b, _, h, w = coords.shape
         n = (2 * self.radius + 1) ** 2
         out = torch.empty(b, self.num_levels * n, h, w, dtype=torch.float32, device=coords.device)
-        div = float(torch.sqrt(torch.tensor(self.dim).float()))
-        return ops.raft_corr_lookup_pyramid(self.f1, self.f2, coords, out, div, self.radius)
+        return ops.raft_corr_lookup_pyramid(self.f1, self.f2, coords, out, self._div, self.radius, self.index1, self.index2)

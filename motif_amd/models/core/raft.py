@@ -26,9 +26,19 @@ def _index_tensor(values, device):
     return t
 
 
+_GRID_CACHE = {}
+
+
 def coords_grid(batch, ht, wd, device):
-    ys, xs = torch.meshgrid(torch.arange(ht, device=device), torch.arange(wd, device=device), indexing="ij")
-    return torch.stack([xs, ys], dim=0).float()[None].repeat(batch, 1, 1, 1)
+    """utils.py:75-78; a constant of (batch, size, device): built once, handed out read-only (callers clone what they update)."""
+    key = (batch, ht, wd, str(device))
+    g = _GRID_CACHE.get(key)
+    if g is None:
+        ys, xs = torch.meshgrid(torch.arange(ht, device=device), torch.arange(wd, device=device), indexing="ij")
+        g = _GRID_CACHE[key] = torch.stack([xs, ys], dim=0).float()[None].repeat(batch, 1, 1, 1).contiguous()
+        if len(_GRID_CACHE) > 16:
+            _GRID_CACHE.pop(next(iter(_GRID_CACHE)))
+    return g
 
 
 def upflow8(flow):
@@ -55,23 +65,25 @@ class RAFT(nn.Module):
         cnet = self.cnet(image1, act=ops.ACT_TANH, act2=ops.ACT_RELU, act_split=self.hidden_dim)
         return self._iterate(corr_fn, cnet, image1.shape, image1.device, iters, flow_init, test_mode, last_only)
 
-    def forward_pairs(self, frames, src, dst, iters=12, last_only=False):
+    def forward_pairs(self, frames, src, dst, iters=12, last_only=False, normalized=False):
         """The same computation for the image pairs (frames[src[i]], frames[dst[i]]), frames [F,3,H,W] in [0,255]: the feature
         and context encoders run ONCE per distinct frame instead of once per pair member -- `Ours.py:544` feeds the pairs
         (a,b) and (b,a), so half of fnet's work there (and 5/6 of it for the 4-frame generators' 12 / 16 pairs) is a repeat.
         Bit-identical to forward(frames[src], frames[dst]): nothing in either encoder crosses the batch dimension (the norm is
         an instance norm), the pairing happens on the 1/8-resolution feature maps."""
-        x = (2 * (frames / 255.0) - 1.0).contiguous()
+        # normalized: `frames` already holds 2 * (f / 255) - 1 (ops.resize_bilinear(..., raft_norm=True) produced them that way)
+        x = frames.contiguous() if normalized else (2 * (frames / 255.0) - 1.0).contiguous()
         dev = frames.device
-        si, di = _index_tensor(src, dev), _index_tensor(dst, dev)
         fmap = self.fnet(x)                                                    # [F,128,h/8,w/8]
         usrc = sorted(set(int(v) for v in src))                                # context net: distinct source frames only
         cn = self.cnet(x[usrc] if len(usrc) < x.shape[0] else x, act=ops.ACT_TANH, act2=ops.ACT_RELU, act_split=self.hidden_dim)
         pos = {f: i for i, f in enumerate(usrc)}
-        ci = _index_tensor([pos[int(v)] for v in src], dev)
-        corr_fn = AlternateCorrBlock(fmap, fmap, radius=self.args.corr_radius, index1=si, index2=di)
+        cidx = [pos[int(v)] for v in src]
+        corr_fn = AlternateCorrBlock(fmap, fmap, radius=self.args.corr_radius, index1=src, index2=dst)
         shape = (len(src),) + tuple(frames.shape[1:])
-        return self._iterate(corr_fn, cn.index_select(0, ci), shape, dev, iters, None, False, last_only)
+        if cidx != list(range(cn.shape[0])):                                   # (a,b),(b,a) of one stack: the context maps are already in pair order
+            cn = cn.index_select(0, _index_tensor(cidx, dev))
+        return self._iterate(corr_fn, cn, shape, dev, iters, None, False, last_only)
 
     def _iterate(self, corr_fn, cnet, shape, device, iters, flow_init, test_mode, last_only):
         class _Dev:                                       # (shape, device) of image1 as the update loop needs them
@@ -80,7 +92,7 @@ class RAFT(nn.Module):
         image1.shape, image1.device = shape, device
         b, _, h, w = image1.shape
         h8, w8 = h // 8, w // 8
-        net = cnet[:, :self.hidden_dim].contiguous()
+        net = cnet[:, :self.hidden_dim]                  # a channel slice: dense planes, batch stride of the full map (the kernels take it)
         # GRU input buffer [inp(64) | motion encoder out(80) | flow(2)] -- written in place, never concatenated
         xbuf = torch.empty(b, 146, h8, w8, dtype=torch.float32, device=image1.device)
         xbuf[:, :64].copy_(cnet[:, self.hidden_dim:])
@@ -92,9 +104,8 @@ class RAFT(nn.Module):
         preds = []
         for itr in range(iters):
             corr = corr_fn(coords1)
-            flow = ops.axpby(coords1, coords0, 1.0, -1.0)
+            flow = ops.axpby_into(coords1, coords0, 1.0, -1.0, xbuf[:, 144:146])     # written where the GRU reads it (raft.py:117-120 concatenates)
             ub.encoder(flow, corr, out=xbuf[:, 64:144])
-            xbuf[:, 144:146].copy_(flow)
             net = ub.gru(net, xbuf)
             delta = ub.flow_head(net)
             coords1 = ops.axpby(coords1, delta, 1.0, 1.0)

@@ -213,8 +213,8 @@ class ResidualBlock_noBN(nn.Module):
         self.conv1 = Conv2d(nf, nf, 3, 1, 1)
         self.conv2 = Conv2d(nf, nf, 3, 1, 1)
 
-    def forward(self, x):
-        return self.conv2(self.conv1(x, act=RELU), res=x, res_mode=1)
+    def forward(self, x, out=None):
+        return self.conv2(self.conv1(x, act=RELU), res=x, res_mode=1, out=out)
 
 
 class ZSM_encoder(nn.Module):
@@ -234,22 +234,29 @@ class ZSM_encoder(nn.Module):
 
     def forward(self, x, target_t=None):           # x [B,N,3,H,W] -> [B,2N-1,64,H,W]
         B, N, C, H, W = x.shape
+        T = 2 * N - 1
         l1 = self.conv_first(x.reshape(-1, C, H, W), act=LRELU)
-        for rb in self.feature_extraction:
+        seq = torch.empty(B, T, l1.shape[1], H, W, dtype=torch.float32, device=x.device)
+        # the L1 features ARE the even entries of the sequence (Ours.py:383-391 copies them there): with one clip per call the last
+        # residual block stores them in place (seq[0, 0::2] = N planar maps, batch stride of two); B > 1 keeps the copies
+        in_place = B == 1
+        blocks = list(self.feature_extraction)
+        for rb in blocks[:-1]:
             l1 = rb(l1)
+        l1 = blocks[-1](l1, out=seq[0, 0::2] if in_place else None)
         l2 = self.fea_L2_conv2(self.fea_L2_conv1(l1, act=LRELU), act=LRELU)
         l3 = self.fea_L3_conv2(self.fea_L3_conv1(l2, act=LRELU), act=LRELU)
-        l1, l2, l3 = (t.view(B, N, *t.shape[1:]) for t in (l1, l2, l3))
-        T = 2 * N - 1
-        seq = torch.empty(B, T, l1.shape[2], H, W, dtype=torch.float32, device=x.device)
+        l1 = seq[:, 0::2] if in_place else l1.view(B, N, *l1.shape[1:])
+        l2, l3 = (t.view(B, N, *t.shape[1:]) for t in (l2, l3))
         for i in range(N - 1):
             fea1 = [l1[:, i], l2[:, i], l3[:, i]]
             fea2 = [l1[:, i + 1], l2[:, i + 1], l3[:, i + 1]]
             y1, y2 = self.pcd_align(fea1, fea2)
             self.fusion(y1, y2, out=seq[:, 2 * i + 1])
-            if i == 0:
-                seq[:, 0].copy_(fea1[0])
-            seq[:, 2 * i + 2].copy_(fea2[0])
+            if not in_place:
+                if i == 0:
+                    seq[:, 0].copy_(fea1[0])
+                seq[:, 2 * i + 2].copy_(fea2[0])
         feats = self.ConvBLSTM(seq)
         out = feats.view(B * T, -1, H, W)
         for rb in self.recon_trunk:
@@ -331,6 +338,7 @@ class LunaTokis(nn.Module):
     number D of source frames splatted into every output frame; the kernels are the same."""
     D = 2                                  # source frames ("directions")
     FLOW_IN, FLOW_GROUPS = 14, 2           # first flow_process conv (Ours.py:494)
+    supports_frames_out = True             # forward(..., frames_out=): render into the caller's tensor (VideoSRBaseModel._test_eager)
 
     def __init__(self, setting=5):
         super().__init__()
@@ -395,7 +403,8 @@ class LunaTokis(nn.Module):
         return fp[9](y)
 
     def _raft_pairs(self, hr, pairs, n_flows, H, W, iters):
-        """RAFT on the listed (source, target) frame pairs of the HR frames `hr` [B,n,3,HH,WW]; flow k of `n_flows` is
+        """RAFT on the listed (source, target) frame pairs of the HR frames `hr` [B,n,3,HH,WW] (ALREADY normalised as RAFT's input:
+        ops.resize_bilinear(..., raft_norm=True)); flow k of `n_flows` is
         pair (src, dst) = pairs[k] or None for a flow the reference multiplies by zero (Ours.py:552-553, Ours_4.py:509-510,
         Ours_44.py:513-516) -- those pairs are not run unless skip_zero_pairs is off.  -> LR flows [n_flows*B,2,H,W]."""
         B, n, HH, WW = hr.shape[0], hr.shape[1], hr.shape[3], hr.shape[4]
@@ -407,9 +416,14 @@ class LunaTokis(nn.Module):
         # a row-tiled clip may ask for RAFT's instance-norm statistics over all ranks (motif_amd.dist.render_clip_tiled(sync_norm=True))
         ns = getattr(self, "norm_sync", None)
         with (extractor.norm_sync(ns[0], HH, ns[1]) if ns is not None else contextlib.nullcontext()):
-            f = self.flow_predictor.forward_pairs(hr.reshape(B * n, 3, HH, WW) * 255.0, src, dst, iters=iters, last_only=True)[-1]
-        f = ops.resize_bilinear(f, (H, W), False, H / HH)
+            f = self.flow_predictor.forward_pairs(hr.reshape(B * n, 3, HH, WW), src, dst, iters=iters, last_only=True, normalized=True)[-1]
         flow = torch.zeros(n_flows * B, 2, H, W, dtype=torch.float32, device=hr.device)
+        ks = [k for k, _ in live]
+        if all(nz for _, (_, _, nz) in live) and ks == list(range(ks[0], ks[0] + len(ks))):
+            # the live flows are consecutive slots (01, 10 of the four pairs): the down-sampling writes them in place
+            ops.resize_bilinear(f, (H, W), False, H / HH, out=flow[ks[0] * B:(ks[0] + len(ks)) * B])
+            return flow
+        f = ops.resize_bilinear(f, (H, W), False, H / HH)
         for i, (k, (s, d, nz)) in enumerate(live):
             if nz:
                 flow[k * B:(k + 1) * B].copy_(f[i * B:(i + 1) * B])
@@ -423,7 +437,8 @@ class LunaTokis(nn.Module):
         """fr [B,2,3,H,W] -> flow [4B,2,H,W] (pairs 00,01,10,11), psies [4B,3,H,W], flow-encoder input [2B,14,H,W]
         (Ours.py:540-578, 614-631)."""
         B, n, _, H, W = fr.shape
-        hr = ops.resize_bilinear(fr.reshape(B * n, 3, H, W), (HH, WW), False).view(B, n, 3, HH, WW)
+        # the HR frames feed RAFT only: the resize kernel also applies `* 255` (Ours.py:544) and RAFT's 2 * (x / 255) - 1 (raft.py:90-91)
+        hr = ops.resize_bilinear(fr.reshape(B * n, 3, H, W), (HH, WW), False, raft_norm=True).view(B, n, 3, HH, WW)
         flow = self._raft_pairs(hr, [(0, 0, False), (0, 1, True), (1, 0, True), (1, 1, False)], 4, H, W, iters)
         psies, flow_feat_in = ops.reliability(fr[:, 0], fr[:, 1], flow, self.g_filter, B, H, W)
         return flow, psies, flow_feat_in
@@ -431,6 +446,8 @@ class LunaTokis(nn.Module):
     def _encode(self, fr):
         """-> encoder features [B,T,64,H,W], the D source features [D*B,64,H,W] (Ours.py:601-611)"""
         feat = self.encoder(fr, None)                                          # [B,3,64,H,W]
+        if feat.shape[0] == 1:
+            return feat, feat[0, 0::2]                                         # the two source features as a view: planar maps, batch stride of two
         return feat, torch.cat((feat[:, 0], feat[:, 2]), 0)
 
     def _residual(self, c, target_t):
@@ -476,17 +493,19 @@ class LunaTokis(nn.Module):
         return ops.siren_imnet(blob, ops.conv2d(self.imnet.l0_plan(0, 64), c["feat01"]), iy, ix, rel_y, rel_x, HH, WW, pre=ops.siren_pre(),
                                add_lr=add_lr)
 
-    def _splat_synth(self, c, imnet_out, pred, sl, iy, ix, times, B, N, H, HH, WW, synth_blob, synth_l0, pre, acc, accumulate, row0=0, finish=True):
-        """fused splat of one direction pair (+ synth_net when `finish`); -> acc, frames"""
+    def _splat_synth(self, c, imnet_out, pred, sl, iy, ix, times, B, N, H, HH, WW, synth_blob, synth_l0, pre, acc, accumulate, row0=0, finish=True,
+                     frames_out=None):
+        """fused splat of one direction pair (+ synth_net when `finish`, into `frames_out` if given); -> acc, frames"""
+        okw = {"out": frames_out} if frames_out is not None else {}
         if self._pc():
             pp = self._pre_plan()
             acc = ops.splat_motif_pre(imnet_out, pred, None, pp["ab"], iy, ix, self.alpha, HH_over_H(c, H), B, N, HH, WW,
                                       acc=acc, row0=row0, accumulate=accumulate, lr_size=c["lr_size"])
-            frames = ops.siren_synth_pre(pp["synth_blob"], acc, synth_l0, iy, ix, times, B, N, HH, WW) if finish else None
+            frames = ops.siren_synth_pre(pp["synth_blob"], acc, synth_l0, iy, ix, times, B, N, HH, WW, **okw) if finish else None
         else:
             acc = ops.splat_motif(imnet_out, pred, c["feat01"][sl], iy, ix, self.alpha, HH_over_H(c, H), B, N, HH, WW,
                                   acc=acc, row0=row0, accumulate=accumulate)
-            frames = ops.siren_synth(synth_blob, acc, synth_l0, iy, ix, times, B, N, HH, WW, pre=pre) if finish else None
+            frames = ops.siren_synth(synth_blob, acc, synth_l0, iy, ix, times, B, N, HH, WW, pre=pre, **okw) if finish else None
         return acc, frames
 
     def _clip_stage(self, x, HH, WW, iters):
@@ -558,7 +577,7 @@ class LunaTokis(nn.Module):
         if key != self._cache_key:
             self._cache, self._cache_key = self._clip_stage(x.float(), HH, WW, iters), key
             self._cache["x"] = x
-        return {k: self._cache[k] for k in self.clip_cache_names()}
+        return {k: self._cache[k].contiguous() for k in self.clip_cache_names()}
 
     def import_clip_cache(self, x, HH, WW, iters, tensors):
         """Install a t-independent stage computed elsewhere (another rank) for clip `x`: later forward calls with the same
@@ -607,7 +626,9 @@ class LunaTokis(nn.Module):
 
     # ----------------------------------------------------------------------------- forward
     def forward(self, x, input_target_frames, target_t, scale=None, rank=0, train_idx=0, use_GT=True, iter=12, flows=None,
-                stages=None):
+                stages=None, frames_out=None):
+        """frames_out (MI355X addition, optional): a contiguous [N,B,3,HH,WW] tensor the frames are rendered into -- the shell passes
+        slices of its whole-clip buffer instead of concatenating the <=3-timestamp chunks (VideoSR_base_model.py:189-193)."""
         if self.training or use_GT:
             raise NotImplementedError("this is the inference path (VideoSR_base_model.py:189: use_GT=False, eval mode)")
         ops.require_device(x, "LunaTokis runs on the MI355X HIP kernels only; move inputs to 'cuda'")
@@ -639,7 +660,7 @@ class LunaTokis(nn.Module):
             sl = slice(d0 * B, (d0 + 2) * B)
             pred = ops.siren_flow(flow_blob, c["flow_l0"][sl], iy, ix, rel_y, rel_x, times, N, HH, WW, pre=pre)   # [2BN,3,HH,WW]
             acc, frames = self._splat_synth(c, c["imnet_out"][sl], pred, sl, iy, ix, times, B, N, H, HH, WW, synth_blob, synth_l0, pre,
-                                            acc, d0 > 0, finish=d0 + 2 >= self.D)
+                                            acc, d0 > 0, finish=d0 + 2 >= self.D, frames_out=frames_out)
             preds.append(pred)
         pred = preds[0] if len(preds) == 1 else torch.cat(preds, 0)              # [D*B*N,3,HH,WW]
         if stages is not None:

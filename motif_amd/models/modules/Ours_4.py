@@ -31,7 +31,7 @@ class LunaTokis(_Base):
     def _motion_stage(self, fr, HH, WW, iters):
         """fr [B,4,3,H,W] -> flow [8B,2,H,W] (kept flows), psies [8B,3,H,W], flow-encoder input [2B,28,H,W]"""
         B, n, _, H, W = fr.shape
-        hr = ops.resize_bilinear(fr.reshape(B * n, 3, H, W), (HH, WW), False).view(B, n, 3, HH, WW)
+        hr = ops.resize_bilinear(fr.reshape(B * n, 3, H, W), (HH, WW), False, raft_norm=True).view(B, n, 3, HH, WW)     # already RAFT-normalised
         flow12 = self._raft_pairs(hr, _PAIRS, 12, H, W, iters)
         psies, flow_feat_in = ops.reliability_pairs(fr, flow12, self.g_filter, _TABLE, _DUR, 4)
         return flow12[2 * B:10 * B], psies, flow_feat_in

@@ -31,7 +31,7 @@ class LunaTokis(_Base):
     def _motion_stage(self, fr, HH, WW, iters):
         """fr [B,4,3,H,W] -> flow [16B,2,H,W], psies [16B,3,H,W], flow-encoder input [4B,28,H,W]"""
         B, n, _, H, W = fr.shape
-        hr = ops.resize_bilinear(fr.reshape(B * n, 3, H, W), (HH, WW), False).view(B, n, 3, HH, WW)
+        hr = ops.resize_bilinear(fr.reshape(B * n, 3, H, W), (HH, WW), False, raft_norm=True).view(B, n, 3, HH, WW)     # already RAFT-normalised
         flow = self._raft_pairs(hr, _PAIRS, 16, H, W, iters)
         psies, flow_feat_in = ops.reliability_pairs(fr, flow, self.g_filter, _TABLE, _DUR, 4)
         return flow, psies, flow_feat_in

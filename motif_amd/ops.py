@@ -495,23 +495,31 @@ def siren_flow(blob, flowfeat_lr, iy, ix, rel_y, rel_x, times, N, HH, WW, pre=Fa
     return pred
 
 
-def siren_synth(blob, acc, residual_lr, iy, ix, times, B, N, HH, WW, pre=False):
+def _frames_out(out, N, B, HH, WW, device):
+    if out is None:
+        return torch.empty(N, B, 3, HH, WW, dtype=torch.float32, device=device)
+    if tuple(out.shape) != (N, B, 3, HH, WW) or not out.is_contiguous():
+        raise RuntimeError("frames `out` must be a contiguous [%d,%d,3,%d,%d] tensor" % (N, B, HH, WW))
+    return out
+
+
+def siren_synth(blob, acc, residual_lr, iy, ix, times, B, N, HH, WW, pre=False, out=None):
     lib = _lib.load()
     residual_lr = _c(residual_lr)
     _, _, h, w = residual_lr.shape
-    frames = torch.empty(N, B, 3, HH, WW, dtype=torch.float32, device=acc.device)
+    frames = _frames_out(out, N, B, HH, WW, acc.device)
     check(lib.motif_siren_synth_fwd(_p(blob), _p(acc), _p(residual_lr), _p(iy), _p(ix), _p(_c(times)), _p(frames),
                                     B, N, h, w, HH, WW, int(pre), _status_ptr(), _stream()), "motif_siren_synth_fwd")
     return frames
 
 
-def siren_synth_pre(blob, acc67, residual_l0, iy, ix, times, B, N, HH, WW, pre=None):
+def siren_synth_pre(blob, acc67, residual_l0, iy, ix, times, B, N, HH, WW, pre=None, out=None):
     """synth_net on the pre-contracted accumulator of splat_motif_pre (blob: siren_pack_split(SIREN_SYNTH_PRE, ...), same `pre`)."""
     lib = _lib.load()
     pre = siren_pre() if pre is None else pre
     residual_l0 = _c(residual_l0)
     _, _, h, w = residual_l0.shape
-    frames = torch.empty(N, B, 3, HH, WW, dtype=torch.float32, device=acc67.device)
+    frames = _frames_out(out, N, B, HH, WW, acc67.device)
     check(lib.motif_siren_synth_pre_fwd(_p(blob), _p(acc67), _p(residual_l0), _p(iy), _p(ix), _p(_c(times)), _p(frames),
                                         B, N, h, w, HH, WW, int(pre), _status_ptr(), _stream()), "motif_siren_synth_pre_fwd")
     return frames
@@ -585,13 +593,18 @@ def splat_motif_pre(u_hr, pred, g_lr, ab, iy, ix, alpha, flow_scale, B, N, HH, W
 
 
 # ----------------------------------------------------------------------------------------- misc
-def resize_bilinear(x, size, align_corners=False, mul=1.0):
+def resize_bilinear(x, size, align_corners=False, mul=1.0, out=None, raft_norm=False):
+    """raft_norm: the result is also normalised as RAFT's input (motif_resize_bilinear post = 1); out: a contiguous destination."""
     lib = _lib.load()
     x = _c(x)
     n, c, h, w = x.shape
     ho, wo = size
-    out = torch.empty(n, c, ho, wo, dtype=torch.float32, device=x.device)
-    check(lib.motif_resize_bilinear(_p(x), _p(out), n * c, h, w, ho, wo, int(align_corners), float(mul), _stream()), "motif_resize_bilinear")
+    if out is None:
+        out = torch.empty(n, c, ho, wo, dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (n, c, ho, wo) or not out.is_contiguous():
+        raise RuntimeError("resize_bilinear: `out` must be a contiguous [%d,%d,%d,%d] tensor" % (n, c, ho, wo))
+    check(lib.motif_resize_bilinear(_p(x), _p(out), n * c, h, w, ho, wo, int(align_corners), float(mul), int(bool(raft_norm)), _stream()),
+          "motif_resize_bilinear")
     return out
 
 
@@ -707,14 +720,24 @@ def raft_corr_lookup(fmap1_nhwc, fmap2_nhwc, coords, coord_scale, out, ch_off, d
     return out
 
 
-def raft_corr_lookup_pyramid(fmap1_nhwc, fmap2_levels, coords, out, div, r=3):
+def raft_corr_lookup_pyramid(fmap1_nhwc, fmap2_levels, coords, out, div, r=3, index1=None, index2=None):
+    """index1 / index2 (host int lists, one entry per pair = row of `coords`): pair i correlates fmap1[index1[i]] with
+    fmap2[.][index2[i]]; None = the maps are already ordered per pair."""
     lib = _lib.load()
-    b, h1, w1, c = fmap1_nhwc.shape
+    _, h1, w1, c = fmap1_nhwc.shape
+    b = coords.shape[0]
     n = len(fmap2_levels)
     hs = (ctypes.c_int * n)(*[f.shape[1] for f in fmap2_levels])
     ws = (ctypes.c_int * n)(*[f.shape[2] for f in fmap2_levels])
+    for idx, nmaps in ((index1, fmap1_nhwc.shape[0]), (index2, fmap2_levels[0].shape[0])):
+        if idx is not None and (len(idx) != b or min(idx) < 0 or max(idx) >= nmaps):
+            raise RuntimeError("raft_corr_lookup_pyramid: bad batch index map %r for %d pairs over %d maps" % (list(idx), b, nmaps))
+    if index1 is None and index2 is None and (fmap1_nhwc.shape[0] != b or fmap2_levels[0].shape[0] != b):
+        raise RuntimeError("raft_corr_lookup_pyramid: %d pairs but %d / %d feature maps" % (b, fmap1_nhwc.shape[0], fmap2_levels[0].shape[0]))
+    i1 = (ctypes.c_int * b)(*[int(v) for v in index1]) if index1 is not None else None
+    i2 = (ctypes.c_int * b)(*[int(v) for v in index2]) if index2 is not None else None
     check(lib.motif_raft_corr_lookup_pyramid(_p(fmap1_nhwc), _ptr_array(fmap2_levels), hs, ws, n, _p(_c(coords)), _p(out),
-                                             b, h1, w1, c, r, out.shape[1], float(div), _stream()), "motif_raft_corr_lookup_pyramid")
+                                             b, h1, w1, c, r, out.shape[1], float(div), i1, i2, _stream()), "motif_raft_corr_lookup_pyramid")
     return out
 
 
@@ -748,6 +771,19 @@ def axpby(x, y=None, a=1.0, b=1.0):
     x = _c(x)
     out = torch.empty_like(x)
     check(lib.motif_axpby(_p(x), _p(_c(y)) if y is not None else None, float(a), float(b), _p(out), x.numel(), _stream()), "motif_axpby")
+    return out
+
+
+def axpby_into(x, y, a, b, out):
+    """out[i] = a*x[i] + b*y[i] for the items i of the leading dimension, `out` a batch-strided view with dense items (a channel
+    slice of a wider tensor): motif_axpby_bs."""
+    lib = _lib.load()
+    x = _c(x)
+    n = x[0].numel()
+    if tuple(out.shape) != tuple(x.shape) or not out[0].is_contiguous():
+        raise RuntimeError("axpby_into: `out` must have x's shape and dense items")
+    check(lib.motif_axpby_bs(_p(x), _p(_c(y)) if y is not None else None, float(a), float(b), _p(out), x.shape[0], n, out.stride(0), _stream()),
+          "motif_axpby_bs")
     return out
 
 

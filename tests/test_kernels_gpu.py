@@ -649,6 +649,20 @@ def test_splat_empty_flow_is_identity_count_four_corners():
 
 
 # ------------------------------------------------------------------------------------------- resampling
+def test_resize_with_raft_normalisation_and_into_a_slice_is_bit_exact():
+    """motif_resize_bilinear post = 1: the HR frames come out as RAFT's normalised input, 2 * ((v * 255) / 255) - 1 with the roundings of
+    the reference's four element-wise operations (Ours.py:544, raft.py:90-91); `out=`: the result lands in a slice of a wider tensor."""
+    from motif_amd import ops
+    x = torch.rand(4, 3, 36, 64, generator=torch.Generator().manual_seed(3))
+    plain = ops.resize_bilinear(x.to(dev()), (144, 256), False)
+    want = 2 * ((plain * 255.0) / 255.0) - 1.0
+    got = ops.resize_bilinear(x.to(dev()), (144, 256), False, raft_norm=True)
+    assert torch.equal(got, want)
+    buf = torch.full((6, 3, 18, 32), 7.0, device=dev())
+    ops.resize_bilinear(x.to(dev()), (18, 32), False, 0.5, out=buf[1:5])
+    assert torch.equal(buf[1:5], ops.resize_bilinear(x.to(dev()), (18, 32), False, 0.5)) and bool((buf[0] == 7.0).all()) and bool((buf[5] == 7.0).all())
+
+
 @pytest.mark.parametrize("align", [False, True])
 @pytest.mark.parametrize("shape", [((18, 32), (72, 128)), ((72, 128), (18, 32)), ((9, 16), (18, 32)), ((45, 80), (90, 160)), ((7, 10), (14, 20)), ((16, 24), (128, 192)), ((23, 31), (47, 50))])
 def test_resize_bilinear(shape, align):
@@ -776,6 +790,12 @@ def test_pool_transpose_gates_axpby():
     xr = rnd(1, 3, 7, 9, seed=15)
     close(ops.axpby(xr.to(dev()), (xr * 2).to(dev()), 1.0, -1.0), -xr, 0)
     close(ops.axpby(xr.to(dev()), None, 0.5, 0.0), xr * 0.5, 0)
+    # batch-strided destination (RAFT: flow = coords1 - coords0 written into two channels of the GRU input buffer)
+    a, b = rnd(3, 2, 9, 13, seed=18), rnd(3, 2, 9, 13, seed=19)
+    buf = torch.full((3, 7, 9, 13), 5.0, device=dev())
+    got = ops.axpby_into(a.to(dev()), b.to(dev()), 1.0, -1.0, buf[:, 4:6])
+    assert got.data_ptr() == buf[:, 4:6].data_ptr() and torch.equal(buf[:, 4:6].cpu(), a - b)
+    assert bool((buf[:, :4] == 5.0).all()) and bool((buf[:, 6:] == 5.0).all())
     cc, c = rnd(2, 8, 5, 7, seed=16, scale=3), rnd(2, 2, 5, 7, seed=17)
     i, f, o, g = torch.split(cc, 2, 1)
     cn = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
