@@ -267,7 +267,7 @@ int motif_raft_corr_lookup(const float* fmap1, const float* fmap2, const float* 
 int motif_raft_corr_lookup_pyramid(const float* fmap1, const float* const* fmap2, const int* H2, const int* W2, int levels,
                                    const float* coords, float* out, int B, int H1, int W1, int C, int r,
                                    int out_C, float div, const int32_t* index1_host, const int32_t* index2_host, void* stream);
-/* index1_host / index2_host (HOST int32 [B], may be NULL = identity; B <= 16 when given): pair b correlates fmap1[index1[b]] with
+/* index1_host / index2_host (HOST int32 [B], may be NULL = identity): pair b correlates fmap1[index1[b]] with
  * fmap2[.][index2[b]] -- MoTIF feeds the pairs (a,b) and (b,a) of one frame stack (Ours.py:544), so the encoders run once per frame
  * and the pairing is an index, not a gathered copy of five feature maps. */
 

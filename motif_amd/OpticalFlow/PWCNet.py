@@ -24,8 +24,8 @@ class _Deconv(nn.Module):
         self.weight = nn.Parameter(torch.empty(cin, cout, 4, 4).uniform_(-0.05, 0.05))
         self.bias = nn.Parameter(torch.zeros(cout))
 
-    def forward(self, x):
-        return ops.deconv4x4s2(x, self.weight, self.bias)
+    def forward(self, x, out=None):
+        return ops.deconv4x4s2(x, self.weight, self.bias, out=out)
 
 
 def _stage(cin, cout):
@@ -81,19 +81,36 @@ class PWCNet(nn.Module):
                 self.moduleSix = nn.Sequential(Conv2d(cur + 448, 2, 3, 1, 1))
 
             def forward(self, first, second, prev):
+                # Dense connections (PWCNet.py:188-213): [vol | first | flow | up] and then every new feature map PREPENDED.  The whole
+                # stack of a level lives in ONE tensor allocated up front; every producer writes its channels in place (the convolutions
+                # and, with one pair per call, the cost volume and the two deconvolutions through `out=`) and every convolution reads
+                # the channels behind its own output as a strided view -- the eleven concatenations per level are gone.
+                B, C, H, W = first.shape
+                own = 448                                                    # 128 + 128 + 96 + 64 + 32 channels of moduleOne .. moduleFiv
+                base = 81 if prev is None else 81 + C + 4
+                buf = torch.empty(B, own + base, H, W, dtype=torch.float32, device=first.device)
+                dense = B == 1                                               # a channel slice of a one-image tensor is contiguous
+
+                def into(lo, hi, fn):
+                    if dense:
+                        fn(buf[:, lo:hi])
+                    else:
+                        buf[:, lo:hi].copy_(fn(None))
+
                 if prev is None:
-                    tensorFeat = ops.corr81(first, second, LRELU)
+                    into(own, own + 81, lambda o: ops.corr81(first, second, LRELU, out=o))
                 else:
-                    flow = self.moduleUpflow(prev["tensorFlow"])
-                    up = self.moduleUpfeat(prev["tensorFeat"])
+                    into(own + 81 + C, own + 81 + C + 2, lambda o: self.moduleUpflow(prev["tensorFlow"], out=o))
+                    into(own + 81 + C + 2, own + 81 + C + 4, lambda o: self.moduleUpfeat(prev["tensorFeat"], out=o))
+                    flow = buf[:, own + 81 + C:own + 81 + C + 2]
                     warped = ops.pwc_backward_warp(second, ops.axpby(flow, None, self.dblBackward, 0.0))
-                    vol = ops.corr81(first, warped, LRELU)
-                    tensorFeat = torch.cat([vol, first, flow, up], 1)
-                for name in ("One", "Two", "Thr", "Fou", "Fiv"):
-                    # dense connection: new features are prepended (PWCNet.py:209-213), the concat is fused
-                    # on the input side of the next conv; materialise once per stage for the growing stack
-                    tensorFeat = torch.cat([_run(getattr(self, "module" + name), tensorFeat), tensorFeat], 1)
-                return {"tensorFlow": _run(self.moduleSix, tensorFeat), "tensorFeat": tensorFeat}
+                    into(own, own + 81, lambda o: ops.corr81(first, warped, LRELU, out=o))
+                    buf[:, own + 81:own + 81 + C].copy_(first)
+                off = own
+                for name, cout in (("One", 128), ("Two", 128), ("Thr", 96), ("Fou", 64), ("Fiv", 32)):
+                    getattr(self, "module" + name)[0](buf[:, off:], act=LRELU, out=buf[:, off - cout:off])
+                    off -= cout
+                return {"tensorFlow": _run(self.moduleSix, buf), "tensorFeat": buf}
 
         class Refiner(nn.Module):
             def __init__(self):
@@ -117,17 +134,26 @@ class PWCNet(nn.Module):
         w, h = tensorFirst.size(3), tensorFirst.size(2)
         pw = int(math.floor(math.ceil(w / 64.0) * 64.0))
         ph = int(math.floor(math.ceil(h / 64.0) * 64.0))
-        a = ops.resize_bilinear(tensorFirst, (ph, pw), False)
-        b = ops.resize_bilinear(tensorSecond, (ph, pw), False)
+        # both frames in one batch: the feature pyramid runs once over 2B images (half the launches; the coarse levels are launch-bound)
+        n = tensorFirst.shape[0]
+        ab = torch.empty(2 * n, tensorFirst.shape[1], ph, pw, dtype=torch.float32, device=tensorFirst.device)
+        ops.resize_bilinear(tensorFirst, (ph, pw), False, out=ab[:n])
+        ops.resize_bilinear(tensorSecond, (ph, pw), False, out=ab[n:])
         h, w = h // 4, w // 4
-        flow = ops.resize_bilinear(self.forward_pre(a, b), (h, w), False)
+        flow = ops.resize_bilinear(self._forward_pre_stacked(ab), (h, w), False)
         flow = flow * 20.0                                   # 20.0 * interpolate(...), PWCNet.py:291-293
         flow[:, 0] *= float(w) / float(pw)
         flow[:, 1] *= float(h) / float(ph)
         return flow
 
     def forward_pre(self, tensorFirst, tensorSecond):
-        f1, f2 = self.moduleExtractor(tensorFirst), self.moduleExtractor(tensorSecond)
+        return self._forward_pre_stacked(torch.cat([tensorFirst, tensorSecond], 0))
+
+    def _forward_pre_stacked(self, both):
+        """both [2B,3,H,W] = the first frames followed by the second frames (PWCNet.py:303-322 runs the extractor twice)"""
+        n = both.shape[0] // 2
+        pyr = self.moduleExtractor(both)
+        f1, f2 = [t[:n] for t in pyr], [t[n:] for t in pyr]
         est = self.moduleSix(f1[-1], f2[-1], None)
         for i, name in zip((-2, -3, -4, -5), ("Fiv", "Fou", "Thr", "Two")):
             est = getattr(self, "module" + name)(f1[i], f2[i], est)

@@ -117,32 +117,35 @@ __global__ __launch_bounds__(256) void raft_lookup_kernel(LookupArgs a) {
     }
 }
 
-static int motif_raft_corr_lookup_pyramid_big(const float* fmap1, const float* const* fmap2, const int* H2, const int* W2, int levels, const float* coords,
-                                              float* out, int B, int H1, int W1, int C, int r, int out_C, float div, void* stream);
 extern "C" int motif_raft_corr_lookup_pyramid(const float* fmap1, const float* const* fmap2, const int* H2, const int* W2, int levels,
                                               const float* coords, float* out, int B, int H1, int W1, int C, int r,
                                               int out_C, float div, const int32_t* index1_host, const int32_t* index2_host, void* stream) {
     if (!fmap1 || !fmap2 || !coords || !out || !H2 || !W2 || B < 1 || levels < 1 || levels > 4) return MOTIF_EINVAL;
     if (r != 3 || (C & 3)) return MOTIF_ELIMIT;
-    if ((index1_host || index2_host) && B > 16) return MOTIF_ELIMIT;
-    LookupArgs a;
-    for (int i = 0; i < 16; ++i) {
-        a.idx1[i] = (index1_host && i < B) ? index1_host[i] : i;
-        a.idx2[i] = (index2_host && i < B) ? index2_host[i] : i;
-        if (a.idx1[i] < 0 || a.idx2[i] < 0) return MOTIF_EINVAL;
+    // the kernel's batch index maps hold 16 pairs: larger batches go in slices (pair b of a slice = pair b0 + b of the call; the map
+    // entries are absolute indices into the feature stacks)
+    for (int b0 = 0; b0 < B; b0 += 16) {
+        const int nb = B - b0 < 16 ? B - b0 : 16;
+        LookupArgs a;
+        for (int i = 0; i < 16; ++i) {
+            const int bi = b0 + (i < nb ? i : 0);
+            a.idx1[i] = index1_host ? index1_host[bi] : bi;
+            a.idx2[i] = index2_host ? index2_host[bi] : bi;
+            if (a.idx1[i] < 0 || a.idx2[i] < 0) return MOTIF_EINVAL;
+        }
+        a.fmap1 = fmap1; a.coords = coords + (long)b0 * 2 * H1 * W1; a.out = out + (long)b0 * out_C * H1 * W1;
+        a.H1 = H1; a.W1 = W1; a.C = C; a.out_C = out_C; a.div = div;
+        for (int i = 0; i < 4; ++i) {
+            const int j = i < levels ? i : 0;
+            if (!fmap2[j]) return MOTIF_EINVAL;
+            a.fmap2[i] = fmap2[j]; a.H2[i] = H2[j]; a.W2[i] = W2[j];
+            a.coord_scale[i] = 1.0f / (float)(1 << j);              // coords / 2**i (corr.py:81)
+            a.ch_off[i] = j * (2 * r + 1) * (2 * r + 1);
+        }
+        dim3 grid(cdiv((long)H1 * W1, 64), nb, levels);
+        raft_lookup_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+        MOTIF_LAUNCH_CHECK();
     }
-    if (B > 16) return motif_raft_corr_lookup_pyramid_big(fmap1, fmap2, H2, W2, levels, coords, out, B, H1, W1, C, r, out_C, div, stream);
-    a.fmap1 = fmap1; a.coords = coords; a.out = out; a.H1 = H1; a.W1 = W1; a.C = C; a.out_C = out_C; a.div = div;
-    for (int i = 0; i < 4; ++i) {
-        const int j = i < levels ? i : 0;
-        if (!fmap2[j]) return MOTIF_EINVAL;
-        a.fmap2[i] = fmap2[j]; a.H2[i] = H2[j]; a.W2[i] = W2[j];
-        a.coord_scale[i] = 1.0f / (float)(1 << j);              // coords / 2**i (corr.py:81)
-        a.ch_off[i] = j * (2 * r + 1) * (2 * r + 1);
-    }
-    dim3 grid(cdiv((long)H1 * W1, 64), B, levels);
-    raft_lookup_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
-    MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }
 
@@ -320,19 +323,3 @@ extern "C" int motif_corr81_fwd(const float* first, const float* second, float* 
     return MOTIF_OK;
 }
 
-// batches beyond the kernel's 16-entry index maps (identity maps only): slices of 16
-extern "C" int motif_raft_corr_lookup_pyramid(const float* fmap1, const float* const* fmap2, const int* H2, const int* W2, int levels,
-                                              const float* coords, float* out, int B, int H1, int W1, int C, int r,
-                                              int out_C, float div, const int32_t* index1_host, const int32_t* index2_host, void* stream);
-static int motif_raft_corr_lookup_pyramid_big(const float* fmap1, const float* const* fmap2, const int* H2, const int* W2, int levels, const float* coords,
-                                              float* out, int B, int H1, int W1, int C, int r, int out_C, float div, void* stream) {
-    for (int b0 = 0; b0 < B; b0 += 16) {
-        const int nb = B - b0 < 16 ? B - b0 : 16;
-        const float* f2[4];
-        for (int i = 0; i < levels; ++i) f2[i] = fmap2[i] + (long)b0 * H2[i] * W2[i] * C;
-        const int rc = motif_raft_corr_lookup_pyramid(fmap1 + (long)b0 * H1 * W1 * C, f2, H2, W2, levels, coords + (long)b0 * 2 * H1 * W1,
-                                                      out + (long)b0 * out_C * H1 * W1, nb, H1, W1, C, r, out_C, div, nullptr, nullptr, stream);
-        if (rc != MOTIF_OK) return rc;
-    }
-    return MOTIF_OK;
-}

@@ -92,9 +92,11 @@ class VideoSRBaseModel(BaseModel):
         # the reference's way and its chunks are concatenated
         in_place = getattr(self.netG, "supports_frames_out", False) and getattr(self.netG, "band", None) is None
         whole = torch.empty(len(times), B, 3, HH, WW, dtype=torch.float32, device=var_L.device) if in_place else None
+        # a clip's timestamps stacked ONCE ([B,T]); the generator takes column slices instead of stacking every chunk again
+        tall = torch.stack(list(times), 1).squeeze(-1).to(var_L.device).float().reshape(B, -1) if in_place else None
         outs = []
         for l in range(0, len(times), step):
-            kw = dict(frames_out=whole[l:l + step]) if in_place else {}
+            kw = dict(frames_out=whole[l:l + step], times_tensor=tall[:, l:l + step]) if in_place else {}
             tmp, flow, flow_GT = self.netG(var_L, getattr(self, "real_H", None) if l == 0 else None, times[l:l + step], self.scale,
                                            use_GT=False, iter=4, **kw)
             outs.append(tmp)

@@ -97,7 +97,7 @@ class RAFT(nn.Module):
         xbuf = torch.empty(b, 146, h8, w8, dtype=torch.float32, device=image1.device)
         xbuf[:, :64].copy_(cnet[:, self.hidden_dim:])
         coords0 = coords_grid(b, h8, w8, image1.device)
-        coords1 = coords0.clone()
+        coords1 = coords0                                # never written in place: every update below makes a new tensor
         if flow_init is not None:
             coords1 = coords1 + flow_init
         ub = self.update_block

@@ -175,8 +175,7 @@ class DeformableConvLSTM(nn.Module):
 
     def forward(self, x):                          # x [B,T,C,H,W] -> list of T tensors [B,C,H,W]
         b, t, c, hh, ww = x.shape
-        h = torch.zeros(b, c, hh, ww, dtype=torch.float32, device=x.device)
-        cs = torch.zeros_like(h)
+        h, cs = torch.zeros(2, b, c, hh, ww, dtype=torch.float32, device=x.device)      # one fill for both initial states
         outs = []
         for i in range(t):
             xi = x[:, i]
@@ -626,15 +625,21 @@ class LunaTokis(nn.Module):
 
     # ----------------------------------------------------------------------------- forward
     def forward(self, x, input_target_frames, target_t, scale=None, rank=0, train_idx=0, use_GT=True, iter=12, flows=None,
-                stages=None, frames_out=None):
+                stages=None, frames_out=None, times_tensor=None):
         """frames_out (MI355X addition, optional): a contiguous [N,B,3,HH,WW] tensor the frames are rendered into -- the shell passes
-        slices of its whole-clip buffer instead of concatenating the <=3-timestamp chunks (VideoSR_base_model.py:189-193)."""
+        slices of its whole-clip buffer instead of concatenating the <=3-timestamp chunks (VideoSR_base_model.py:189-193).
+        times_tensor (optional): `target_t` already stacked to a float [B,N] device tensor (the shell stacks a clip's timestamps once)."""
         if self.training or use_GT:
             raise NotImplementedError("this is the inference path (VideoSR_base_model.py:189: use_GT=False, eval mode)")
         ops.require_device(x, "LunaTokis runs on the MI355X HIP kernels only; move inputs to 'cuda'")
         x = x.float()
         B, _, _, H, W = x.shape
-        target_t = torch.stack(list(target_t), 1).squeeze(-1).to(x.device).float().reshape(B, -1)
+        if times_tensor is not None:
+            if tuple(times_tensor.shape) != (B, len(target_t)):
+                raise ValueError("times_tensor must be [B, len(target_t)]")
+            target_t = times_tensor
+        else:
+            target_t = torch.stack(list(target_t), 1).squeeze(-1).to(x.device).float().reshape(B, -1)
         N = target_t.shape[1]
         if isinstance(scale, list):
             HH, WW = int(scale[0][0]), int(scale[1][0])

@@ -741,11 +741,14 @@ def raft_corr_lookup_pyramid(fmap1_nhwc, fmap2_levels, coords, out, div, r=3, in
     return out
 
 
-def corr81(first, second, act=ACT_NONE):
+def corr81(first, second, act=ACT_NONE, out=None):
     lib = _lib.load()
     first, second = _c(first), _c(second)
     b, c, h, w = first.shape
-    out = torch.empty(b, 81, h, w, dtype=torch.float32, device=first.device)
+    if out is None:
+        out = torch.empty(b, 81, h, w, dtype=torch.float32, device=first.device)
+    elif tuple(out.shape) != (b, 81, h, w) or not out.is_contiguous():
+        raise RuntimeError("corr81: `out` must be a contiguous [%d,81,%d,%d] tensor" % (b, h, w))
     check(lib.motif_corr81_fwd(_p(first), _p(second), _p(out), b, c, h, w, act, _stream()), "motif_corr81_fwd")
     return out
 
@@ -797,12 +800,15 @@ def flow_roundtrip(pred, a, b):
     return out
 
 
-def deconv4x4s2(x, weight, bias):
+def deconv4x4s2(x, weight, bias, out=None):
     lib = _lib.load()
     x = _c(x)
     n, ci, h, w = x.shape
     co = weight.shape[1]
-    out = torch.empty(n, co, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(n, co, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (n, co, 2 * h, 2 * w) or not out.is_contiguous():
+        raise RuntimeError("deconv4x4s2: `out` must be a contiguous [%d,%d,%d,%d] tensor" % (n, co, 2 * h, 2 * w))
     check(lib.motif_deconv4x4s2(_p(x), _p(_c(weight.detach())), _p(bias.detach()) if bias is not None else None, _p(out),
                                 n, ci, co, h, w, _stream()), "motif_deconv4x4s2")
     return out
