@@ -178,8 +178,10 @@ typedef struct MotifConvDesc {
     int mma;                  /* arithmetic of the contraction: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32);
                                  6 = fp32-equivalent on the bf16 matrix cores (3-way bf16 split, 6 products, fp32
                                  accumulate); 3 = 2-way split, 3 products (16-bit mantissa); 1 = plain bf16.
-                                 Non-zero values apply to 3x3/stride-1 layers with > 32 couts and >= 16 input
-                                 channels per group, every other layer runs mode 0.  The packed weight format
+                                 Non-zero values apply to 3x3/stride-1 layers with >= 16 input channels per group and
+                                 > 32 couts per group (or 17 .. 32 couts when the group has >= 128 input channels: half of
+                                 a workgroup's matrix work is then spent on zero weights, still well ahead of mode 0 on
+                                 such long reductions); every other layer runs mode 0.  The packed weight format
                                  depends on it: pack and forward must be given the same value.  With mode 6 the blob of
                                  such a layer holds two fragment blocks, direct and Winograd F(2,3)-along-the-rows
                                  (U = G g, formed in fp64 and split from there); which kernel runs is decided per launch

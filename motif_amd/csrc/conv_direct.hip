@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * NS) void conv_direct_deep_kernel(ConvArgs a) {
     for (int o = 0; o < NCO; ++o) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto plane_of = [&](int c) { return c < a.C0 ? in0n + (long)c * HW : in1n + (long)(c - a.C0) * HW; };
     auto wrow_of = [&](int c) { return wp + (long)(((c >> 1) * T) * 2 + (c & 1)) * 32; };
-    constexpr int CG = K == 1 ? 8 : 2;
+    constexpr int CG = K == 1 ? 8 : (NS >= 16 ? 4 : 2);    // channels whose loads are in flight together (the 16-slice form serves small maps: latency, not registers)
     auto group = [&](int c0, auto n_tag) {
         constexpr int NG = decltype(n_tag)::value;
         if constexpr (K == 1) {
@@ -272,7 +272,9 @@ __global__ __launch_bounds__(64 * NS) void conv_direct_deep_kernel(ConvArgs a) {
 // tiny-Cout / deep-K form (flow heads): any map size that fills the chip.  ONE predicate for eligibility and launch.
 static bool direct_is_deep(const MotifConvDesc* d, int P) {
     const int Cin = d->C0 + d->C1;
-    return d->Cout <= 4 && Cin >= 32 && (long)Cin * d->Cout * d->KH * d->KW <= 16384 && (long)d->N * P * d->H * d->W >= 16384 &&
+    // small maps too when the reduction is long (PWC-Net's flow heads: 529 .. 661 -> 2 on 12x20 .. 96x160 maps took 200-250 us on the
+    // MFMA engine -- one or a few workgroups walking 5 000 K-rows for 2 of a tile's 32 couts; here 8 waves share the channels: ~10 us)
+    return d->Cout <= 4 && Cin >= 32 && (long)Cin * d->Cout * d->KH * d->KW <= 16384 && ((long)d->N * P * d->H * d->W >= 16384 || Cin >= 128) &&
            (d->C1 == 0 || (d->C0 & 1) == 0);
 }
 
@@ -300,7 +302,10 @@ int motif_conv_direct_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStre
     const long quads = (long)(d->W >> 2) * d->H;
     if (direct_is_deep(d, P)) {                          // deep form: 8 channel slices (waves) per 64 pixel quads
         dim3 grid((unsigned)((quads + 63) / 64), 1, d->N * P);
-        if (d->KH == 1) conv_direct_deep_kernel<4, 1, 8><<<grid, 512, 0, s>>>(a); else conv_direct_deep_kernel<4, 3, 8><<<grid, 512, 0, s>>>(a);
+        // few workgroups and a long reduction (PWC-Net's flow heads on the coarse levels): 16 slices, four channels' loads in flight
+        const bool tiny = d->KH == 3 && d->Cout <= 2 && (long)grid.x * grid.z < 512 && d->C0 + d->C1 >= 256;
+        if (tiny) conv_direct_deep_kernel<2, 3, 16><<<grid, 1024, 0, s>>>(a);
+        else if (d->KH == 1) conv_direct_deep_kernel<4, 1, 8><<<grid, 512, 0, s>>>(a); else conv_direct_deep_kernel<4, 3, 8><<<grid, 512, 0, s>>>(a);
         MOTIF_LAUNCH_CHECK();
         return MOTIF_OK;
     }

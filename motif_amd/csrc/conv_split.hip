@@ -228,7 +228,10 @@ bool motif_conv_split_eligible(const MotifConvDesc* d) {
     if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->dil != 1 || d->groups < 1) return false;
     const int Cin = d->C0 + d->C1;
     if (Cin % d->groups || d->Cout % d->groups) return false;
-    return Cin / d->groups >= 16 && d->Cout / d->groups > 32;
+    // > 32 couts per group fill both cout tiles of a workgroup; 17 .. 32 fill one (half the matrix work is spent on zero weights), which
+    // still beats the fp32 engine when the reduction is long (PWC-Net's 497 .. 629 -> 32 layers: 190-240 us there)
+    const int Cin_g = Cin / d->groups, Cout_g = d->Cout / d->groups;
+    return Cin_g >= 16 && (Cout_g > 32 || (Cout_g >= 17 && Cin_g >= 128));
 }
 
 long motif_conv_split_packed_floats_direct(const MotifConvDesc* d) {

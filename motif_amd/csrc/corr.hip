@@ -190,10 +190,12 @@ extern "C" int motif_raft_corr_lookup(const float* fmap1, const float* fmap2, co
 #define C81_WS (C81_TW + 8)
 #define C81_WH (C81_TH + 8)
 #define C81_CK 8
-#define C81_NT 192
-
-__global__ __launch_bounds__(C81_NT) void corr81_tiled_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
-                                                              float* __restrict__ out, int C, int H, int W, int act) {
+// DYW = vertical displacements per wave: 3 (three waves per block: the large maps, whose tiles fill the chip) or 1 (nine waves per block:
+// the middle pyramid levels, 60-240 tiles -- three times the waves for the same window, a third of the FMA chain per wave).
+template <int DYW>
+__global__ __launch_bounds__(64 * (9 / DYW)) void corr81_tiled_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                                       float* __restrict__ out, int C, int H, int W, int act) {
+    constexpr int C81_NT = 64 * (9 / DYW);
     __shared__ __attribute__((aligned(16))) float win[C81_CK][C81_WH * C81_WS];
     const int tid = threadIdx.x, g = tid >> 6, q = tid & 63, qy = q >> 3, qx = q & 7;
     const int x0 = blockIdx.x * C81_TW, y0 = blockIdx.y * C81_TH, b = blockIdx.z;
@@ -203,9 +205,9 @@ __global__ __launch_bounds__(C81_NT) void corr81_tiled_kernel(const float* __res
     const bool vec = (W & 3) == 0;                                             // block-uniform: float4 global access
     const float* f1b = f1 + (long)b * C * HW;
     const float* f2b = f2 + (long)b * C * HW;
-    float acc[3][9][4];
+    float acc[DYW][9][4];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < DYW; ++i)
 #pragma unroll
         for (int d = 0; d < 9; ++d)
 #pragma unroll
@@ -252,11 +254,11 @@ __global__ __launch_bounds__(C81_NT) void corr81_tiled_kernel(const float* __res
             for (int j = 0; j < 4; ++j) a[c][j] = an[c][j];
         __syncthreads();
         if (c0 + C81_CK < C) request(c0 + C81_CK);
-        const float* wp = &win[0][(qy + 3 * g) * C81_WS + 4 * qx];
+        const float* wp = &win[0][(qy + DYW * g) * C81_WS + 4 * qx];
 #pragma unroll
         for (int c = 0; c < C81_CK; ++c)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < DYW; ++i) {
                 float w[12];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -273,10 +275,10 @@ __global__ __launch_bounds__(C81_NT) void corr81_tiled_kernel(const float* __res
     const float inv = (float)C;
     float* ob = out + (long)b * 81 * HW + (long)y * W + x;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < DYW; ++i)
 #pragma unroll
         for (int d = 0; d < 9; ++d) {
-            float* op = ob + (long)((3 * g + i) * 9 + d) * HW;
+            float* op = ob + (long)((DYW * g + i) * 9 + d) * HW;
             if (vec && x + 3 < W) {
                 f32x4 v;
 #pragma unroll
@@ -302,7 +304,17 @@ __global__ void corr81_small_kernel(const float* __restrict__ f1, const float* _
     if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) {
         const float* a = f1 + (long)b * C * HW + (long)y * W + x;
         const float* v = f2 + (long)b * C * HW + (long)y2 * W + x2;
-        for (int c = 0; c < C; ++c) s = fmaf(a[(long)c * HW], v[(long)c * HW], s);
+        // eight channels' loads in flight, then the same ascending-order FMA chain (one load pair per FMA was 57 us of pure latency for
+        // the 196 channels of the coarsest level)
+        int c = 0;
+        for (; c + 8 <= C; c += 8) {
+            float av[8], vv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { av[e] = a[(long)(c + e) * HW]; vv[e] = v[(long)(c + e) * HW]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(av[e], vv[e], s);
+        }
+        for (; c < C; ++c) s = fmaf(a[(long)c * HW], v[(long)c * HW], s);
     }
     out[((long)b * 81 + d) * HW + (long)y * W + x] = act_apply(s / (float)C, act);
 }
@@ -314,7 +326,8 @@ extern "C" int motif_corr81_fwd(const float* first, const float* second, float* 
     const bool tiled = force ? force == 1 : (long)H * W >= 64L * 96;
     if (tiled) {
         dim3 grid(cdiv(W, C81_TW), cdiv(H, C81_TH), B);
-        corr81_tiled_kernel<<<grid, C81_NT, 0, (hipStream_t)stream>>>(first, second, out, C, H, W, act);
+        if ((long)grid.x * grid.y * grid.z >= 512) corr81_tiled_kernel<3><<<grid, 192, 0, (hipStream_t)stream>>>(first, second, out, C, H, W, act);
+        else corr81_tiled_kernel<1><<<grid, 576, 0, (hipStream_t)stream>>>(first, second, out, C, H, W, act);
     } else {
         dim3 grid(cdiv(W, 64), H, B * 81);
         corr81_small_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(first, second, out, C, H, W, act);

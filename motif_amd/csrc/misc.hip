@@ -731,10 +731,65 @@ __global__ void deconv4x4s2_kernel(const float* __restrict__ in, const float* __
     out[((long)(n * Cout + co) * Ho + oy) * Wo + ox] = acc;
 }
 
+// Long reductions (PWC-Net's moduleUpfeat: 529 .. 661 channels -> 2): the channels are cut into NS slices, one per 128-thread row of the
+// workgroup; the NS partial sums meet in LDS and slice 0 adds them in slice order (fixed order: deterministic).  One thread per output
+// pixel walking 600 channels alone was pure load latency (110-177 us per call for a few megabytes).
+template <int NS>
+__global__ __launch_bounds__(128 * NS) void deconv4x4s2_sliced_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                     float* __restrict__ out, int Cin, int Cout, int H, int W) {
+    __shared__ float red[NS][128];
+    const int lx = threadIdx.x & 127, slice = threadIdx.x >> 7;
+    const int ox = blockIdx.x * 128 + lx, oy = blockIdx.y;
+    const int n = blockIdx.z / Cout, co = blockIdx.z % Cout;
+    const int Ho = 2 * H, Wo = 2 * W;
+    const bool live = ox < Wo;
+    const long HW = (long)H * W;
+    long ioff[4], woff[4];
+    float on[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ky = ((oy + 1) & 1) + 2 * (t >> 1), kx = ((ox + 1) & 1) + 2 * (t & 1);
+        const int iy = (oy + 1 - ky) / 2, ix = (ox + 1 - kx) / 2;
+        const bool ok = live && iy >= 0 && iy < H && ix >= 0 && ix < W && (oy + 1 - ky) >= 0 && (ox + 1 - kx) >= 0;
+        ioff[t] = ok ? (long)iy * W + ix : 0;
+        woff[t] = (long)co * 16 + ky * 4 + kx;
+        on[t] = ok ? 1.f : 0.f;
+    }
+    const float* ip = in + (long)n * Cin * HW;
+    const long wstep = (long)Cout * 16;
+    const int per = (Cin + NS - 1) / NS, cbeg = slice * per, cend = cbeg + per < Cin ? cbeg + per : Cin;
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+    int ci = cbeg;
+    for (; ci + 1 < cend; ci += 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a0[t] = fmaf(ip[(long)ci * HW + ioff[t]], w[(long)ci * wstep + woff[t]] * on[t], a0[t]);
+            a1[t] = fmaf(ip[(long)(ci + 1) * HW + ioff[t]], w[(long)(ci + 1) * wstep + woff[t]] * on[t], a1[t]);
+        }
+    }
+    if (ci < cend) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a0[t] = fmaf(ip[(long)ci * HW + ioff[t]], w[(long)ci * wstep + woff[t]] * on[t], a0[t]);
+    }
+    red[slice][lx] = ((a0[0] + a1[0]) + (a0[1] + a1[1])) + ((a0[2] + a1[2]) + (a0[3] + a1[3]));
+    __syncthreads();
+    if (slice == 0 && live) {
+        float acc = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc += red[s][lx];
+        out[((long)(n * Cout + co) * Ho + oy) * Wo + ox] = acc;
+    }
+}
+
 extern "C" int motif_deconv4x4s2(const float* in, const float* weight, const float* bias, float* out,
                                  int N, int Cin, int Cout, int H, int W, void* stream) {
     if (!in || !weight || !out || N < 1 || Cin < 1 || Cout < 1) return MOTIF_EINVAL;
     dim3 grid(cdiv(2 * W, 128), 2 * H, N * Cout);
+    if (Cin >= 64) {
+        deconv4x4s2_sliced_kernel<8><<<grid, 128 * 8, 0, (hipStream_t)stream>>>(in, weight, bias, out, Cin, Cout, H, W);
+        MOTIF_LAUNCH_CHECK();
+        return MOTIF_OK;
+    }
     deconv4x4s2_kernel<<<grid, 128, 0, (hipStream_t)stream>>>(in, weight, bias, out, Cin, Cout, H, W);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;

@@ -210,6 +210,9 @@ DIRECT_CASES = [  # cin, cout, k, H, W, N, two-source split, act, res_mode, act_
     (128, 2, 3, 90, 160, 2, 0, "none", 0, 0),         # RAFT flow head: deep-K form (8 channel slices per workgroup, LDS reduction)
     (200, 3, 3, 46, 76, 2, 104, "lrelu", 2, 0),       # deep form: two sources, slice ends inside a source, ragged quads, 3 couts
     (96, 4, 1, 128, 132, 1, 0, "relu", 1, 0),         # deep form, 1x1
+    (529, 2, 3, 12, 20, 1, 0, "none", 0, 0),          # PWC-Net flow head on the coarsest level: 16-slice deep form (one workgroup)
+    (597, 2, 3, 48, 80, 2, 0, "none", 0, 0),          # the same form, several workgroups, ragged channel slices
+    (300, 1, 3, 20, 24, 1, 0, "relu", 0, 0),          # one cout
 ]
 
 
@@ -864,7 +867,7 @@ def test_raft_lookup_and_raft_against_reference_corrblock_fixtures():
 
 
 @pytest.mark.parametrize("kernel", ["small", "tiled"])
-@pytest.mark.parametrize("shape", [(2, 33, 12, 20), (1, 19, 37, 70), (1, 8, 64, 96)])
+@pytest.mark.parametrize("shape", [(2, 33, 12, 20), (1, 19, 37, 70), (1, 8, 64, 96), (1, 5, 264, 520)])      # the last: > 512 tiles = the 3-wave form of the tiled kernel
 def test_corr81(kernel, shape):
     """Both cost-volume kernels (per-displacement threads for the coarse levels, LDS-tiled + register-blocked for the large
     ones) against the kernel-text restatement: ragged tiles, W % 4 != 0 (scalar edge path), C not a multiple of the chunk."""
