@@ -148,9 +148,14 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
 // by its k-loop (52 us for 0.27 GFLOP).  Here the input channels are cut into NS slices, one per wave of the workgroup: a thread owns
 // four pixels x NCO couts over its slice's channels, the NS partial sums meet in LDS and wave 0 adds them in slice order (fixed order:
 // deterministic), then bias / activation / residual / store as above.
+// 3x3 form (round 5): a slice's weights -- 9 x NCO floats per channel, 2 .. 4 of every 32-float row of the packed block -- are gathered
+// into LDS once (64 loads in flight per instruction) and read from there.  Scalar loads of them were one row = one scalar-cache miss each,
+// ~2 us of L2 latency per channel pair: every 529 .. 661 -> 2 flow head of PWC-Net took 80 us whatever the map size, RAFT's 128 -> 2 head
+// 26 us.  The workgroup's dynamic LDS is NS regions of `rs` 16-byte units: a wave's weights first, its partial sums afterwards (the
+// same wave, in program order: no barrier between the two uses).
 template <int NCO, int K, int NS>
-__global__ __launch_bounds__(64 * NS) void conv_direct_deep_kernel(ConvArgs a) {
-    __shared__ f32x4 red[NS][NCO][64];
+__global__ __launch_bounds__(64 * NS) void conv_direct_deep_kernel(ConvArgs a, int rs) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 dsm[];        // [NS][rs]
     const int pz = blockIdx.z / a.N, n = blockIdx.z - pz * a.N;
     const int W4 = a.W >> 2, nquads = W4 * a.H;
     const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -167,19 +172,41 @@ __global__ __launch_bounds__(64 * NS) void conv_direct_deep_kernel(ConvArgs a) {
     const int Cin = a.Cin_g;
     const int per = ((Cin + NS - 1) / NS + 1) & ~1;                  // channels per slice, even
     const int cbeg = slice * per, cend = min(Cin, cbeg + per);
+    float* wl = (float*)(dsm + slice * rs);                          // this wave's weights [channel][tap][cout] (K == 3)
+    if constexpr (K == 3) {
+        const int nw = (cend - cbeg) * T * NCO;
+        for (int i0 = 0; i0 < nw; i0 += 64 * 8) {          // eight gathers in flight per lane, then their LDS stores
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 64 * u + lane;
+                const int ic = i < nw ? i : 0;
+                const int cl = ic / (T * NCO), r = ic - cl * (T * NCO), tap = r / NCO, o = r - tap * NCO;
+                const int c = cbeg + cl;
+                wv[u] = wp[(long)(((c >> 1) * T) * 2 + (c & 1)) * 32 + tap * 64 + o];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 64 * u + lane;
+                if (i < nw) wl[i] = wv[u];
+            }
+        }
+    }
 
     f32x4 acc[NCO];
 #pragma unroll
     for (int o = 0; o < NCO; ++o) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto plane_of = [&](int c) { return c < a.C0 ? in0n + (long)c * HW : in1n + (long)(c - a.C0) * HW; };
     auto wrow_of = [&](int c) { return wp + (long)(((c >> 1) * T) * 2 + (c & 1)) * 32; };
-    constexpr int CG = K == 1 ? 8 : (NS >= 16 ? 4 : 2);    // channels whose loads are in flight together (the 16-slice form serves small maps: latency, not registers)
+    constexpr int CG = K == 1 ? 8 : (NS >= 16 ? 3 : 2);    // channels whose loads are in flight together (the 16-slice form serves small maps: latency; four spill at its 128-register cap)
     auto group = [&](int c0, auto n_tag) {
         constexpr int NG = decltype(n_tag)::value;
         if constexpr (K == 1) {
             f32x4 v[NG];
 #pragma unroll
             for (int i = 0; i < NG; ++i) v[i] = *(const f32x4*)(plane_of(c0 + i) + (long)y * a.W + x);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
                 cptr wrow = wrow_of(c0 + i);
@@ -200,9 +227,12 @@ __global__ __launch_bounds__(64 * NS) void conv_direct_deep_kernel(ConvArgs a) {
                     l[i][dy] = rp[x > 0 ? -1 : 0];
                     rr[i][dy] = rp[x + 4 < a.W ? 4 : 3];
                 }
+            // every load of the group is REQUESTED before the first multiply: left alone, the scheduler sinks each channel's loads next to
+            // their uses to save registers and the slice becomes one load latency per channel (72 us for 42 channels, round 5 ISA)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
-                cptr wrow = wrow_of(c0 + i);
+                const float* wrow = wl + (c0 + i - cbeg) * (T * NCO);
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     const int yy = y + dy - 1;
@@ -213,7 +243,7 @@ __global__ __launch_bounds__(64 * NS) void conv_direct_deep_kernel(ConvArgs a) {
                     for (int e = 0; e < 4; ++e) r[1 + e] = rowok ? m[i][dy][e] : 0.f;
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) {
-                        cptr wt = wrow + (dy * 3 + dx) * 64;
+                        const float* wt = wrow + (dy * 3 + dx) * NCO;
 #pragma unroll
                         for (int o = 0; o < NCO; ++o) {
                             const float w = wt[o];
@@ -229,7 +259,7 @@ __global__ __launch_bounds__(64 * NS) void conv_direct_deep_kernel(ConvArgs a) {
     for (; c + CG <= cend; c += CG) group(c, std::integral_constant<int, CG>{});
     for (; c < cend; ++c) group(c, std::integral_constant<int, 1>{});
 #pragma unroll
-    for (int o = 0; o < NCO; ++o) red[slice][o][lane] = acc[o];
+    for (int o = 0; o < NCO; ++o) dsm[slice * rs + o * 64 + lane] = acc[o];
     __syncthreads();
     if (slice != 0 || !live) return;
     const float* bias = a.bias[pz];
@@ -248,9 +278,9 @@ __global__ __launch_bounds__(64 * NS) void conv_direct_deep_kernel(ConvArgs a) {
 #pragma unroll
     for (int o = 0; o < NCO; ++o) {
         if (o >= a.Cout) break;
-        f32x4 v = red[0][o][lane];
+        f32x4 v = dsm[o * 64 + lane];
 #pragma unroll
-        for (int sidx = 1; sidx < NS; ++sidx) v += red[sidx][o][lane];
+        for (int sidx = 1; sidx < NS; ++sidx) v += dsm[sidx * rs + o * 64 + lane];
         const int ac = (a.act_split > 0 && o >= a.act_split) ? a.act2 : a.act;
         v = v + bvv[o];
         const f32x4 rv = rvv[o];
@@ -303,9 +333,25 @@ int motif_conv_direct_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStre
     if (direct_is_deep(d, P)) {                          // deep form: 8 channel slices (waves) per 64 pixel quads
         dim3 grid((unsigned)((quads + 63) / 64), 1, d->N * P);
         // few workgroups and a long reduction (PWC-Net's flow heads on the coarse levels): 16 slices, four channels' loads in flight
-        const bool tiny = d->KH == 3 && d->Cout <= 2 && (long)grid.x * grid.z < 512 && d->C0 + d->C1 >= 256;
-        if (tiny) conv_direct_deep_kernel<2, 3, 16><<<grid, 1024, 0, s>>>(a);
-        else if (d->KH == 1) conv_direct_deep_kernel<4, 1, 8><<<grid, 512, 0, s>>>(a); else conv_direct_deep_kernel<4, 3, 8><<<grid, 512, 0, s>>>(a);
+        const int Cin = d->C0 + d->C1;
+        const bool tiny = d->KH == 3 && d->Cout <= 2 && (long)grid.x * grid.z < 512 && Cin >= 256;
+        auto region = [&](int ns, int nco) {               // 16-byte units per slice: its weights (3x3) or its partial sums, whichever is larger
+            const int per = ((Cin + ns - 1) / ns + 1) & ~1;
+            const int wq = d->KH == 3 ? (per * 9 * nco + 3) / 4 : 0;
+            return wq > nco * 64 ? wq : nco * 64;
+        };
+#define MOTIF_LAUNCH_DEEP(NCOV, KV, NSV)                                                                                    \
+    do {                                                                                                                     \
+        const int rs_ = region(NSV, NCOV);                                                                                   \
+        const size_t lds_ = (size_t)NSV * rs_ * 16;                                                                          \
+        if (lds_ > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_direct_deep_kernel<NCOV, KV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+        conv_direct_deep_kernel<NCOV, KV, NSV><<<grid, 64 * NSV, lds_, s>>>(a, rs_);                                        \
+    } while (0)
+        if (tiny) MOTIF_LAUNCH_DEEP(2, 3, 16);
+        else if (d->KH == 1) MOTIF_LAUNCH_DEEP(4, 1, 8);
+        else if (d->Cout <= 2) MOTIF_LAUNCH_DEEP(2, 3, 8);
+        else MOTIF_LAUNCH_DEEP(4, 3, 8);
+#undef MOTIF_LAUNCH_DEEP
         MOTIF_LAUNCH_CHECK();
         return MOTIF_OK;
     }

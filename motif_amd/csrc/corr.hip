@@ -323,11 +323,13 @@ extern "C" int motif_corr81_fwd(const float* first, const float* second, float* 
                                 int act, void* stream) {
     if (!first || !second || !out || B < 1 || C < 1) return MOTIF_EINVAL;
     const int force = motif_opt(MOTIF_OPT_CORR81);           // 1 = tiled, 2 = small: tests and tools/pwc_bench.py
-    const bool tiled = force ? force == 1 : (long)H * W >= 64L * 96;
+    const bool tiled = force ? force != 2 : (long)H * W >= 64L * 96;
     if (tiled) {
         dim3 grid(cdiv(W, C81_TW), cdiv(H, C81_TH), B);
-        if ((long)grid.x * grid.y * grid.z >= 512) corr81_tiled_kernel<3><<<grid, 192, 0, (hipStream_t)stream>>>(first, second, out, C, H, W, act);
-        else corr81_tiled_kernel<1><<<grid, 576, 0, (hipStream_t)stream>>>(first, second, out, C, H, W, act);
+        // (DYW = 1, nine waves per block, for the 60-240-tile levels: measured SLOWER, 79 -> 102 and 52 -> 74 us -- the window staging and
+        // its two barriers per chunk do not shrink with the FMA chain; option corr81 = 3 keeps it reachable for tests)
+        if (force == 3) corr81_tiled_kernel<1><<<grid, 576, 0, (hipStream_t)stream>>>(first, second, out, C, H, W, act);
+        else corr81_tiled_kernel<3><<<grid, 192, 0, (hipStream_t)stream>>>(first, second, out, C, H, W, act);
     } else {
         dim3 grid(cdiv(W, 64), H, B * 81);
         corr81_small_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(first, second, out, C, H, W, act);

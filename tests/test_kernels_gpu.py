@@ -250,9 +250,10 @@ def test_conv_direct_narrow_layers_match_the_mfma_engine_and_torch(case):
         di = m(*args, **kw).double().cpu()
     finally:
         ops.set_option("conv_nodirect", 0)
-    assert float((mf - y).abs().max()) < 2e-6 * scale
-    assert float((di - y).abs().max()) < 2e-6 * scale
-    assert float((di - mf).abs().max()) < 2e-6 * scale
+    tol = 2e-6 * scale * max(1.0, math.sqrt(cin * k * k / 1800.0))      # fp32 accumulation: the bound grows with the square root of the reduction length
+    assert float((mf - y).abs().max()) < tol
+    assert float((di - y).abs().max()) < tol
+    assert float((di - mf).abs().max()) < tol
 
 
 def test_conv_split_multi_problem_and_views(keep_mma):
@@ -866,7 +867,7 @@ def test_raft_lookup_and_raft_against_reference_corrblock_fixtures():
     close(lr, torch.from_numpy(g["flow_lr"]), 5e-4, 1e-3, "RAFT 1/8 flow")
 
 
-@pytest.mark.parametrize("kernel", ["small", "tiled"])
+@pytest.mark.parametrize("kernel", ["small", "tiled", "tiled9"])
 @pytest.mark.parametrize("shape", [(2, 33, 12, 20), (1, 19, 37, 70), (1, 8, 64, 96), (1, 5, 264, 520)])      # the last: > 512 tiles = the 3-wave form of the tiled kernel
 def test_corr81(kernel, shape):
     """Both cost-volume kernels (per-displacement threads for the coarse levels, LDS-tiled + register-blocked for the large
@@ -875,7 +876,7 @@ def test_corr81(kernel, shape):
     from motif_amd import ops
     n, c, h, w = shape
     a, b = rnd(n, c, h, w, seed=1), rnd(n, c, h, w, seed=2)
-    ops.set_option("corr81", {"tiled": 1, "small": 2}[kernel])     # the library reads no environment per launch
+    ops.set_option("corr81", {"tiled": 1, "small": 2, "tiled9": 3}[kernel])     # the library reads no environment per launch
     try:
         close(ops.corr81(a.to(dev()), b.to(dev())), native.corr81(a, b), 2e-6, 1e-5, "corr81")
         close(ops.corr81(a.to(dev()), b.to(dev()), ops.ACT_LRELU), F.leaky_relu(native.corr81(a, b), 0.1), 2e-6, 1e-5)
