@@ -467,9 +467,11 @@ class LunaTokis(nn.Module):
         wh, bh = self.imnet.net[3].weight, self.imnet.net[3].bias
         key = (self._weights_epoch, ops.get_siren_mma()) + tuple((t.data_ptr(), t._version) for t in [w0, wh, bh] + [t for wb in self.imnet.linears() + self.synth_net.linears() for t in wb])
         if getattr(self, "_pre_key", None) != key:
-            W0 = w0.detach().double()
-            whc = (W0[:, :64] @ wh.detach().double()).float().contiguous()
-            bhc = (W0[:, :64] @ bh.detach().double()).float().contiguous()
+            # composed in fp64 ON THE HOST (a 64x64 product once per weight version): a device matmul here would be the one place
+            # where the path reaches a vendor BLAS (rocBLAS / Tensile through torch.matmul)
+            W0 = w0.detach().double().cpu()
+            whc = (W0[:, :64] @ wh.detach().double().cpu()).float().contiguous().to(w0.device)
+            bhc = (W0[:, :64] @ bh.detach().double().cpu()).float().contiguous().to(w0.device)
             self._pre = dict(
                 imnet_blob=ops.siren_pack_split(ops.SIREN_IMNET, self.imnet.linears()[:-1] + [(whc, bhc)]),
                 g_plan=ops.ConvPlan(w0.detach()[:, 66:130].contiguous().view(64, 64, 1, 1), None),
