@@ -571,7 +571,8 @@ def main():
         "config": {"arithmetic": ("fp32-equivalent on the bf16 matrix cores: every fp32 operand = 3 exact bf16 parts, 6 products, fp32 "
                                   "accumulate (3x3 convolutions, fused DCN and the three MLPs); everything else fp32" if a.mma == "bf16x3"
                                   else "fp32-equivalent on the 16-bit matrix cores: 3x3 stride-1 convolutions (conv_wino.hip) and the three MLPs with every "
-                                  "fp32 operand = 2 fp16 parts (22+ bits), 3 products, fp32 accumulate, as do the fused DCN's GEMM and the 1x1 layers (conv_pw.hip); "
+                                  "fp32 operand = 2 fp16 parts (22 bits; the low activation part stored x 2^11, so fp32-equivalent for tensor magnitudes 3e-5 .. 3e4: tests sweep 1 .. 1e-4; "
+                                  "beyond fp16's range the overflowing kernel sets a status word and the shell re-renders with bf16x3), 3 products, fp32 accumulate, as do the fused DCN's GEMM and the 1x1 layers (conv_pw.hip); "
                                   "the few remaining split convolutions with 3 exact bf16 parts, 6 products; everything else fp32" if a.mma == "f16x2"
                                   else "fp32 MFMA (v_mfma_f32_32x32x2_f32) and fp32 VALU"),
                    "workload": ("c2" if world == 1 else "c4 (independent c2 clips sharded over %d GPUs as the reference's DistIterSampler strides them: "
@@ -582,6 +583,9 @@ def main():
                    "clips_in_flight_per_gpu": a.streams,
                    "launch": "one HIP graph per clip (recorded from the second clip on, inputs copied in, replayed)" if a.graph else "host launches"},
     }
+    # the range status words of the timed clips (include/motif_hip.h): 0 = no kernel of the two-part fp16 arithmetic met an operand beyond
+    # fp16's range, i.e. the timed numbers are those of the default arithmetic with no bf16x3 re-render pending
+    line["range_status"] = [int(m.range_status()) for m in models]
     if world > 1:
         try:
             ver = ".".join(str(v) for v in torch.cuda.nccl.version())
