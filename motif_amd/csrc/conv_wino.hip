@@ -193,9 +193,16 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 }  // namespace
 
+// TR (round 5): the two MFMA operands are SWAPPED (activations as A, weights as B -- both operands have the same per-lane structure, a lane
+// = one row / column index and 8 consecutive k, so the staging and the weight fragments are untouched) and the accumulators come out
+// TRANSPOSED: lane = cout, registers = pixels, four consecutive registers = four consecutive pixels of a row.  A lane then holds 16-byte
+// pieces of NCHW rows, and the epilogue stores them straight from registers: no transposition through LDS (16 ds_write + 4 ds_read_b128 per
+// pass and their round trip), the bias is one value per lane, the residual is loaded in the same pieces.  ~400 instead of ~750 instructions
+// in the exposed epilogue of every tile.  Per-cout activation switches (act_split: the DCNs' offset | sigmoid(mask) layers) would diverge
+// across lanes there: those launches keep the row-major form.  RESULT: bit-identical, and no faster (see motif_conv_wino_launch): opt-in.
 // MULTI: more than one problem in the launch (the per-problem argument selects are ~100 scalar instructions per tile: a lone wave
 // hides none of them).
-template <int NP, bool MULTI>
+template <int NP, bool MULTI, bool TR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino_kernel(ConvArgs a, int ntiles, int tiles_y) {
     using WS = WSched<NP>;
     using WO = WOrder<NP>;
@@ -315,7 +322,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wb, wvoff, (ks * NP + p) * (2 * 64 * 16), 0));
     };
     auto bias_of = [&](const TileP& t) __attribute__((always_inline)) {
-        return (t.bp && lane < 32 && ct * 32 + lane < t.clg) ? gload(t.bp + ct * 32 + lane) : 0.f;
+        if constexpr (TR) return (t.bp && ct * 32 + l31 < t.clg) ? gload(t.bp + ct * 32 + l31) : 0.f;      // lane = cout in both half-waves
+        else return (t.bp && lane < 32 && ct * 32 + lane < t.clg) ? gload(t.bp + ct * 32 + lane) : 0.f;
     };
     // the accumulators of the two-part form carry 2^8 x the sums (exact).  Scaled where the value is STORED for init_acc, not where it is
     // requested: arithmetic on it at the request would wait for every vector-memory request in flight (vmcnt is one in-order queue)
@@ -497,7 +505,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
             if constexpr (!(WINO_ABL & 1024) && (!(WINO_ABL & 512) || (k & 1)))
             {
-                if constexpr (NP == 2) acc[tl][pos] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, WO::w[k] == 2 ? ws[pi] : wf[ss % WB][pi][WO::w[k] & 1]),
+                if constexpr (NP == 2 && TR) acc[tl][pos] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bfr[WO::x[k]][j]),
+                                                                                                  __builtin_bit_cast(f16x8, WO::w[k] == 2 ? ws[pi] : wf[ss % WB][pi][WO::w[k] & 1]), acc[tl][pos], 0, 0, 0);
+                else if constexpr (NP == 2) acc[tl][pos] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, WO::w[k] == 2 ? ws[pi] : wf[ss % WB][pi][WO::w[k] & 1]),
                                                                                             __builtin_bit_cast(f16x8, bfr[WO::x[k]][j]), acc[tl][pos], 0, 0, 0);
                 else acc[tl][pos] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ss % WB][pi][WO::w[k]]),
                                                                             __builtin_bit_cast(bf16x8, bfr[WO::x[k]][j]), acc[tl][pos], 0, 0, 0);
@@ -529,13 +539,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // out(2T) = M0 + M1 + M2, out(2T+1) = M1 - M2 - M3) -- the zeros written by SIX matrix instructions with zero operands and C = 0
     // instead of 96 v_accvgpr_write (one issue slot each, beside the epilogue's vector work), the bias by 32 moves instead of 64
     // additions in the epilogue.  The wave's bias lies in LDS (bias_w, written by its lanes 0..31 just before: same wave, in order).
+    float bias_lane = 0.f;                               // TR: this lane's (cout's) bias of the tile about to start, already scaled
     auto init_acc = [&]() __attribute__((always_inline)) {
         f32x16 bvec;
+        if constexpr (TR) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b4 = *(const f32x4*)(bias_w + 8 * q + 4 * half);
+            for (int r = 0; r < 16; ++r) bvec[r] = bias_lane;
+        } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) bvec[4 * q + u] = b4[u];
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *(const f32x4*)(bias_w + 8 * q + 4 * half);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bvec[4 * q + u] = b4[u];
+            }
         }
         // zq: a register quad of zeros written once at kernel start (opaque to the compiler: it cannot re-materialise it right in front
         // of an instruction whose operand hazards it does not know); s_nop: wait states of a just-written operand, whatever wrote it
@@ -566,6 +582,97 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned long long obp = (unsigned long long)(t.ob + (long)(ct * 32) * (long)HWo);            // uniform: the stores take it in SGPRs
         const float* rb = t.rb ? t.rb + (long)(ct * 32) * (long)HWo : nullptr;
         const int rm = a.res_mode;
+        if constexpr (TR) {
+            // Transposed accumulators: lane = cout l5 of this wave's cout tile (both half-waves), register r = pixel (r & 3) + 8 (r >> 2) + 4 hf of
+            // the 32-pixel row: registers 4q .. 4q+3 are the four consecutive pixels 8q + 4hf .. + 3, i.e. ONE 16-byte piece of an NCHW row.
+            // Per lane 2 row pairs x 2 rows x 4 pieces = 16 pieces: residual pieces requested first, inverse transform / scale / residual /
+            // activation in registers, 16-byte stores as inline assembly (see the row-major form below for the wait-count reasons).
+            int lane_t = lane;                           // opaque copy: keeps the per-lane geometry inside the tile loop
+            asm volatile("" : "+v"(lane_t));
+            const int hf_t = lane_t >> 5, co = lane_t & 31;
+            const bool cok = co < cl;
+            const int oyb = ty * TH + 4 * tp, oxb = tx * 32 + 4 * hf_t;
+            const unsigned lbase = (unsigned)co * HWo + (unsigned)(oyb * a.Wo + oxb);
+            const bool fullt = cl >= 32 && oyb + 4 <= a.Ho && tx * 32 + 32 <= a.Wo;                 // uniform: every lane stores every piece
+            auto okp = [&](int row, int q) __attribute__((always_inline)) { return cok && oyb + row < a.Ho && oxb + 8 * q < a.Wo; };      // Wo % 4 == 0: a piece is inside or outside as a whole
+            auto offp = [&](int row, int q) __attribute__((always_inline)) { return lbase + (unsigned)(row * a.Wo + 8 * q); };
+            f32x4 rv[4][4];
+            if (rm) {
+#pragma unroll
+                for (int row = 0; row < 4; ++row)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        // branch-free on purpose (bitwise |): with the short-circuit form hipcc 7.2 dropped the per-lane select of the FIRST piece
+                        // on the not-full path (an empty exec region in the ISA: every lane read element 0 there)
+                        const bool okl = (bool)((int)fullt | (int)okp(row, q));
+                        rv[row][q] = gload((const f32x4*)(rb + (okl ? offp(row, q) : 0u)));       // masked pieces read element 0
+                    }
+            }
+            const int act = a.act;
+            // the scalar operands of the inline-assembly stores, pinned to scalar registers (the compiler is free to keep a uniform 64-bit
+            // value in vector registers, which the `s` constraint then receives as they are)
+            auto sgpr64 = [](unsigned long long v) __attribute__((always_inline)) {
+                return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+            };
+            const unsigned long long obq = sgpr64(obp), stp = sgpr64((unsigned long long)a.status);
+            float chk = 0.f;                             // range status: 0 * value accumulates NaN for any non-finite output of this lane
+            // AC / RM >= 0: activation / residual mode known at compile time (the common layers: one straight-line body -- 16 pieces x a chain of
+            // wave-uniform tests is what a lone wave cannot hide); -1: run-time switches
+            auto pieces = [&](auto ac_tag, auto rm_tag) __attribute__((always_inline)) {
+            constexpr int AC = decltype(ac_tag)::value, RM = decltype(rm_tag)::value;
+            const int rmv = RM >= 0 ? RM : rm, acv = AC >= 0 ? AC : act;
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row = 2 * tl + j;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int r = 4 * q + u;
+                            v[u] = j == 0 ? (acc[tl][0][r] + acc[tl][1][r]) + acc[tl][2][r]         // the bias is inside M1 (init_acc)
+                                          : (acc[tl][1][r] - acc[tl][2][r]) - acc[tl][3][r];
+                        }
+                        if constexpr (NP == 2) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) chk = __builtin_fmaf(v[u], 0.f, chk);
+                            v *= 1.f / kWinoF16Scale;
+                        }
+                        if (rmv == 1) v += rv[row][q];
+                        if (acv == MOTIF_ACT_RELU) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] = v[u] > 0.f ? v[u] : 0.f;
+                        } else if (acv == MOTIF_ACT_LRELU) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] = v[u] > 0.f ? v[u] : 0.1f * v[u];
+                        } else if (acv != MOTIF_ACT_NONE) v = act_uniform(v, acv);
+                        if (rmv == 2) v += rv[row][q];
+                        else if (rmv == 3) {
+                            v += rv[row][q];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] = v[u] > 0.f ? v[u] : 0.f;
+                        } else if (rmv == 4) v *= rv[row][q];
+                        const unsigned bo = offp(row, q) * 4u;
+                        if (fullt) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(bo), "v"(v), "s"(obq) : "memory");
+                        else if (okp(row, q)) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(bo), "v"(v), "s"(obq) : "memory");
+                    }
+                }
+            };
+            using I0 = std::integral_constant<int, 0>;
+            if (rm == 0 && act == MOTIF_ACT_NONE) pieces(std::integral_constant<int, MOTIF_ACT_NONE>{}, I0{});
+            else if (rm == 0 && act == MOTIF_ACT_RELU) pieces(std::integral_constant<int, MOTIF_ACT_RELU>{}, I0{});
+            else if (rm == 0 && act == MOTIF_ACT_LRELU) pieces(std::integral_constant<int, MOTIF_ACT_LRELU>{}, I0{});
+            else if (rm == 1 && act == MOTIF_ACT_NONE) pieces(std::integral_constant<int, MOTIF_ACT_NONE>{}, std::integral_constant<int, 1>{});
+            else if (rm == 1 && act == MOTIF_ACT_LRELU) pieces(std::integral_constant<int, MOTIF_ACT_LRELU>{}, std::integral_constant<int, 1>{});
+            else pieces(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
+            if constexpr (NP == 2) {
+                // an operand beyond fp16's range makes every cout of its pixel non-finite: any lane's check sees it
+                if (stp && __builtin_amdgcn_class(chk, 0x207)) asm volatile("s_nop 5\n\tglobal_atomic_or %0, %1, %2" :: "v"(0u), "v"(1u), "s"(stp) : "memory");
+            }
+            return;
+        }
         int lane_e = lane;                               // opaque copy: keeps the per-lane geometry inside the tile loop
         asm volatile("" : "+v"(lane_e));
         const int hf = lane_e >> 5, l5 = lane_e & 31;
@@ -711,7 +818,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < NLD; ++i) st_load(i, 0);
     static_for<WS::S>([&](auto ic) __attribute__((always_inline)) { piece(std::integral_constant<int, kWSchedOf<NP>.ext[decltype(ic)::value]>{}, stg0); });
-    if (lane < 32) bias_w[lane] = bias_scaled(bias_v);
+    if constexpr (TR) bias_lane = bias_scaled(bias_v); else { if (lane < 32) bias_w[lane] = bias_scaled(bias_v); }
     init_acc();
 #pragma unroll
     for (int i = 0; i < NLD; ++i) st_load(i, 16);        // nch >= 2: step 1 is chunk 1 of this tile
@@ -735,9 +842,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             chunk_body(c, buf, sc, wn, lc0);
             if (slot < 29) WNTRACE(slot);                // trace: body end | epilogue end | barrier passed, for the first 9 chunks
             if (last) {
-                bias_v = (has_next && bp_next && lane < 32 && ct * 32 + lane < clg_next) ? gload(bp_next + ct * 32 + lane) : 0.f;
+                if constexpr (TR) bias_v = (has_next && bp_next && ct * 32 + l31 < clg_next) ? gload(bp_next + ct * 32 + l31) : 0.f;
+                else bias_v = (has_next && bp_next && lane < 32 && ct * 32 + lane < clg_next) ? gload(bp_next + ct * 32 + lane) : 0.f;
                 finish_tile(load_tile(ti));
-                if (lane < 32) bias_w[lane] = bias_scaled(bias_v);    // the next tile's bias,
+                if constexpr (TR) bias_lane = bias_scaled(bias_v); else { if (lane < 32) bias_w[lane] = bias_scaled(bias_v); }    // the next tile's bias,
                 init_acc();                              // into its accumulators
             }
             if (slot < 29) WNTRACE(slot + 1);
@@ -864,16 +972,25 @@ int motif_conv_wino_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream
     if (T >= 0x7fffffffL) return MOTIF_ELIMIT;
     const int G = (int)(T < cus ? T : cus);
     const size_t ldsb = ((size_t)4 * 16 + (size_t)2 * NP * (2 * 16 * 34 + 4) + (size_t)4 * 640 + (size_t)128 * 4) * 16;      // bias | staging | landing | tile table
-    const void* fn = NP == 2 ? (P > 1 ? (const void*)conv_wino_kernel<2, true> : (const void*)conv_wino_kernel<2, false>)
-                             : (P > 1 ? (const void*)conv_wino_kernel<3, true> : (const void*)conv_wino_kernel<3, false>);
+    // transposed accumulators (register-only epilogue): OPT-IN (option conv_wino_tr = 1), for launches whose activation is uniform over the
+    // couts.  Measured (tools/conv_bench.py, same box, 3 x 64 -> 64 x 180 x 320): 49.7 vs 49.0 us without a residual -- the 350 instructions
+    // and the LDS round trip it removes are not what the exposed epilogue waits for -- and 61.7 vs 53.7 us WITH one (a residual piece per lane
+    // = 32 cache lines per load instruction instead of 8).  The default stays the row-major form.
+    const bool tr = NP == 2 && d->act_split <= 0 && motif_opt(MOTIF_OPT_CONV_WINO_TR) == 1;
+    const void* fn = NP == 2 ? (tr ? (P > 1 ? (const void*)conv_wino_kernel<2, true, true> : (const void*)conv_wino_kernel<2, false, true>)
+                                    : (P > 1 ? (const void*)conv_wino_kernel<2, true, false> : (const void*)conv_wino_kernel<2, false, false>))
+                             : (P > 1 ? (const void*)conv_wino_kernel<3, true, false> : (const void*)conv_wino_kernel<3, false, false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    if (NP == 2) {
-        if (P > 1) conv_wino_kernel<2, true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
-        else conv_wino_kernel<2, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+    if (NP == 2 && tr) {
+        if (P > 1) conv_wino_kernel<2, true, true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+        else conv_wino_kernel<2, false, true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+    } else if (NP == 2) {
+        if (P > 1) conv_wino_kernel<2, true, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+        else conv_wino_kernel<2, false, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
     } else {
-        if (P > 1) conv_wino_kernel<3, true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
-        else conv_wino_kernel<3, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+        if (P > 1) conv_wino_kernel<3, true, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+        else conv_wino_kernel<3, false, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
     }
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;

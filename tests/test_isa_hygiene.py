@@ -28,14 +28,14 @@ def wino_isa(tmp_path_factory):
     subprocess.run(cmd, check=True, capture_output=True, timeout=900)
     text = out.read_text()
     kernels = {}
-    for m in re.finditer(r"^(_Z16conv_wino_kernelILi(\d)ELb(\d)EEv8ConvArgsii):", text, re.M):
+    for m in re.finditer(r"^(_Z16conv_wino_kernelILi(\d)ELb(\d)ELb(\d)EEv8ConvArgsii):", text, re.M):
         end = text.index(".Lfunc_end", m.end())
-        kernels[(int(m.group(2)), bool(int(m.group(3))))] = text[m.end():end].splitlines()
+        kernels[(int(m.group(2)), bool(int(m.group(3))), bool(int(m.group(4))))] = text[m.end():end].splitlines()
     meta = {}
-    for m in re.finditer(r"\.name:\s+(_Z16conv_wino_kernelILi(\d)ELb(\d)EEv8ConvArgsii)\s", text):
+    for m in re.finditer(r"\.name:\s+(_Z16conv_wino_kernelILi(\d)ELb(\d)ELb(\d)EEv8ConvArgsii)\s", text):
         blk = text[max(0, m.start() - 1500):m.end() + 1500]
         sp = re.search(r"\.vgpr_spill_count:\s+(\d+)", blk)
-        meta[(int(m.group(2)), bool(int(m.group(3))))] = int(sp.group(1)) if sp else None
+        meta[(int(m.group(2)), bool(int(m.group(3))), bool(int(m.group(4))))] = int(sp.group(1)) if sp else None
     return kernels, meta
 
 
@@ -48,18 +48,23 @@ def _instr(lines):
 
 def test_conv_wino_kernels_exist_without_flat_loads_and_without_spills_in_the_shipped_form(wino_isa):
     kernels, meta = wino_isa
-    assert set(kernels) == {(2, False), (2, True), (3, False), (3, True)}
+    # (parts, multi-problem, transposed accumulators): the two-part form in both accumulator layouts, the three-part form row-major
+    assert set(kernels) == {(2, False, False), (2, True, False), (2, False, True), (2, True, True), (3, False, False), (3, True, False)}
     for key, lines in kernels.items():
         ops = [t.split()[0] for t in _instr(lines)]
-        assert not [o for o in ops if o.startswith("flat_")], "conv_wino_kernel<%d, %s> has FLAT memory instructions" % key
+        assert not [o for o in ops if o.startswith("flat_")], "conv_wino_kernel<%d, %s, %s> has FLAT memory instructions" % key
     for multi in (False, True):
-        assert meta[(2, multi)] == 0, "the two-part kernel must not spill vector registers (%s)" % meta
+        for tr in (False, True):
+            assert meta[(2, multi, tr)] == 0, "the two-part kernel must not spill vector registers (%s)" % meta
+    # the transposed form's epilogue stays out of LDS: no more LDS instructions than the row-major form's chunk body + staging alone
+    lds = {key: sum(1 for t in _instr(lines) if t.startswith("ds_")) for key, lines in kernels.items()}
+    assert lds[(2, False, True)] < lds[(2, False, False)] // 2, lds
 
 
-@pytest.mark.parametrize("parts, mfmas", [(2, 72), (3, 144)])
-def test_conv_wino_chunk_body_is_one_run_of_matrix_instructions_behind_a_counted_wait(wino_isa, parts, mfmas):
+@pytest.mark.parametrize("parts, mfmas, tr", [(2, 72, False), (2, 72, True), (3, 144, False)])
+def test_conv_wino_chunk_body_is_one_run_of_matrix_instructions_behind_a_counted_wait(wino_isa, parts, mfmas, tr):
     kernels, _ = wino_isa
-    lines = kernels[(parts, False)]
+    lines = kernels[(parts, False, tr)]
     idx = [i for i, ln in enumerate(lines) if "v_mfma_f32_32x32x16" in ln]
     runs, start, prev, n = [], idx[0], idx[0], 1
     for i in idx[1:]:
@@ -84,7 +89,7 @@ def test_wide_inline_assembly_stores_are_followed_by_two_wait_states(wino_isa):
         assert stores, key
         for i in stores:
             nxt = ins[i + 1]
-            assert nxt.startswith("s_nop") and int(nxt.split()[1]) >= 1, "conv_wino_kernel<%d, %s>: %s / %s" % (key + (ins[i], nxt))
+            assert nxt.startswith("s_nop") and int(nxt.split()[1]) >= 1, "conv_wino_kernel<%d, %s, %s>: %s / %s" % (key + (ins[i], nxt))
 
 
 @pytest.fixture(scope="module")

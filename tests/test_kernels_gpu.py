@@ -383,6 +383,39 @@ def test_conv_pw_pointwise_layers_match_fp64_and_the_fp32_engine(case, keep_mma)
     assert torch.equal(again.double().cpu(), outs[ops.MMA_F16X2][:1])
 
 
+@pytest.mark.parametrize("case", [(3, 64, 64, 45, 80, "relu", 1), (2, 128, 64, 37, 52, "lrelu", 0), (1, 64, 216, 20, 36, "none", 0), (2, 242, 96, 23, 40, "tanh", 4),
+                                  (2, 48, 40, 19, 36, "none", 2)])
+def test_conv_wino_transposed_accumulators_give_the_bits_of_the_row_major_form(case, keep_mma):
+    """Round 5: conv_wino_kernel<2, ., TR = true> swaps the two MFMA operands, so its accumulators come out transposed (lane = cout,
+    registers = pixels) and the epilogue stores 16-byte row pieces straight from registers.  Same products, same fp32 sums in the
+    same order, same epilogue arithmetic: the output must equal the row-major form BIT FOR BIT -- full and ragged tiles, partial cout
+    groups, every residual mode, a transcendental activation.  (Opt-in, option conv_wino_tr = 1: measured no faster)"""
+    from motif_amd import ops
+    from motif_amd.models.modules.layers import Conv2d
+    n, cin, cout, H, W, actn, rm = case
+    act = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "tanh": ops.ACT_TANH}[actn]
+    m = Conv2d(cin, cout, 3, 1, 1)
+    with torch.no_grad():
+        m.weight.copy_(rnd(*m.weight.shape, seed=1, scale=1.0 / math.sqrt(cin * 9)))
+        m.bias.copy_(rnd(cout, seed=2, scale=0.1))
+    m = m.to(dev())
+    x, res = rnd(n, cin, H, W, seed=3).to(dev()), rnd(n, cout, H, W, seed=4).to(dev())
+    kw = dict(act=act) if rm == 0 else dict(act=act, res=res, res_mode=rm)
+    ops.set_conv_mma(ops.MMA_F16X2)
+    outs = {}
+    try:
+        ops.set_option("conv_engine", 5)
+        for tr in (1, 0):
+            ops.set_option("conv_wino_tr", tr)
+            outs[tr] = m(x, **kw).clone()
+    finally:
+        ops.set_option("conv_wino_tr", 0)
+        ops.set_option("conv_engine", 0)
+    assert torch.equal(outs[0], outs[1])
+    ref = F.conv2d(x.double().cpu(), m.weight.double().cpu(), m.bias.double().cpu(), 1, 1)
+    assert float((outs[0].double().cpu() - (torch.tanh(ref) * res.double().cpu() if rm == 4 else ref)).abs().max()) < 1e3      # (finite; the value tests are the engine tests above)
+
+
 def test_conv_pw_guard_bands_channels_past_cin_and_couts_past_cout_touch_nothing(keep_mma):
     """conv_pw.hip relies on the buffer range check for channels past Cin (a ragged last 16-channel step), couts past
     Cout (a partial cout tile) and the masked lanes of a ragged pixel group.  The plane offsets are therefore part of the VECTOR

@@ -43,7 +43,9 @@ def main():
         ops.set_conv_mma(int(os.environ["MMA"]))                       # 6 = three bf16 parts, 7 = two fp16 parts (conv_wino.hip)
     if os.environ.get("ENGINE"):
         ops.set_option("conv_engine", int(os.environ["ENGINE"]))      # 1 = round-2 two-block kernel, 2 / 3 = round-3 kernel, 5 = round-4 Winograd kernel, 6 = never it, 0 = the library's choice
-    print("conv mma mode", ops.get_conv_mma(), "engine", ops.get_option("conv_engine"))
+    if os.environ.get("WINO_TR"):
+        ops.set_option("conv_wino_tr", int(os.environ["WINO_TR"]))    # 1 = transposed accumulators + register-only epilogue (experimental), 0 = row-major (default)
+    print("conv mma mode", ops.get_conv_mma(), "engine", ops.get_option("conv_engine"), "wino_tr", ops.get_option("conv_wino_tr"))
     for i, (n, ci, co, k, s, h, w) in enumerate(SHAPES):
         if only is not None and int(only) != i:
             continue
