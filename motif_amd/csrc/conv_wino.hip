@@ -460,6 +460,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         else if constexpr (kind == WP_HW) { if constexpr (!(WINO_ABL & 32)) st_hw(idx, dstbuf); }
     };
 
+    // Residual quads of the tile's first two epilogue passes, REQUESTED UNDER ITS LAST CHUNK (round 5, row-major form).  tools/trace_wino.py:
+    // requested at the start of the epilogue, the 16 quads first stalled 1.8 k cycles at issue behind the ~20 KB of next-tile row pieces and
+    // weight fragments in flight, then pass 0 waited another 1.8 k for them (in-order return): 9.5 k instead of 5.8 k cycles of epilogue.
+    // Eight quads fit the registers the main loop leaves free; they go into four request-free even slots of super-step 3, where every later
+    // request of the chunk belongs to the NEXT tile (its weight fragments and row pieces are consumed after this tile's epilogue), so
+    // nothing the MFMA stream is about to need queues behind a cold residual line.  Passes 2 / 3 are requested in the epilogue as before.
+    f32x4 rpre[2][4] = {};
+    bool rpre_on = false;                                // uniform: the current chunk is the last of a tile that has a residual (and couts)
+    const float* rpre_base = nullptr;                    // uniform
+    unsigned rpre_lb = 0;                                // per lane: offset of pass 0 / item 0 (see finish_tile)
+    int rpre_cl = 0;                                     // uniform: valid couts of this wave's cout tile
+    bool rpre_okl = false, rpre_full = false;            // per lane / uniform
     f32x16 acc[2][4];                                    // [row pair of this wave][position]
     constexpr int WB = 3;                                // weight fragment sets: a set is refilled for three super-steps ahead while in use
     u32x4 wf[WB][2][NP];                                 // [set][position of the pair][weight part]
@@ -522,6 +534,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 else wf[ss % WB][qi][p] = wfrag(wn, sc * 12 + wks(ss + 3 - SS, qi), p);
             }
             if constexpr (kWSchedOf<NP>.rl[s] >= 0 && !(WINO_ABL & 1)) st_load(kWSchedOf<NP>.rl[s], lc0);
+            if constexpr (NP == 2 && !TR && (s == 36 || s == 40 || s == 42 || s == 46)) {
+                if (rpre_on) {                           // uniform branch; two residual quads per slot
+                    constexpr int b0 = s == 36 ? 0 : s == 40 ? 2 : s == 42 ? 4 : 6;
+#pragma unroll
+                    for (int e = b0; e < b0 + 2; ++e) {
+                        const int pass = e >> 2, it = e & 3;
+                        const bool okq = (bool)((int)rpre_full | (int)(rpre_okl && 8 * pass + 2 * it + half < rpre_cl));    // bitwise: see the note at the transposed form's loads
+                        rpre[pass][it] = gload((const f32x4*)(rpre_base + (okq ? rpre_lb + (unsigned)(8 * pass + 2 * it) * HWo : 0u)));
+                    }
+                }
+            }
             piece(std::integral_constant<int, kWSchedOf<NP>.ext[s]>{}, dstbuf);
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -689,7 +712,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int it = 0; it < 4; ++it) rv[pass][it] = gload((const f32x4*)(rb + ((full || okv(pass, it)) ? offv(pass, it) : 0u)));   // masked lanes read element 0
         };
-        if (rm) { load_res(0); load_res(1); load_res(2); load_res(3); }
+        if (rm) {
+            if (rpre_on) {                               // passes 0 / 1 were requested under the last chunk
+#pragma unroll
+                for (int it = 0; it < 4; ++it) { rv[0][it] = rpre[0][it]; rv[1][it] = rpre[1][it]; }
+            } else { load_res(0); load_res(1); }
+            load_res(2); load_res(3);
+        }
         EPSTAMP();
         float* scr = (float*)land;                       // two halves of [8 couts][4 rows x 32 px]
         const int ew = hf * 512 + l5, er = hf * 128 + (l5 >> 3) * 32 + (l5 & 7) * 4;
@@ -837,6 +866,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 setup_loads(tq, has_next);
             }
             const bool last = c + 1 == nch;
+            if constexpr (NP == 2 && !TR) {
+                if (last && a.res_mode) {                // geometry of this tile's epilogue (finish_tile computes the same values)
+                    const TileP tc = load_tile(ti);
+                    rpre_cl = tc.clg - ct * 32;
+                    rpre_on = rpre_cl > 0 && tc.rb != nullptr && !(WINO_ABL & 256) && !(a.dbg & 64);
+                    rpre_base = tc.rb ? tc.rb + (long)(ct * 32) * (long)HWo : nullptr;
+                    int lane_q = lane;
+                    asm volatile("" : "+v"(lane_q));
+                    const int l5q = lane_q & 31, oyq = tc.ty * TH + 4 * tp + (l5q >> 3), oxq = tc.tx * 32 + (l5q & 7) * 4;
+                    rpre_okl = oyq < a.Ho && oxq < a.Wo;
+                    rpre_lb = (unsigned)(lane_q >> 5) * HWo + (unsigned)(oyq * a.Wo + oxq);
+                    rpre_full = rpre_cl >= 32 && tc.ty * TH + 4 * tp + 4 <= a.Ho && tc.tx * 32 + 32 <= a.Wo;
+                }
+            }
             const int sc = last ? 0 : c + 1, lc0 = (c + 2 < nch ? c + 2 : c + 2 - nch) * 16;
             const __amdgpu_buffer_rsrc_t wn = last ? wnext : wbase;
             chunk_body(c, buf, sc, wn, lc0);
@@ -845,6 +888,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if constexpr (TR) bias_v = (has_next && bp_next && ct * 32 + l31 < clg_next) ? gload(bp_next + ct * 32 + l31) : 0.f;
                 else bias_v = (has_next && bp_next && lane < 32 && ct * 32 + lane < clg_next) ? gload(bp_next + ct * 32 + lane) : 0.f;
                 finish_tile(load_tile(ti));
+                rpre_on = false;
                 if constexpr (TR) bias_lane = bias_scaled(bias_v); else { if (lane < 32) bias_w[lane] = bias_scaled(bias_v); }    // the next tile's bias,
                 init_acc();                              // into its accumulators
             }
@@ -977,6 +1021,7 @@ int motif_conv_wino_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream
     // and the LDS round trip it removes are not what the exposed epilogue waits for -- and 61.7 vs 53.7 us WITH one (a residual piece per lane
     // = 32 cache lines per load instruction instead of 8).  The default stays the row-major form.
     const bool tr = NP == 2 && d->act_split <= 0 && motif_opt(MOTIF_OPT_CONV_WINO_TR) == 1;
+    if (motif_opt(MOTIF_OPT_CONV_WINO_RPRE) == 1) a.dbg |= 64;          // A/B switch: residual quads requested in the epilogue only
     const void* fn = NP == 2 ? (tr ? (P > 1 ? (const void*)conv_wino_kernel<2, true, true> : (const void*)conv_wino_kernel<2, false, true>)
                                     : (P > 1 ? (const void*)conv_wino_kernel<2, true, false> : (const void*)conv_wino_kernel<2, false, false>))
                              : (P > 1 ? (const void*)conv_wino_kernel<3, true, false> : (const void*)conv_wino_kernel<3, false, false>);

@@ -43,6 +43,8 @@ def main():
         ops.set_conv_mma(int(os.environ["MMA"]))                       # 6 = three bf16 parts, 7 = two fp16 parts (conv_wino.hip)
     if os.environ.get("ENGINE"):
         ops.set_option("conv_engine", int(os.environ["ENGINE"]))      # 1 = round-2 two-block kernel, 2 / 3 = round-3 kernel, 5 = round-4 Winograd kernel, 6 = never it, 0 = the library's choice
+    if os.environ.get("WINO_RPRE"):
+        ops.set_option("conv_wino_rpre", int(os.environ["WINO_RPRE"]))    # 1 = residual quads requested in the epilogue only (round 4 behaviour)
     if os.environ.get("WINO_TR"):
         ops.set_option("conv_wino_tr", int(os.environ["WINO_TR"]))    # 1 = transposed accumulators + register-only epilogue (experimental), 0 = row-major (default)
     print("conv mma mode", ops.get_conv_mma(), "engine", ops.get_option("conv_engine"), "wino_tr", ops.get_option("conv_wino_tr"))
