@@ -828,11 +828,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int t = bq;
     WNTRACE(0);
     WNTRACE_RT(30);
+#ifdef MOTIF_TRACE
+    long long pst[6];
+    pst[0] = __builtin_amdgcn_s_memtime();
+#endif
     if (wave == 0) {
         fill_table(0);
         if ((long)bq + 64L * G < ntiles) fill_table(64);
     }
     __syncthreads();
+#ifdef MOTIF_TRACE
+    pst[1] = __builtin_amdgcn_s_memtime();
+#endif
     {
         const TileP t0 = load_tile(0);
         setup_loads(t0, true);
@@ -846,12 +853,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int clg_next = 0;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) st_load(i, 0);
+#ifdef MOTIF_TRACE
+    pst[2] = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pst[3] = __builtin_amdgcn_s_memtime();
+#endif
     static_for<WS::S>([&](auto ic) __attribute__((always_inline)) { piece(std::integral_constant<int, kWSchedOf<NP>.ext[decltype(ic)::value]>{}, stg0); });
+#ifdef MOTIF_TRACE
+    pst[4] = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (TR) bias_lane = bias_scaled(bias_v); else { if (lane < 32) bias_w[lane] = bias_scaled(bias_v); }
     init_acc();
 #pragma unroll
     for (int i = 0; i < NLD; ++i) st_load(i, 16);        // nch >= 2: step 1 is chunk 1 of this tile
     __syncthreads();
+#ifdef MOTIF_TRACE
+    pst[5] = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && blockIdx.x < 256) { for (int i = 0; i < 6; ++i) g_wn_trace2[((blockIdx.x * 4 + wave) * 8 + 7) * 8 + i] = pst[i]; }
+#endif
     WNTRACE(1);
 
     // ---- persistent tile loop ------------------------------------------------------------------------------------------------

@@ -65,3 +65,10 @@ if os.environ.get("SS"):      # a -DMOTIF_TRACE_SS build: entries 3 .. 7 hold th
             print("  chunk %d (chunk %d of its tile): %s | total %6.0f" % (k, k % nch, " ".join("%6.0f" % d[..., i][okc].mean() for i in range(6)), (t2[:, :, k, 6] - t2[:, :, k, 0])[okc].mean()))
             if k == 5:
                 print("     per wave: " + " | ".join(" ".join("%5.0f" % d[:, w, i][okc[:, w]].mean() for i in range(6)) for w in range(4)))
+
+if os.environ.get("PRO"):
+    d = t2[:, :, 7, 1:6] - t2[:, :, 7, 0:5]
+    okc = t2[:, :, 7, 5] > 0
+    print("prologue phases (cycles): table+barrier | issue weights+row pieces | wait for them | staging pieces | init + step-1 requests + barrier")
+    print("   " + " ".join("%6.0f" % d[..., i][okc].mean() for i in range(5)))
+    print("   per wave: " + " | ".join(" ".join("%5.0f" % d[:, w, i][okc[:, w]].mean() for i in range(5)) for w in range(4)))
