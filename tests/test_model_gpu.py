@@ -315,6 +315,28 @@ def test_pwcnet_matches_reference_golden():
     golden_cmp(g, "flow", flow, 2e-4, 1e-3)
 
 
+def test_pwcnet_batch_of_pairs_equals_the_pairs_one_by_one_and_the_oracle():
+    """Round 5 host changes of PWC-Net: both frames of a pair go through the extractor as one batch, and every pyramid level keeps its
+    dense-connection stack in ONE tensor (producers write channel slices in place when a batch item's slice is contiguous, B = 1, and copy
+    into them otherwise).  A batch of two different pairs exercises the copy path: item i must equal pair i run alone bit for bit, and the
+    CPU oracle (`oracle/pwc_ref.py`, pinned to the reference by `pwc_96x128.npz`) within the golden's tolerance -- at an odd map size."""
+    from oracle.pwc_ref import PwcRef
+    from motif_amd.OpticalFlow.PWCNet import PWCNet
+    from motif_amd.utils.synth_weights import fill_state_dict
+    g = torch.Generator().manual_seed(11)
+    first, second = torch.rand(2, 3, 72, 136, generator=g), torch.rand(2, 3, 72, 136, generator=g)
+    net = fill_state_dict(PWCNet()).cuda().eval()
+    with torch.no_grad():
+        both = net(first.cuda(), second.cuda())
+        solo = [net(first[i:i + 1].cuda(), second[i:i + 1].cuda()) for i in range(2)]
+        ref = fill_state_dict(PwcRef().eval())(first, second)
+    assert both.shape == ref.shape == (2, 2, 18, 34)
+    for i in range(2):
+        assert torch.equal(both[i:i + 1], solo[i])
+    err = (both.cpu() - ref).abs()
+    assert float(err.max()) <= 2e-4 + 1e-3 * float(ref.abs().max()), float(err.max())
+
+
 def test_non_integer_scale_and_cache_invalidation():
     """scale 2.5 exercises the literal nearest-gather tables (no i//s shortcut); the HIP path must agree with
     the CPU oracle (the restatement pinned bit-exact to the reference), and the t-independent cache must be
