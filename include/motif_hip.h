@@ -222,6 +222,33 @@ int motif_conv2d_fwd_multi(const MotifConvDesc* d, int P, const float* const* in
                            float* const* out, const long* in0_bs, const long* in1_bs, const long* res_bs,
                            const long* out_bs, void* stream);
 
+/* A CHAIN of L dependent 3x3 / stride-1 / zero-pad-1 convolutions C -> C of one shape in ONE persistent launch (ABI 8): what
+ * nn.Sequential(ResidualBlock_noBN x 40) -- the reconstruction trunk, models/modules/module_util.py:34-52 as built at
+ * models/modules/Ours.py:349 and run at Ours.py:393-409 -- and the 5-block feature extraction (Ours.py:352-356, 368-370)
+ * are: x' = x + conv2(relu(conv1(x))).  Same arithmetic and the same bits as L calls of motif_conv2d_fwd (the per-tile
+ * computation is that kernel's; tests compare with torch.equal), without L launch boundaries, with one kernel prologue per
+ * workgroup instead of one per layer and no idle tail per layer: the tiles of all layers are handed out in layer-major order,
+ * a tile starts when the <= 9 tiles of the layer before that it reads have been published (conv_wino.hip, CHAIN).
+ *   d        shape and arithmetic of EVERY layer: mma = 7, groups 1, C1 = 0, 49 <= C0 = Cout <= 64, W % 4 == 0; d->act /
+ *            res_mode are ignored (per layer below); d->in0_bs / out_bs = batch strides of x / out (0 = dense); d->status as usual,
+ *            bit 1 = the chain did not advance for a second and was abandoned (results invalid; never seen in testing).
+ *   layers   DEVICE array of L entries.  Buffer ids: 0 = x (never written), 1 = out, 2 + i = scratch buffer i =
+ *            work + i * N * C * H * W (dense NCHW).  The caller orders the buffers so that a layer overwrites a buffer only
+ *            when all its readers are producers-of-producers of the writing tile; the rotation of a residual trunk
+ *            (conv1: X_b -> T; conv2: T (+ X_b) -> X_b+1, X alternating between two buffers) satisfies it with three buffers.
+ *   ws       device scratch of motif_conv2d_chain_ws_words(d, L) 32-bit words (<= 0: this shape cannot run as a chain:
+ *            call the layers one by one); zeroed by the entry on `stream` before the launch.
+ * 16-byte aligned pointers; all on `stream`. */
+typedef struct MotifChainLayer {
+    const float* packed;      /* motif_conv2d_pack blob of the layer (same desc but for the epilogue fields) */
+    const float* bias;        /* [C] or NULL */
+    int32_t src, dst, res;    /* buffer ids; res = -1: no residual */
+    int32_t act_rm;           /* MOTIF_ACT_* | residual mode << 8 (modes as MotifConvDesc.res_mode) */
+} MotifChainLayer;
+long motif_conv2d_chain_ws_words(const MotifConvDesc* d, int L);
+int motif_conv2d_chain_fwd(const MotifConvDesc* d, int L, const MotifChainLayer* layers /*device*/, const float* x, float* out,
+                           float* work, long work_floats, uint32_t* ws, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * D2  modulated deformable convolution v2, forward.
  * Replaces _ext.dcn_v2_forward (models/modules/DCNv2/src/dcn_v2.h:9-39, cuda/dcn_v2_cuda.cu:42-171,

@@ -46,6 +46,8 @@ _SIGS = {
     "motif_conv2d_pack": (c_int, [POINTER(MotifConvDesc), P, P, P]),
     "motif_conv2d_fwd": (c_int, [POINTER(MotifConvDesc), P, P, P, P, P, P, P]),
     "motif_conv2d_fwd_multi": (c_int, [POINTER(MotifConvDesc), c_int] + [POINTER(c_void_p)] * 6 + [POINTER(c_long)] * 4 + [P]),
+    "motif_conv2d_chain_ws_words": (c_long, [POINTER(MotifConvDesc), c_int]),
+    "motif_conv2d_chain_fwd": (c_int, [POINTER(MotifConvDesc), c_int, P, P, P, P, c_long, P, P]),
     "motif_dcn_v2_fwd_multi": (c_int, [c_int, POINTER(c_void_p), POINTER(c_long)] + [POINTER(c_void_p)] * 4 + [P, POINTER(c_void_p)]
                                + [c_int] * 11 + [c_long, c_long, c_int, P]),
     "motif_dcn_v2_fwd": (c_int, [P, P, P, P, P, P, P] + [c_int] * 11 + [c_long, c_long, c_int, P]),
@@ -72,7 +74,7 @@ _SIGS = {
     "motif_flow_roundtrip": (c_int, [P, P, c_int, c_long, c_float, c_float, P]),
     "motif_deconv4x4s2": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
 }
-ABI_VERSION = 7          # include/motif_hip.h / api.hip: motif_abi_version()
+ABI_VERSION = 8          # include/motif_hip.h / api.hip: motif_abi_version()
 EXPORTS = tuple(_SIGS)
 
 

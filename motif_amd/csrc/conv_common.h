@@ -19,6 +19,17 @@ struct ConvArgs {
     unsigned* status;   // MotifConvDesc.status: the fp16-form kernels OR bit 0 into it on a non-finite accumulator (may be null)
 };
 
+// conv_wino's CHAIN mode (motif_conv2d_chain_fwd): L dependent same-shape layers in one persistent launch.  `layers` is the caller's DEVICE
+// table (MotifChainLayer of the header), buffer id 0 = ConvArgs.in0[0] (chain input), 1 = ConvArgs.out[0] (chain output), >= 2 = scratch.
+struct ChainLayerDev { const float* packed; const float* bias; int src, dst, res, act_rm; };     // act_rm = act | res_mode << 8
+struct ChainArgs {
+    const ChainLayerDev* layers;
+    float* work; long buf_floats;      // scratch buffer id i at work + (i - 2) * buf_floats, contiguous NCHW
+    unsigned* ws;                      // [0] ticket counter, [1] abort word, [64 + layer * T + tile] completion flags; zeroed before the launch
+    long wp_off;                       // floats from a layer's packed blob to its Winograd block
+    int L;
+};
+
 // Limits of one reduction chunk (host planner keeps to them): patch elements <= PATCH_MAX, packed weight
 // floats <= WCHUNK_MAX, so that a whole chunk can be prefetched into registers while the previous one is
 // being multiplied (global -> VGPR issue-early, VGPR -> LDS write-late; two LDS buffers, one barrier per chunk).

@@ -202,8 +202,18 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make
 // across lanes there: those launches keep the row-major form.  RESULT: bit-identical, and no faster (see motif_conv_wino_launch): opt-in.
 // MULTI: more than one problem in the launch (the per-problem argument selects are ~100 scalar instructions per tile: a lone wave
 // hides none of them).
-template <int NP, bool MULTI, bool TR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino_kernel(ConvArgs a, int ntiles, int tiles_y) {
+// CHAIN (round 5): ch.L dependent same-shape layers (a residual trunk: module_util.py:34-52 x 40, Ours.py:349) in ONE persistent launch.  The
+// tiles of all layers form one ticket sequence in layer-major order (atomic counter: a workgroup that is not resident holds no ticket, so the
+// smallest unfinished tile is always owned by a running workgroup -- no deadlock whatever the residency, two clips in flight included); tile
+// (l, y, x) needs the <= 9 tiles (l-1, y+-1, x+-1): one completion flag per tile, set after the tile's stores have been acknowledged, polled
+// WITHOUT blocking while the previous tile is still being multiplied (the next tile's row pieces are requested two chunks ahead) and waited
+// for only between tiles, when the workgroup has nothing in flight.  The XCDs' L2s are not coherent inside a kernel: activations and
+// residuals are loaded and stored with sc1 (device-coherent), weights and biases (read-only) stay cached; tools/ubench_chain.hip is the
+// protocol on its own (exact over 80 layers x 690 tiles; the plain data path fails there).  No launch boundaries, ONE prologue per workgroup
+// instead of one per layer, and the round fill of a layer (690 tiles on 256 CUs: 0.90) becomes that of the whole chain (~1.0).
+template <int NP, bool MULTI, bool TR, bool CHAIN = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino_kernel(ConvArgs a, int ntiles, int tiles_y, ChainArgs ch) {
+    static_assert(!CHAIN || (NP == 2 && !MULTI && !TR), "chain mode: two-part row-major form, one problem");
     using WS = WSched<NP>;
     using WO = WOrder<NP>;
     constexpr int WAVES = 4, TH = 8, PW = 34, OCT = 16 * PW;   // 16 (pair, position) planes of 34 pixels per octet
@@ -223,8 +233,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int TT = 128;                              // tile-parameter table: [TT][4] x 16 bytes, entry = ordinal of the tile in this workgroup
     u32x4* ttab = lds_raw + WAVES * 16 + 2 * STG + WAVES * LW;
 
-    const int G = gridDim.x, bq = xcd_block_id(blockIdx.x, G);
-    if (bq >= ntiles) return;
+    const int G = gridDim.x, bq = CHAIN ? 0 : xcd_block_id(blockIdx.x, G);
+    if (!CHAIN && bq >= ntiles) return;
     const int nch = a.Kpad / 12;                                        // >= 2 (host)
     const int ncgG = a.CK;                                              // groups * ncg
     const int HW = a.H * a.W;
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // residual / bias addresses (64-bit multiply-adds, per-problem selects) are computed by ONE LANE EACH of wave 0 -- 64 tiles at a
     // time on the vector ALU -- and parked in LDS; a tile change then costs four broadcast ds_read_b128 and sixteen readfirstlanes
     // instead of ~150 dependent scalar instructions (a lone wave hides none of them: they were 1-1.5 k of a tile's 34 k cycles).
-    struct TileP { const float* in0n; const float* in1n; const u32x4* wb; float* ob; const float* rb; const float* bp; int ty, tx, g, clg, cbg; };
+    struct TileP { const float* in0n; const float* in1n; const u32x4* wb; float* ob; const float* rb; const float* bp; int ty, tx, g, clg, cbg, act, rm, tk; };
     auto fill_table = [&](int e0) __attribute__((always_inline)) {       // entries e0 .. e0 + 63, by the 64 lanes of the calling wave
         const int e = e0 + lane;
         const long tl = (long)bq + (long)e * G;
@@ -281,8 +291,85 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         t.wb = (const u32x4*)p64(r1[0], r1[1]); t.ob = (float*)p64(r1[2], r1[3]);
         t.rb = (const float*)p64(r2[0], r2[1]); t.bp = (const float*)p64(r2[2], r2[3]);
         const unsigned yx = sg(r3[0]);
-        t.ty = (int)(yx & 0xffffu); t.tx = (int)(yx >> 16); t.g = (int)sg(r3[1]); t.clg = (int)sg(r3[2]); t.cbg = (int)sg(r3[3]);
+        t.ty = (int)(yx & 0xffffu); t.tx = (int)(yx >> 16); t.clg = (int)sg(r3[2]);
+        if constexpr (CHAIN) {                           // one group, one cout group: the two words carry the layer's epilogue and the tile's ticket
+            const unsigned ar = sg(r3[1]);
+            t.g = 0; t.cbg = 0; t.act = (int)(ar & 255u); t.rm = (int)((ar >> 8) & 255u); t.tk = (int)sg(r3[3]);
+        } else { t.g = (int)sg(r3[1]); t.cbg = (int)sg(r3[3]); t.act = a.act; t.rm = a.res_mode; t.tk = 0; }
         return t;
+    };
+
+    // ---- CHAIN mode: tickets, table entries, completion flags (wave 0 does all of it; the other waves learn the outcome from LDS behind a barrier)
+    int* chs = (int*)((float*)lds_raw + 32);             // spare words of wave 0's bias area: [0] pending ticket, [1] its state (0 none left, 1 ready, 2 not ready yet, 3 aborted)
+    const int chain_total = CHAIN ? ch.L * ntiles : 0;   // < 2^24 (host)
+    int lane_c = lane;                                   // opaque copy: a lane test on it is never merged with another test of the lane index across a
+    asm volatile("" : "+v"(lane_c));                     // barrier (tools/ubench_chain.hip: hipcc threaded two `tid == 0` blocks round a loop and split wave 0 at the barriers)
+    auto chain_ticket_issue = [&]() __attribute__((always_inline)) {
+        unsigned v = 0;
+        if (lane_c == 0) v = __hip_atomic_fetch_add(ch.ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    };
+    auto chain_entry = [&](int e, int tk) __attribute__((always_inline)) {      // tk uniform: scalar arithmetic, one lane writes
+        const int l = tk / ntiles, r = tk - l * ntiles;
+        const int tx = r % a.tiles_x, s2 = r / a.tiles_x, ty = s2 % tiles_y, n = s2 / tiles_y;
+        const u32x4* lp = (const u32x4*)(ch.layers + l);
+        const u32x4 q0 = gload(lp), q1 = gload(lp + 1);
+        auto sg = [](unsigned v) __attribute__((always_inline)) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+        const unsigned long long packed = ((unsigned long long)sg(q0[1]) << 32) | sg(q0[0]), bp = ((unsigned long long)sg(q0[3]) << 32) | sg(q0[2]);
+        const int src = (int)sg(q1[0]), dst = (int)sg(q1[1]), res = (int)sg(q1[2]);
+        const long HWol = (long)a.Ho * a.Wo, plane = (long)a.Cout * HWol;
+        auto bufp = [&](int id) __attribute__((always_inline)) {
+            if (id == 0) return (unsigned long long)(a.in0[0] + (long)n * a.in0_bs[0]);
+            if (id == 1) return (unsigned long long)(a.out[0] + (long)n * a.out_bs[0]);
+            return (unsigned long long)(ch.work + (long)(id - 2) * ch.buf_floats + (long)n * plane);
+        };
+        const unsigned long long i0 = bufp(src), ob = bufp(dst), rb = res >= 0 ? bufp(res) : 0ull;
+        const unsigned long long wb = packed + (unsigned long long)ch.wp_off * 4ull;
+        if (lane_c == 0) {
+            u32x4* rr = ttab + (e & (TT - 1)) * 4;
+            rr[0] = u32x4{(unsigned)i0, (unsigned)(i0 >> 32), 0u, 0u};
+            rr[1] = u32x4{(unsigned)wb, (unsigned)(wb >> 32), (unsigned)ob, (unsigned)(ob >> 32)};
+            rr[2] = u32x4{(unsigned)rb, (unsigned)(rb >> 32), (unsigned)bp, (unsigned)(bp >> 32)};
+            rr[3] = u32x4{(unsigned)ty | ((unsigned)tx << 16), sg(q1[3]), (unsigned)a.Cout_g, (unsigned)tk};
+        }
+    };
+    // lane i < 9 = producer (dy, dx) of tile tk in the layer before: its flag, 1 where there is none
+    auto chain_flags = [&](int tk) __attribute__((always_inline)) {
+        const int l = tk / ntiles, r = tk - l * ntiles;
+        const int tx = r % a.tiles_x, ty = (r / a.tiles_x) % tiles_y;
+        const int dy = lane_c / 3 - 1, dx = lane_c - 3 * (lane_c / 3) - 1;
+        const bool has = l > 0 && lane_c < 9 && (unsigned)(ty + dy) < (unsigned)tiles_y && (unsigned)(tx + dx) < (unsigned)a.tiles_x;
+        unsigned f = 1u;
+        if (has) f = __hip_atomic_load(ch.ws + 64 + (long)(l - 1) * ntiles + r + dy * a.tiles_x + dx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return f;
+    };
+    auto chain_all = [](unsigned f) __attribute__((always_inline)) { return __builtin_amdgcn_ballot_w64(f != 0u) == ~0ull; };
+    // between tiles only (nothing of this workgroup in flight, so waiting here can block nobody this workgroup could unblock); bounded: a chain
+    // that does not advance for a second sets the abort word and status bit 1 instead of hanging the device
+    auto chain_wait = [&](int tk) __attribute__((always_inline)) {
+        const long long t0 = __builtin_amdgcn_s_memrealtime();              // 100 MHz
+        for (;;) {
+            if (chain_all(chain_flags(tk))) return true;
+            if (__hip_atomic_load(ch.ws + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ll) {
+                if (lane_c == 0) {
+                    __hip_atomic_store(ch.ws + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (a.status) atomicOr(a.status, 2u);
+                }
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    };
+    auto chain_publish = [&](int tk) __attribute__((always_inline)) {
+        if (lane_c == 0) __hip_atomic_store(ch.ws + 64 + tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // activations / residuals of a chain come from other XCDs inside this launch: device-coherent (sc1) accesses
+    auto rload = [&](const float* base, unsigned off_elems) __attribute__((always_inline)) {
+        if constexpr (CHAIN) {
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(off_elems * 4u), 0, 16));
+        } else return gload((const f32x4*)(base + off_elems));
     };
 
     // ---- per-lane constants of the staging role (row pair T = wave) ------------------------------------------------------
@@ -361,7 +448,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nchv * HW * 4, 0x00020000);
         // BYTE offset from the chunk's first plane; 2^31 = "outside the image": beyond any descriptor's range, the load returns 0
         const int off = POFF ? po[POFF ? i : 0] : ((vmask >> i) & 1u ? pl[i] + origin : (int)0x80000000);
-        gq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+        gq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, CHAIN ? 16 : 0));
     };
     auto st_park = [&](int i) __attribute__((always_inline)) { *(f32x4*)(land + i * 64 + lane) = gq[i]; };
     float sv[4][8] = {};                                   // [input row of the pair][channel of the octet]
@@ -541,7 +628,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     for (int e = b0; e < b0 + 2; ++e) {
                         const int pass = e >> 2, it = e & 3;
                         const bool okq = (bool)((int)rpre_full | (int)(rpre_okl && 8 * pass + 2 * it + half < rpre_cl));    // bitwise: see the note at the transposed form's loads
-                        rpre[pass][it] = gload((const f32x4*)(rpre_base + (okq ? rpre_lb + (unsigned)(8 * pass + 2 * it) * HWo : 0u)));
+                        rpre[pass][it] = rload(rpre_base, okq ? rpre_lb + (unsigned)(8 * pass + 2 * it) * HWo : 0u);
                     }
                 }
             }
@@ -604,7 +691,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
         const unsigned long long obp = (unsigned long long)(t.ob + (long)(ct * 32) * (long)HWo);            // uniform: the stores take it in SGPRs
         const float* rb = t.rb ? t.rb + (long)(ct * 32) * (long)HWo : nullptr;
-        const int rm = a.res_mode;
+        const int rm = CHAIN ? t.rm : a.res_mode;
         if constexpr (TR) {
             // Transposed accumulators: lane = cout l5 of this wave's cout tile (both half-waves), register r = pixel (r & 3) + 8 (r >> 2) + 4 hf of
             // the 32-pixel row: registers 4q .. 4q+3 are the four consecutive pixels 8q + 4hf .. + 3, i.e. ONE 16-byte piece of an NCHW row.
@@ -710,7 +797,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         f32x4 rv[4][4];
         auto load_res = [&](int pass) __attribute__((always_inline)) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) rv[pass][it] = gload((const f32x4*)(rb + ((full || okv(pass, it)) ? offv(pass, it) : 0u)));   // masked lanes read element 0
+            for (int it = 0; it < 4; ++it) rv[pass][it] = rload(rb, (full || okv(pass, it)) ? offv(pass, it) : 0u);   // masked lanes read element 0
         };
         if (rm) {
             if (rpre_on) {                               // passes 0 / 1 were requested under the last chunk
@@ -751,7 +838,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 if (pass + 1 < 4) write_pass(pass + 1);
-                const int ac = AC >= 0 ? AC : ((a.act_split > 0 && cb + 8 * pass >= a.act_split) ? a.act2 : a.act);      // uniform per pass
+                const int ac = AC >= 0 ? AC : ((a.act_split > 0 && cb + 8 * pass >= a.act_split) ? a.act2 : (CHAIN ? t.act : a.act));      // uniform per pass
                 f32x4 v[4];
 #pragma unroll
                 for (int it = 0; it < 4; ++it) v[it] = *(const f32x4*)(scr + (pass & 1) * 1024 + er + it * 256);
@@ -797,14 +884,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     const f32x4 val = v[it];
                     // s_nop: the wait state between a store of more than 8 bytes and the next vector write of its data registers -- hipcc
                     // inserts it for its own stores, not around inline assembly
-                    if (full) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(bo), "v"(val), "s"(obq) : "memory");
-                    else if (okv(pass, it)) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(bo), "v"(val), "s"(obq) : "memory");
+                    if constexpr (CHAIN) {
+                        if (full) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(bo), "v"(val), "s"(obq) : "memory");
+                        else if (okv(pass, it)) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(bo), "v"(val), "s"(obq) : "memory");
+                    } else {
+                        if (full) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(bo), "v"(val), "s"(obq) : "memory");
+                        else if (okv(pass, it)) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(bo), "v"(val), "s"(obq) : "memory");
+                    }
                 }
                 EPSTAMP();
             }
         };
         using I = std::integral_constant<int, 0>;
-        const int act = a.act;
+        const int act = CHAIN ? t.act : a.act;
         if (a.act_split > 0 && rm == 0 && act == MOTIF_ACT_NONE && a.act2 == MOTIF_ACT_SIGMOID) passes(std::integral_constant<int, -2>{}, I{});    // the DCNs' offset | mask layer
         else if (a.act_split > 0) passes(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
         else if (rm == 0 && act == MOTIF_ACT_NONE) passes(std::integral_constant<int, MOTIF_ACT_NONE>{}, I{});
@@ -826,29 +918,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- prologue: step 0 staged in full, the row pieces of step 1 requested (nothing to hide them under) --------------------
     int t = bq;
+    unsigned tkv = 0, fv = 1u;                           // CHAIN: the ticket requested during chunk nch - 4 (read a chunk later), the flags polled under chunk nch - 3
+    int tk_pend = 0;
+    bool first_run = true;
+    // CHAIN: one iteration per RUN = prologue + tiles that follow each other through the step pipeline.  A run ends when the tickets are used
+    // up or when the next tile's producers had not all finished at the time it was polled; the workgroup then finishes its tile, waits with
+    // nothing in flight, and starts the next run.  Otherwise: one iteration.
+    for (;;) {
     WNTRACE(0);
     WNTRACE_RT(30);
 #ifdef MOTIF_TRACE
     long long pst[6];
     pst[0] = __builtin_amdgcn_s_memtime();
 #endif
-    if (wave == 0) {
-        fill_table(0);
-        if ((long)bq + 64L * G < ntiles) fill_table(64);
+    if constexpr (CHAIN) {
+        if (wave == 0) {
+            int tk, st;
+            if (first_run) {
+                tk = __builtin_amdgcn_readfirstlane((int)chain_ticket_issue());
+                st = tk < chain_total ? 2 : 0;
+                if (st) chain_entry(ti, tk);
+            } else { tk = __builtin_amdgcn_readfirstlane(chs[0]); st = __builtin_amdgcn_readfirstlane(chs[1]); }
+            if (st == 2) st = chain_wait(tk) ? 1 : 3;
+            if (lane_c == 0) { chs[0] = tk; chs[1] = st; }
+        }
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(chs[1]) != 1) return;
+        first_run = false;
+    } else {
+        if (wave == 0) {
+            fill_table(0);
+            if ((long)bq + 64L * G < ntiles) fill_table(64);
+        }
+        __syncthreads();
     }
-    __syncthreads();
 #ifdef MOTIF_TRACE
     pst[1] = __builtin_amdgcn_s_memtime();
 #endif
     {
-        const TileP t0 = load_tile(0);
+        const TileP t0 = load_tile(ti);
         setup_loads(t0, true);
         wbase = wnext = wptr(t0);
     }
     loadw(wbase, 0, wf[0]);
     loadw(wbase, 1, wf[1]);
     loadw(wbase, 2, wf[2]);
-    float bias_v = bias_of(load_tile(0));
+    float bias_v = bias_of(load_tile(ti));
     const float* bp_next = nullptr;                      // bias pointer / valid couts of the next tile (uniform), set at the tile change
     int clg_next = 0;
 #pragma unroll
@@ -875,10 +990,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- persistent tile loop ------------------------------------------------------------------------------------------------
     int buf = 0, slot = 2;
+    bool has_next = false;
     for (;;) {
         const int t_next = t + G;
-        const bool has_next = t_next < ntiles;
+        if constexpr (!CHAIN) has_next = t_next < ntiles;
         for (int c = 0; c < nch; ++c) {
+            if constexpr (CHAIN) {
+                if (wave == 0) {
+                    if (c == nch - 4) tkv = chain_ticket_issue();
+                    if (c == nch - 3) {                  // the ticket has had a chunk to return: the next tile's table entry, its producers' flags requested
+                        tk_pend = __builtin_amdgcn_readfirstlane((int)tkv);
+                        if (tk_pend < chain_total) { chain_entry(ti + 1, tk_pend); fv = chain_flags(tk_pend); }
+                    }
+                }
+                if (c == nch - 2) has_next = __builtin_amdgcn_readfirstlane(chs[1]) == 1;
+            }
             if (c == nch - 2) {                          // from here on the row-piece requests belong to the next tile
                 const TileP tq = load_tile(has_next ? ti + 1 : ti);
                 if (has_next) { wnext = wptr(tq); bp_next = tq.bp; clg_next = tq.clg; } else wnext = wbase;      // (the next tile's bias is requested under the epilogue)
@@ -886,7 +1012,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             const bool last = c + 1 == nch;
             if constexpr (NP == 2 && !TR) {
-                if (last && a.res_mode) {                // geometry of this tile's epilogue (finish_tile computes the same values)
+                const bool res_tile = last && (CHAIN ? load_tile(ti).rm != 0 : a.res_mode != 0);
+                if (res_tile) {                          // geometry of this tile's epilogue (finish_tile computes the same values)
                     const TileP tc = load_tile(ti);
                     rpre_cl = tc.clg - ct * 32;
                     rpre_on = rpre_cl > 0 && tc.rb != nullptr && !(WINO_ABL & 256) && !(a.dbg & 64);
@@ -903,6 +1030,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const __amdgpu_buffer_rsrc_t wn = last ? wnext : wbase;
             chunk_body(c, buf, sc, wn, lc0);
             if (slot < 29) WNTRACE(slot);                // trace: body end | epilogue end | barrier passed, for the first 9 chunks
+            if constexpr (CHAIN) {
+                if (c == nch - 3 && wave == 0) {         // published by this chunk's barrier, read at the top of the next chunk
+                    const int st = tk_pend >= chain_total ? 0 : (chain_all(fv) ? 1 : 2);
+                    if (lane_c == 0) { chs[0] = tk_pend; chs[1] = st; }
+                }
+            }
             if (last) {
                 if constexpr (TR) bias_v = (has_next && bp_next && ct * 32 + l31 < clg_next) ? gload(bp_next + ct * 32 + l31) : 0.f;
                 else bias_v = (has_next && bp_next && lane < 32 && ct * 32 + lane < clg_next) ? gload(bp_next + ct * 32 + lane) : 0.f;
@@ -910,9 +1043,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 rpre_on = false;
                 if constexpr (TR) bias_lane = bias_scaled(bias_v); else { if (lane < 32) bias_w[lane] = bias_scaled(bias_v); }    // the next tile's bias,
                 init_acc();                              // into its accumulators
+                // CHAIN: the tile is published once every wave's stores have been acknowledged (a store is counted until it is written)
+                if constexpr (CHAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             if (slot < 29) WNTRACE(slot + 1);
             __syncthreads();
+            if constexpr (CHAIN) {
+                if (last && wave == 0) chain_publish(load_tile(ti).tk);
+            }
             buf ^= 1;
             if (slot < 29) { WNTRACE(slot + 2); slot += 3; }
         }
@@ -920,7 +1058,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         t = t_next; ++ti; wbase = wnext;
         // the table is a ring of 128 entries: when the first half of an epoch of 64 tiles begins, the entries of the epoch after next go
         // where the epoch before lay (every wave has passed the last barrier of tile ti - 1, the last reader of those)
-        if ((ti & 63) == 0 && wave == 0) fill_table(ti + 64);
+        if constexpr (!CHAIN) { if ((ti & 63) == 0 && wave == 0) fill_table(ti + 64); }
+    }
+    if constexpr (!CHAIN) break;
+    ++ti;                                                // CHAIN: the pending tile's entry (if any) becomes the current one
     }
     WNTRACE(31);
     WNTRACE_RT(29);
@@ -1047,15 +1188,76 @@ int motif_conv_wino_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     if (NP == 2 && tr) {
-        if (P > 1) conv_wino_kernel<2, true, true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
-        else conv_wino_kernel<2, false, true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+        if (P > 1) conv_wino_kernel<2, true, true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y, ChainArgs{});
+        else conv_wino_kernel<2, false, true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y, ChainArgs{});
     } else if (NP == 2) {
-        if (P > 1) conv_wino_kernel<2, true, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
-        else conv_wino_kernel<2, false, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+        if (P > 1) conv_wino_kernel<2, true, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y, ChainArgs{});
+        else conv_wino_kernel<2, false, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y, ChainArgs{});
     } else {
-        if (P > 1) conv_wino_kernel<3, true, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
-        else conv_wino_kernel<3, false, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+        if (P > 1) conv_wino_kernel<3, true, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y, ChainArgs{});
+        else conv_wino_kernel<3, false, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y, ChainArgs{});
     }
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}
+
+// ---- chain mode (motif_conv2d_chain_fwd) -----------------------------------------------------------------------------------------
+static_assert(sizeof(ChainLayerDev) == sizeof(MotifChainLayer) && sizeof(MotifChainLayer) == 32, "the device table is read as two 16-byte quads");
+
+static bool wino_chain_shape_ok(const MotifConvDesc* d, int L, long* tiles) {
+    if (!d || L < 1 || wino_parts(d->mma) != 2 || d->groups != 1 || d->C1 != 0 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->dil != 1) return false;
+    if (d->pad != 1 || d->pad_mode != 0 || (d->W & 3) || d->N < 1 || d->H < 1 || d->W < 1) return false;
+    if (d->C0 != d->Cout || d->Cout > 64 || d->C0 < 49) return false;          // one cout group; >= 4 chunks: the ticket and the flags are a chunk each ahead of the tile change
+    const long HW = (long)d->H * d->W;
+    if (HW * 64 * 4 >= 0x7fffffffL) return false;
+    const long T = (long)((d->W + 31) / 32) * ((d->H + 7) / 8) * d->N;
+    if (T * L >= (1L << 24)) return false;
+    if (tiles) *tiles = T;
+    return true;
+}
+
+extern "C" long motif_conv2d_chain_ws_words(const MotifConvDesc* d, int L) {
+    long T = 0;
+    if (!wino_chain_shape_ok(d, L, &T)) return 0;
+    return 64 + T * L;
+}
+
+extern "C" int motif_conv2d_chain_fwd(const MotifConvDesc* d, int L, const MotifChainLayer* layers, const float* x, float* out, float* work,
+                                      long work_floats, uint32_t* ws, void* stream) {
+    long T = 0;
+    if (!wino_chain_shape_ok(d, L, &T)) return MOTIF_ELIMIT;
+    if (!layers || !x || !out || !ws) return MOTIF_EINVAL;
+    const long HW = (long)d->H * d->W, plane = (long)d->Cout * HW;
+    const long bsx = d->in0_bs ? d->in0_bs : plane, bso = d->out_bs ? d->out_bs : plane;
+    if ((((unsigned long long)x | (unsigned long long)out | (unsigned long long)work | (unsigned long long)layers) & 15) || ((bsx | bso) & 3)) return MOTIF_EINVAL;
+    if (work_floats < 0 || (work_floats > 0 && !work)) return MOTIF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ConvArgs a = {};
+    a.in0[0] = x; a.out[0] = out; a.in0_bs[0] = bsx; a.out_bs[0] = bso;
+    a.N = d->N; a.C0 = d->C0; a.H = d->H; a.W = d->W; a.Ho = d->H; a.Wo = d->W; a.Cout = d->Cout;
+    a.Cin_g = d->C0; a.Cout_g = d->Cout;
+    a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1; a.dil = 1; a.pad_mode = 0;
+    a.Kpad = 12 * ((d->C0 + 15) / 16);
+    a.ncg = 1; a.CK = 1;
+    a.tiles_x = (d->W + 31) / 32;
+    a.dbg = motif_opt(MOTIF_OPT_CONV_DBG);
+    if (motif_opt(MOTIF_OPT_CONV_WINO_RPRE) == 1) a.dbg |= 64;
+    a.status = d->status;
+    ChainArgs ch = {};
+    ch.layers = (const ChainLayerDev*)layers;
+    ch.work = work; ch.buf_floats = (long)d->N * plane;
+    ch.ws = ws;
+    ch.wp_off = motif_conv_split_packed_floats_direct(d);               // the Winograd block follows the direct one in every layer's blob
+    ch.L = L;
+    const int tiles_y = (d->H + 7) / 8, cus = wn_cu_count();
+    const long total = T * L;
+    const int G = (int)(total < cus ? total : cus);
+    const size_t ldsb = ((size_t)4 * 16 + (size_t)2 * 2 * (2 * 16 * 34 + 4) + (size_t)4 * 640 + (size_t)128 * 4) * 16;      // as motif_conv_wino_launch, NP = 2
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<2, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(ws, 0, (size_t)(64 + total) * 4, s);
+    if (e != hipSuccess) return (int)e;
+    conv_wino_kernel<2, false, false, true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y, ch);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

@@ -211,6 +211,61 @@ def conv2d(plan, x, x2=None, act=ACT_NONE, res=None, res_mode=0, act2=ACT_NONE, 
     return out
 
 
+CONV_CHAIN = os.environ.get("MOTIF_CONV_CHAIN", "1") != "0"     # residual chains as ONE persistent launch where the shape allows it
+_chain_tables = {}
+
+
+def resblock_chain(blocks, x, out=None, act=ACT_RELU):
+    """x' = x + conv2(act(conv1(x))) over `blocks` = [(plan1, plan2), ...] (`module_util.py:34-52` in an nn.Sequential: the reconstruction
+    trunk and the feature extraction, `Ours.py:349-356`).  One persistent launch (`motif_conv2d_chain_fwd`: the tiles of all layers in
+    dependency order, conv_wino.hip CHAIN) where the shape and the arithmetic allow it -- the same bits as the launches layer by layer,
+    which is what runs otherwise.  x [N,C,H,W] planar; `out` may be a batch-strided view."""
+    lib = _lib.load()
+    if not _planar(x):
+        x = x.contiguous()
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.empty(n, c, h, w, dtype=torch.float32, device=x.device)
+    elif not _planar(out) or tuple(out.shape) != (n, c, h, w):
+        raise RuntimeError("resblock_chain: bad `out` view")
+    L = 2 * len(blocks)
+    d = blocks[0][0].desc(n, h, w, c)
+    ok = CONV_CHAIN and x.is_cuda and all(tuple(p.weight.shape) == (c, c, 3, 3) and p.stride == 1 and p.pad == 1 and p.dil == 1 and p.groups == 1 and
+                                          p.pad_mode == 0 and (p.mma is None or p.mma == d.mma) for blk in blocks for p in blk)
+    words = lib.motif_conv2d_chain_ws_words(ctypes.byref(d), L) if ok else 0
+    if words <= 0 or ((x.data_ptr() | out.data_ptr()) & 15) or ((x.stride(0) | out.stride(0)) & 3):
+        y = x
+        for i, (p1, p2) in enumerate(blocks):
+            y = conv2d(p2, conv2d(p1, y, act=act), res=y, res_mode=1, out=out if i == len(blocks) - 1 else None)
+        return y
+    packed = [p.packed() for blk in blocks for p in blk]
+    key = (tuple(t.data_ptr() for t in packed), tuple(p.bias.data_ptr() if p.bias is not None else 0 for blk in blocks for p in blk), act, x.device)
+    tab = _chain_tables.get(key)
+    if tab is None:
+        # MotifChainLayer[L]: packed, bias, src, dst, res, act | res_mode << 8.  Buffers: 0 = x, 1 = out, 2 = T, 3 / 4 = X (x_b lives in X[b % 2]):
+        # conv1 of block b reads x_b and writes T; conv2 reads T (+ x_b) and writes x_b+1 -- the rotation the header proves hazard-free
+        rows = []
+        nb = len(blocks)
+        for b, (p1, p2) in enumerate(blocks):
+            xb = 0 if b == 0 else 3 + (b % 2)
+            xn = 1 if b == nb - 1 else 3 + ((b + 1) % 2)
+            for p, src, dst, res, arm in ((p1, xb, 2, -1, act), (p2, 2, xn, xb, ACT_NONE | (1 << 8))):
+                bias = p.bias.detach().data_ptr() if p.bias is not None else 0
+                rows.append((p.packed().data_ptr(), bias, (src & 0xffffffff) | ((dst & 0xffffffff) << 32), (res & 0xffffffff) | ((arm & 0xffffffff) << 32)))
+        import numpy as np
+        tab = torch.from_numpy(np.array(rows, dtype=np.uint64).view(np.int64)).to(x.device)
+        if len(_chain_tables) > 64:
+            _chain_tables.clear()
+        _chain_tables[key] = tab
+        _packed_ready()
+    work = torch.empty(3 * n * c * h * w, dtype=torch.float32, device=x.device)           # T, X[0], X[1]
+    ws = torch.empty(words, dtype=torch.int32, device=x.device)
+    d.in0_bs, d.out_bs = x.stride(0), out.stride(0)
+    d.status = _status_ptr()
+    check(lib.motif_conv2d_chain_fwd(ctypes.byref(d), L, ctypes.c_void_p(tab.data_ptr()), _p(x), _p(out), _p(work), work.numel(), _p(ws), _stream()), "motif_conv2d_chain_fwd")
+    return out
+
+
 def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
 
