@@ -182,7 +182,14 @@ def instrumented_clip(model, sample):
         P, b, co, ho, wo = out.shape
         return "dcn", 2.0 * P * b * co * xs[0].shape[1] * 9 * ho * wo, None
 
+    def chain_sw(out, blocks, x, *a, **k):       # one launch = 2 * len(blocks) layers: N counts them all (like the problems of a multi launch)
+        p0 = blocks[0][0]
+        co, cig, kh, kw = p0.weight.shape
+        d = (2 * len(blocks) * x.shape[0], co, cig, 1, kh, kw, out.shape[2], out.shape[3])
+        return "conv3x3", conv_flops([d]), d
+
     hook("conv2d", conv_sw)
+    hook("conv2d_chain", chain_sw)
     hook("conv2d_multi", convm_sw)
     hook("dcn_v2_multi", dcn_sw)
     hook("siren_imnet", lambda out, *a, **k: ("imnet", 2.0 * IMNET_MAC * out.shape[0] * out.shape[2] * out.shape[3], None))

@@ -54,15 +54,28 @@ extern "C" int motif_debug_wino_trace(long long* host, int n) { return (int)hipM
 // per-super-step stamps of the first 8 chunks of a workgroup: [block][wave][chunk][7]
 __device__ long long g_wn_trace2[256 * 4 * 8 * 8];
 extern "C" int motif_debug_wino_trace2(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wn_trace2), sizeof(long long) * n); }
+// chain mode, wave 0, end of the first 8 tiles of a workgroup: [block][tile][8] stamps (see CHSTAMP)
+__device__ long long g_ch_trace[256 * 8 * 8];
+extern "C" int motif_debug_chain_trace(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ch_trace), sizeof(long long) * n); }
+#define CHSTAMP(i) do { if (CHAIN && wave == 0 && lane == 0 && blockIdx.x < 256 && ti < 8) g_ch_trace[(blockIdx.x * 8 + ti) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WNTRACE(slot)
 #define WNTRACE_RT(slot)
+#define CHSTAMP(i)
 #endif
 
 #ifndef WINO_ABL
 #define WINO_ABL 0        // ablation builds (tools/wino_ablate.sh): bit 0 no loads, 1 no parks, 2 no read-back, 3 no transform/split,
 #endif                    // 4 no staging stores, 5 no halo item, 6 no B fragments, 7 no weight fragments, 8 no epilogue pieces,
                           // 9 every second product only (the MFMA count of a 3-product split), 10 no MFMAs at all
+
+#ifndef CHAIN_DEFER
+#define CHAIN_DEFER 0     // 0: a tile is published at its own end, behind s_waitcnt vmcnt(0); 1: under chunk 1 of the next tile (see pub_pending:
+                          // measured SLOWER on the same box, 3.11 against 2.89 ms for the 40-block trunk)
+#endif
+#ifndef CHAIN_ABL
+#define CHAIN_ABL 0       // chain-mode ablation builds (timing only, results invalid): bit 0 no store wait before a tile is published, 1 plain
+#endif                    // (not device-coherent) activation loads / stores, 2 no flag polls (every tile counts as ready)
 
 namespace {
 // Products ordered by ACTIVATION part, smallest part first (w = weight part, x = activation part).
@@ -211,8 +224,8 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make
 // residuals are loaded and stored with sc1 (device-coherent), weights and biases (read-only) stay cached; tools/ubench_chain.hip is the
 // protocol on its own (exact over 80 layers x 690 tiles; the plain data path fails there).  No launch boundaries, ONE prologue per workgroup
 // instead of one per layer, and the round fill of a layer (690 tiles on 256 CUs: 0.90) becomes that of the whole chain (~1.0).
-template <int NP, bool MULTI, bool TR, bool CHAIN = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino_kernel(ConvArgs a, int ntiles, int tiles_y, ChainArgs ch) {
+template <int NP, bool MULTI, bool TR, bool CHAIN>
+__device__ __forceinline__ void conv_wino_body(const ConvArgs& a, const int ntiles, const int tiles_y, const ChainArgs& ch) {
     static_assert(!CHAIN || (NP == 2 && !MULTI && !TR), "chain mode: two-part row-major form, one problem");
     using WS = WSched<NP>;
     using WO = WOrder<NP>;
@@ -299,60 +312,93 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         return t;
     };
 
-    // ---- CHAIN mode: tickets, table entries, completion flags (wave 0 does all of it; the other waves learn the outcome from LDS behind a barrier)
+    // ---- CHAIN mode: tickets, table entries, completion counters.  Wave 0 does all of it with SCALAR instructions; the other waves learn the
+    // outcome from LDS behind a barrier.  Nothing here may touch the vector-memory queue: vmcnt retires in order, so a value loaded there is
+    // only readable once every row piece and weight fragment requested before it has returned -- the first version (vector atomic for the
+    // ticket, nine flag loads) stalled wave 0 for 2.9 k cycles per tile at its two consumption points.  s_atomic_add ... glc returns to an
+    // SGPR and is counted by lgkmcnt (tools/ubench_chain.hip: one counter for all 8 XCDs, coherent read-back by adding 0).  Issue and use
+    // are a chunk apart, so the result lands in a MAILBOX register the compiler never allocates: s100 / s101 (hipcc's allocatable range on
+    // gfx950 ends at s99; tests/test_isa_hygiene.py holds it to that -- a compiler-visible destination could be copied or spilled before the
+    // value has arrived).
+    // Completion is counted per (layer, image, tile row) in ONE word per row that also carries its two neighbours: a finished tile of row y
+    // adds 1 << 10 to word y, 1 to word y-1 and 1 << 20 to word y+1, so tile (l, n, y, x) may start when word y of (l-1, n) reads
+    // tiles_x in every field whose row exists -- one scalar read per poll.
     int* chs = (int*)((float*)lds_raw + 32);             // spare words of wave 0's bias area: [0] pending ticket, [1] its state (0 none left, 1 ready, 2 not ready yet, 3 aborted)
+    u32x4* ltab = ttab + TT * 4;                         // [L][4]: the layers resolved (see chain_entry)
     const int chain_total = CHAIN ? ch.L * ntiles : 0;   // < 2^24 (host)
-    int lane_c = lane;                                   // opaque copy: a lane test on it is never merged with another test of the lane index across a
-    asm volatile("" : "+v"(lane_c));                     // barrier (tools/ubench_chain.hip: hipcc threaded two `tid == 0` blocks round a loop and split wave 0 at the barriers)
-    auto chain_ticket_issue = [&]() __attribute__((always_inline)) {
-        unsigned v = 0;
-        if (lane_c == 0) v = __hip_atomic_fetch_add(ch.ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return v;
+    const unsigned long long ws64 = (unsigned long long)ch.ws;
+    // The lane index, recomputed where it is used (two v_mbcnt): OPAQUE, so a lane test is never merged with another test of the lane index
+    // across a barrier (tools/ubench_chain.hip: hipcc threaded two `tid == 0` blocks round a loop and split wave 0 at the barriers), and
+    // never a long-lived register -- a copy kept for the whole kernel was spilled, and its reload is a scratch load + s_waitcnt vmcnt(0):
+    // a wait for every store of the tile just finished (2 k cycles at each tile end, tools/trace_wino.py CHAIN=..)
+    auto lane_now = []() __attribute__((always_inline)) {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
     };
-    auto chain_entry = [&](int e, int tk) __attribute__((always_inline)) {      // tk uniform: scalar arithmetic, one lane writes
-        const int l = tk / ntiles, r = tk - l * ntiles;
-        const int tx = r % a.tiles_x, s2 = r / a.tiles_x, ty = s2 % tiles_y, n = s2 / tiles_y;
-        const u32x4* lp = (const u32x4*)(ch.layers + l);
-        const u32x4 q0 = gload(lp), q1 = gload(lp + 1);
-        auto sg = [](unsigned v) __attribute__((always_inline)) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
-        const unsigned long long packed = ((unsigned long long)sg(q0[1]) << 32) | sg(q0[0]), bp = ((unsigned long long)sg(q0[3]) << 32) | sg(q0[2]);
-        const int src = (int)sg(q1[0]), dst = (int)sg(q1[1]), res = (int)sg(q1[2]);
-        const long HWol = (long)a.Ho * a.Wo, plane = (long)a.Cout * HWol;
-        auto bufp = [&](int id) __attribute__((always_inline)) {
-            if (id == 0) return (unsigned long long)(a.in0[0] + (long)n * a.in0_bs[0]);
-            if (id == 1) return (unsigned long long)(a.out[0] + (long)n * a.out_bs[0]);
-            return (unsigned long long)(ch.work + (long)(id - 2) * ch.buf_floats + (long)n * plane);
-        };
-        const unsigned long long i0 = bufp(src), ob = bufp(dst), rb = res >= 0 ? bufp(res) : 0ull;
-        const unsigned long long wb = packed + (unsigned long long)ch.wp_off * 4ull;
-        if (lane_c == 0) {
-            u32x4* rr = ttab + (e & (TT - 1)) * 4;
-            rr[0] = u32x4{(unsigned)i0, (unsigned)(i0 >> 32), 0u, 0u};
-            rr[1] = u32x4{(unsigned)wb, (unsigned)(wb >> 32), (unsigned)ob, (unsigned)(ob >> 32)};
-            rr[2] = u32x4{(unsigned)rb, (unsigned)(rb >> 32), (unsigned)bp, (unsigned)(bp >> 32)};
-            rr[3] = u32x4{(unsigned)ty | ((unsigned)tx << 16), sg(q1[3]), (unsigned)a.Cout_g, (unsigned)tk};
-        }
+#define CHAIN_SADD(REG, BYTEOFF, VAL) asm volatile("s_mov_b32 " REG ", %2\n\ts_atomic_add " REG ", %0, %1 glc" :: "s"(ws64), "s"(BYTEOFF), "s"(VAL) : "memory", REG)
+#define CHAIN_STAKE(REG, OUT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, " REG : "=s"(OUT) :: "memory")
+#define CHAIN_SSET(REG, VAL) asm volatile("s_mov_b32 " REG ", %0" :: "s"(VAL) : REG)
+    auto chain_ticket_issue = [&]() __attribute__((always_inline)) { CHAIN_SADD("s100", 0, 1); };
+    auto chain_ticket_take = [&]() __attribute__((always_inline)) { int tk; CHAIN_STAKE("s100", tk); return tk; };
+    int pr_row = -1, pr_ty = 0;                          // of the tile last decoded: its own row word in the layer before (-1: layer 0), its tile row
+    int e_row = 0;                                       // ... its own row word (what it adds to when it is finished)
+    int dec_tk = -1, dec_l = 0, dec_r = 0;               // the last ticket decoded: tickets only grow, so (layer, tile) advance by the difference -- no division
+    // LDS tables built at kernel start: ltab[l] = the layer RESOLVED, 4 quads: {src base lo, hi, batch stride in bytes, act | res_mode << 8}
+    // {dst base, stride, 0} {res base (0: none), stride, 0} {weights lo, hi, bias lo, hi};  dtab[tile of a layer] = ty | tx << 10 | image << 20
+    const unsigned* dtab = (const unsigned*)(ltab + 4 * (CHAIN ? ch.L : 0));
+    // One table entry = five 8-byte fields and one quad, each formed by ITS OWN LANE (base + image * stride is one v_mad_u64_u32): a lone
+    // wave issues a dependent instruction every ~8 cycles, and the scalar form of this -- three 64-bit multiply-adds, the buffer selects,
+    // sixteen moves -- was a chain of 1.9 k cycles at the end of every tile (tools/trace_wino.py CHAIN=..).
+    auto chain_entry = [&](int e, int tk) __attribute__((always_inline)) {      // tk uniform
+        int l, r;
+        if (dec_tk < 0) { l = tk / ntiles; r = tk - l * ntiles; }
+        else { l = dec_l; r = dec_r + (tk - dec_tk); while (r >= ntiles) { r -= ntiles; ++l; } }
+        dec_tk = tk; dec_l = l; dec_r = r;
+        const int jl = lane_now();
+        const unsigned dwv = dtab[r];                     // the two LDS reads are independent: one round trip
+        const u32x4 q = ltab[4 * l + (jl < 3 ? jl : jl < 5 ? 3 : 0)];
+        const unsigned dw = (unsigned)__builtin_amdgcn_readfirstlane((int)dwv);
+        const int ty = (int)(dw & 1023u), tx = (int)((dw >> 10) & 1023u), n = (int)(dw >> 20);
+        e_row = (l * a.N + n) * tiles_y + ty;
+        pr_row = l > 0 ? e_row - a.N * tiles_y : -1;
+        pr_ty = ty;
+        const unsigned long long base = ((unsigned long long)q[1] << 32) | q[0];
+        unsigned long long v64 = base + (unsigned long long)(unsigned)n * (unsigned long long)q[2];
+        if (jl == 2 && base == 0ull) v64 = 0ull;
+        if (jl == 3) v64 = base;
+        if (jl == 4) v64 = ((unsigned long long)q[3] << 32) | q[2];
+        if (jl == 6) v64 = 0ull;                          // (no second source in a chain)
+        char* ent = (char*)(ttab + (e & (TT - 1)) * 4);
+        const int wr = jl == 0 ? 0 : jl == 1 ? 24 : jl == 2 ? 32 : jl == 3 ? 16 : jl == 4 ? 40 : 8;
+        if (jl < 5 || jl == 6) *(unsigned long long*)(ent + wr) = v64;
+        if (jl == 5) ((u32x4*)ent)[3] = u32x4{(unsigned)ty | ((unsigned)tx << 16), q[3], (unsigned)a.Cout_g, (unsigned)e_row};      // [3]: the tile's own completion word
     };
-    // lane i < 9 = producer (dy, dx) of tile tk in the layer before: its flag, 1 where there is none
-    auto chain_flags = [&](int tk) __attribute__((always_inline)) {
-        const int l = tk / ntiles, r = tk - l * ntiles;
-        const int tx = r % a.tiles_x, ty = (r / a.tiles_x) % tiles_y;
-        const int dy = lane_c / 3 - 1, dx = lane_c - 3 * (lane_c / 3) - 1;
-        const bool has = l > 0 && lane_c < 9 && (unsigned)(ty + dy) < (unsigned)tiles_y && (unsigned)(tx + dx) < (unsigned)a.tiles_x;
-        unsigned f = 1u;
-        if (has) f = __hip_atomic_load(ch.ws + 64 + (long)(l - 1) * ntiles + r + dy * a.tiles_x + dx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return f;
+    // the pending tile's row word of the layer before -> mailbox s101 (layer 0: the expected value at once)
+    auto chain_rows_want = [&]() __attribute__((always_inline)) {
+        return (pr_ty + 1 < tiles_y ? a.tiles_x : 0) | (a.tiles_x << 10) | (pr_ty > 0 ? a.tiles_x << 20 : 0);
     };
-    auto chain_all = [](unsigned f) __attribute__((always_inline)) { return __builtin_amdgcn_ballot_w64(f != 0u) == ~0ull; };
+    auto chain_rows_issue = [&]() __attribute__((always_inline)) {
+        if (pr_row >= 0) CHAIN_SADD("s101", (64 + pr_row) * 4, 0); else CHAIN_SSET("s101", chain_rows_want());
+    };
+    auto chain_rows_take = [&]() __attribute__((always_inline)) {
+        int c1;
+        CHAIN_STAKE("s101", c1);
+        return c1 == chain_rows_want();
+    };
     // between tiles only (nothing of this workgroup in flight, so waiting here can block nobody this workgroup could unblock); bounded: a chain
     // that does not advance for a second sets the abort word and status bit 1 instead of hanging the device
-    auto chain_wait = [&](int tk) __attribute__((always_inline)) {
+    auto chain_wait = [&]() __attribute__((always_inline)) {
         const long long t0 = __builtin_amdgcn_s_memrealtime();              // 100 MHz
         for (;;) {
-            if (chain_all(chain_flags(tk))) return true;
-            if (__hip_atomic_load(ch.ws + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+            chain_rows_issue();
+            if (chain_rows_take()) return true;
+            int ab;
+            CHAIN_SADD("s101", 4, 0);                    // (s100 may hold a ticket in flight)
+            CHAIN_STAKE("s101", ab);
+            if (ab) return false;
             if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ll) {
-                if (lane_c == 0) {
+                if (lane_now() == 0) {
                     __hip_atomic_store(ch.ws + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (a.status) atomicOr(a.status, 2u);
                 }
@@ -361,14 +407,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_s_sleep(4);
         }
     };
-    auto chain_publish = [&](int tk) __attribute__((always_inline)) {
-        if (lane_c == 0) __hip_atomic_store(ch.ws + 64 + tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int cur_row = 0, cur_ty = 0, pend_row = 0, pend_ty = 0, fut_row = 0, fut_ty = 0;     // completion word / tile row of the current tile, the next, the one after
+    auto chain_publish = [&](int row, int ty) __attribute__((always_inline)) {      // lanes 0 .. 2: words row - 1, row, row + 1 (one atomic instruction)
+        const int lc = lane_now();
+        const bool on = lc < 3 && (lc != 0 || ty > 0) && (lc != 2 || ty + 1 < tiles_y);
+        if (on) __hip_atomic_fetch_add(ch.ws + 64 + row + lc - 1, lc == 0 ? 1u : lc == 1 ? 1u << 10 : 1u << 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // activations / residuals of a chain come from other XCDs inside this launch: device-coherent (sc1) accesses
     auto rload = [&](const float* base, unsigned off_elems) __attribute__((always_inline)) {
         if constexpr (CHAIN) {
             const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
-            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(off_elems * 4u), 0, 16));
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(off_elems * 4u), 0, (CHAIN_ABL & 2) ? 0 : 16));
         } else return gload((const f32x4*)(base + off_elems));
     };
 
@@ -448,7 +497,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nchv * HW * 4, 0x00020000);
         // BYTE offset from the chunk's first plane; 2^31 = "outside the image": beyond any descriptor's range, the load returns 0
         const int off = POFF ? po[POFF ? i : 0] : ((vmask >> i) & 1u ? pl[i] + origin : (int)0x80000000);
-        gq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, CHAIN ? 16 : 0));
+        gq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, (CHAIN && !(CHAIN_ABL & 2)) ? 16 : 0));
     };
     auto st_park = [&](int i) __attribute__((always_inline)) { *(f32x4*)(land + i * 64 + lane) = gq[i]; };
     float sv[4][8] = {};                                   // [input row of the pair][channel of the octet]
@@ -650,7 +699,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // instead of 96 v_accvgpr_write (one issue slot each, beside the epilogue's vector work), the bias by 32 moves instead of 64
     // additions in the epilogue.  The wave's bias lies in LDS (bias_w, written by its lanes 0..31 just before: same wave, in order).
     float bias_lane = 0.f;                               // TR: this lane's (cout's) bias of the tile about to start, already scaled
-    auto init_acc = [&]() __attribute__((always_inline)) {
+    auto init_bias = [&]() __attribute__((always_inline)) {
         f32x16 bvec;
         if constexpr (TR) {
 #pragma unroll
@@ -663,6 +712,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int u = 0; u < 4; ++u) bvec[4 * q + u] = b4[u];
             }
         }
+        return bvec;
+    };
+    auto init_acc_from = [&](const f32x16& bvec) __attribute__((always_inline)) {
         // zq: a register quad of zeros written once at kernel start (opaque to the compiler: it cannot re-materialise it right in front
         // of an instruction whose operand hazards it does not know); s_nop: wait states of a just-written operand, whatever wrote it
 #pragma unroll
@@ -674,6 +726,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[tl][p]) : "v"(zq));
             }
     };
+    auto init_acc = [&]() __attribute__((always_inline)) { init_acc_from(init_bias()); };
     // After a tile's last chunk: inverse transform + bias in the C/D layout, then four passes of 8 couts x 4 rows x 32 pixels through
     // the landing area (free between the last read-back and the next chunk's parks): lane item it of a pass = cout half + 2 it, row
     // l31 / 8, columns 4 (l31 % 8) .. + 3 -- residual, activation, one 16-byte store.
@@ -884,7 +937,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     const f32x4 val = v[it];
                     // s_nop: the wait state between a store of more than 8 bytes and the next vector write of its data registers -- hipcc
                     // inserts it for its own stores, not around inline assembly
-                    if constexpr (CHAIN) {
+                    if constexpr (CHAIN && !(CHAIN_ABL & 2)) {
                         if (full) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(bo), "v"(val), "s"(obq) : "memory");
                         else if (okv(pass, it)) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(bo), "v"(val), "s"(obq) : "memory");
                     } else {
@@ -918,9 +971,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- prologue: step 0 staged in full, the row pieces of step 1 requested (nothing to hide them under) --------------------
     int t = bq;
-    unsigned tkv = 0, fv = 1u;                           // CHAIN: the ticket requested during chunk nch - 4 (read a chunk later), the flags polled under chunk nch - 3
-    int tk_pend = 0;
+    // CHAIN: the scalar atomics are ISSUED only where a tile ends (behind init_acc, in front of the store wait and the barrier): an
+    // outstanding scalar request holds every `s_waitcnt lgkmcnt` of the LDS traffic -- the B fragments of a chunk body -- until it has
+    // returned (~700 cycles; issued inside a chunk they cost wave 0, and through the barrier the workgroup, 0.8 + 2.4 k cycles per tile).
+    // At the end of tile i: the ticket requested one tile earlier is taken (tile i + 2), its table entry written, its row word requested,
+    // the next ticket requested; under chunk 1 of tile i + 1 the row word is taken: the state of tile i + 2, used from chunk nch - 2 on.
+    // A finished tile is published at its own end, once every wave has waited for its stores (s_waitcnt vmcnt(0): the acknowledgements take
+    // 2-3 k cycles from the last store, partly under init_acc and the bookkeeping above).  CHAIN_DEFER = 1 is the alternative that was built and
+    // measured: publish under chunk 1 of the NEXT tile without any explicit wait -- vmcnt retires loads and stores in one order on gfx950
+    // (tools/ubench_chain.hip: [store sc1; load; s_waitcnt vmcnt(1)] takes the store's latency), and every wave parks, in chunk 1, row pieces
+    // it requested in chunk 0, i.e. behind the last store of the tile before.  Exact too, and slower: the acknowledgements then hold up the
+    // in-order queue of the next tile's first chunk.
+    bool tick_inflight = false, rows_inflight = false, pub_pending = false;
+    int pub_row = 0, pub_ty = 0;
     bool first_run = true;
+    if constexpr (CHAIN) {
+        const long plane_b = (long)a.Cout * a.Ho * a.Wo * 4;
+        for (int l = tid; l < ch.L; l += 256) {
+            const u32x4 q0 = gload((const u32x4*)ch.layers + 2 * l), q1 = gload((const u32x4*)ch.layers + 2 * l + 1);
+            auto bufq = [&](int id) __attribute__((always_inline)) {      // buffer id -> {base lo, hi, batch stride in bytes (< 2^32: host), 0}
+                const unsigned long long b = id < 0 ? 0ull : id == 0 ? (unsigned long long)a.in0[0] : id == 1 ? (unsigned long long)a.out[0]
+                                                   : (unsigned long long)(ch.work + (long)(id - 2) * ch.buf_floats);
+                const long bs = id == 0 ? a.in0_bs[0] * 4 : id == 1 ? a.out_bs[0] * 4 : plane_b;
+                return u32x4{(unsigned)b, (unsigned)(b >> 32), (unsigned)bs, 0u};
+            };
+            u32x4 s0 = bufq((int)q1[0]);
+            s0[3] = q1[3];
+            const unsigned long long wb = (((unsigned long long)q0[1] << 32) | q0[0]) + (unsigned long long)ch.wp_off * 4ull;
+            ltab[4 * l] = s0;
+            ltab[4 * l + 1] = bufq((int)q1[1]);
+            ltab[4 * l + 2] = bufq((int)q1[2]);
+            ltab[4 * l + 3] = u32x4{(unsigned)wb, (unsigned)(wb >> 32), q0[2], q0[3]};
+        }
+        for (int r = tid; r < ntiles; r += 256) {
+            const int tx = r % a.tiles_x, s2 = r / a.tiles_x;
+            ((unsigned*)(ltab + 4 * ch.L))[r] = (unsigned)(s2 % tiles_y) | ((unsigned)tx << 10) | ((unsigned)(s2 / tiles_y) << 20);
+        }
+        __syncthreads();
+    }
     // CHAIN: one iteration per RUN = prologue + tiles that follow each other through the step pipeline.  A run ends when the tickets are used
     // up or when the next tile's producers had not all finished at the time it was polled; the workgroup then finishes its tile, waits with
     // nothing in flight, and starts the next run.  Otherwise: one iteration.
@@ -932,18 +1020,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     pst[0] = __builtin_amdgcn_s_memtime();
 #endif
     if constexpr (CHAIN) {
-        if (wave == 0) {
-            int tk, st;
+        if (wave == 0) {                                 // a safe point: nothing of this workgroup in flight, blocking is allowed
+            int st_cur = 1;
             if (first_run) {
-                tk = __builtin_amdgcn_readfirstlane((int)chain_ticket_issue());
-                st = tk < chain_total ? 2 : 0;
-                if (st) chain_entry(ti, tk);
-            } else { tk = __builtin_amdgcn_readfirstlane(chs[0]); st = __builtin_amdgcn_readfirstlane(chs[1]); }
-            if (st == 2) st = chain_wait(tk) ? 1 : 3;
-            if (lane_c == 0) { chs[0] = tk; chs[1] = st; }
+                chain_ticket_issue();
+                const int tk0 = chain_ticket_take();
+                if (tk0 < chain_total) { chain_entry(ti, tk0); chain_ticket_issue(); tick_inflight = true; } else st_cur = 0;
+            } else if (__builtin_amdgcn_readfirstlane(chs[1]) != 2) st_cur = 0;         // 2: the tile the last run polled too early (its entry is slot ti now)
+            if (st_cur) {
+                const TileP tc = load_tile(ti);
+                cur_row = tc.tk; cur_ty = tc.ty;           // .tk = the tile's own row word; its producers' = one layer back
+                pr_row = tc.tk >= a.N * tiles_y ? tc.tk - a.N * tiles_y : -1;
+                pr_ty = tc.ty;
+                if (!chain_wait()) st_cur = 3;
+            }
+            int stp = 0;
+            if (st_cur == 1 && tick_inflight) {          // the tile after it: entry, one poll
+                const int tkp = chain_ticket_take();
+                tick_inflight = false;
+                if (tkp < chain_total) {
+                    chain_entry(ti + 1, tkp);
+                    pend_row = e_row; pend_ty = pr_ty;
+                    chain_rows_issue();
+                    stp = chain_rows_take() ? 1 : 2;
+                    chain_ticket_issue();
+                    tick_inflight = true;
+                }
+            }
+            rows_inflight = false;
+            if (lane_now() == 0) { chs[0] = st_cur; chs[1] = stp; }
         }
         __syncthreads();
-        if (__builtin_amdgcn_readfirstlane(chs[1]) != 1) return;
+        if (__builtin_amdgcn_readfirstlane(chs[0]) != 1) return;
         first_run = false;
     } else {
         if (wave == 0) {
@@ -996,12 +1104,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if constexpr (!CHAIN) has_next = t_next < ntiles;
         for (int c = 0; c < nch; ++c) {
             if constexpr (CHAIN) {
-                if (wave == 0) {
-                    if (c == nch - 4) tkv = chain_ticket_issue();
-                    if (c == nch - 3) {                  // the ticket has had a chunk to return: the next tile's table entry, its producers' flags requested
-                        tk_pend = __builtin_amdgcn_readfirstlane((int)tkv);
-                        if (tk_pend < chain_total) { chain_entry(ti + 1, tk_pend); fv = chain_flags(tk_pend); }
-                    }
+                if (wave == 0 && c == 1 && rows_inflight) {         // requested at the end of the tile before: the state of the tile after this one
+                    const int st = (chain_rows_take() || (CHAIN_ABL & 4)) ? 1 : 2;
+                    rows_inflight = false;
+                    if (lane_now() == 0) chs[1] = st;
                 }
                 if (c == nch - 2) has_next = __builtin_amdgcn_readfirstlane(chs[1]) == 1;
             }
@@ -1030,32 +1136,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const __amdgpu_buffer_rsrc_t wn = last ? wnext : wbase;
             chunk_body(c, buf, sc, wn, lc0);
             if (slot < 29) WNTRACE(slot);                // trace: body end | epilogue end | barrier passed, for the first 9 chunks
-            if constexpr (CHAIN) {
-                if (c == nch - 3 && wave == 0) {         // published by this chunk's barrier, read at the top of the next chunk
-                    const int st = tk_pend >= chain_total ? 0 : (chain_all(fv) ? 1 : 2);
-                    if (lane_c == 0) { chs[0] = tk_pend; chs[1] = st; }
-                }
-            }
             if (last) {
                 if constexpr (TR) bias_v = (has_next && bp_next && ct * 32 + l31 < clg_next) ? gload(bp_next + ct * 32 + l31) : 0.f;
                 else bias_v = (has_next && bp_next && lane < 32 && ct * 32 + lane < clg_next) ? gload(bp_next + ct * 32 + lane) : 0.f;
                 finish_tile(load_tile(ti));
                 rpre_on = false;
                 if constexpr (TR) bias_lane = bias_scaled(bias_v); else { if (lane < 32) bias_w[lane] = bias_scaled(bias_v); }    // the next tile's bias,
-                init_acc();                              // into its accumulators
+                CHSTAMP(0);
+                const f32x16 bvec = init_bias();         // into its accumulators (below: CHAIN requests its scalar atomics in between, behind the last LDS read)
+                CHSTAMP(1);
+                if constexpr (CHAIN) {
+                    if (wave == 0 && has_next) {         // (a run that ends here leaves the ticket in flight: the next run takes it)
+                        bool none = true;
+                        if (tick_inflight) {
+                            const int tkn = chain_ticket_take();
+                            CHSTAMP(2);
+                            tick_inflight = false;
+                            if (tkn < chain_total) {
+                                chain_entry(ti + 2, tkn);
+                                fut_row = e_row; fut_ty = pr_ty;
+                                CHSTAMP(3);
+                                chain_rows_issue();
+                                rows_inflight = true;
+                                chain_ticket_issue();
+                                tick_inflight = true;
+                                none = false;
+                            }
+                        }
+                        if (none && lane_now() == 0) chs[1] = 0;            // the tickets are used up: the tile about to start is this workgroup's last
+                    }
+                }
+                init_acc_from(bvec);
                 // CHAIN: the tile is published once every wave's stores have been acknowledged (a store is counted until it is written)
-                if constexpr (CHAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                CHSTAMP(4);
+                if constexpr (CHAIN && !(CHAIN_ABL & 1)) { if (!has_next || !CHAIN_DEFER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                CHSTAMP(5);
             }
             if (slot < 29) WNTRACE(slot + 1);
             __syncthreads();
             if constexpr (CHAIN) {
-                if (last && wave == 0) chain_publish(load_tile(ti).tk);
+                if (last) CHSTAMP(6);
+                if (last) {
+                    if (has_next && CHAIN_DEFER) { pub_pending = true; pub_row = cur_row; pub_ty = cur_ty; }
+                    else if (wave == 0) chain_publish(cur_row, cur_ty);   // (from scalar registers: an LDS read here would wait for the scalar atomics just requested)
+                }
+                if (c == 1 && pub_pending) {             // the tile before: see pub_pending
+                    if (wave == 0) chain_publish(pub_row, pub_ty);
+                    pub_pending = false;
+                }
+                if (last) CHSTAMP(7);
             }
             buf ^= 1;
             if (slot < 29) { WNTRACE(slot + 2); slot += 3; }
         }
         if (!has_next) break;
         t = t_next; ++ti; wbase = wnext;
+        if constexpr (CHAIN) { cur_row = pend_row; cur_ty = pend_ty; pend_row = fut_row; pend_ty = fut_ty; }
         // the table is a ring of 128 entries: when the first half of an epoch of 64 tiles begins, the entries of the epoch after next go
         // where the epoch before lay (every wave has passed the last barrier of tile ti - 1, the last reader of those)
         if constexpr (!CHAIN) { if ((ti & 63) == 0 && wave == 0) fill_table(ti + 64); }
@@ -1065,6 +1201,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     WNTRACE(31);
     WNTRACE_RT(29);
+#undef CHAIN_SADD
+#undef CHAIN_STAKE
+#undef CHAIN_SSET
+}
+
+template <int NP, bool MULTI, bool TR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino_kernel(ConvArgs a, int ntiles, int tiles_y) {
+    conv_wino_body<NP, MULTI, TR, false>(a, ntiles, tiles_y, ChainArgs{});
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino_chain_kernel(ConvArgs a, int ntiles, int tiles_y, ChainArgs ch) {
+    conv_wino_body<2, false, false, true>(a, ntiles, tiles_y, ch);
 }
 
 // weight [Cout, Cin_g, 3, 3] fp32 -> A fragments [group][cout group of 64][k-step][part][cout tile][lane][8] bf16 (NP = 3) / fp16 of 2^8 x (NP = 2),
@@ -1188,14 +1335,14 @@ int motif_conv_wino_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     if (NP == 2 && tr) {
-        if (P > 1) conv_wino_kernel<2, true, true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y, ChainArgs{});
-        else conv_wino_kernel<2, false, true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y, ChainArgs{});
+        if (P > 1) conv_wino_kernel<2, true, true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+        else conv_wino_kernel<2, false, true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
     } else if (NP == 2) {
-        if (P > 1) conv_wino_kernel<2, true, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y, ChainArgs{});
-        else conv_wino_kernel<2, false, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y, ChainArgs{});
+        if (P > 1) conv_wino_kernel<2, true, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+        else conv_wino_kernel<2, false, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
     } else {
-        if (P > 1) conv_wino_kernel<3, true, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y, ChainArgs{});
-        else conv_wino_kernel<3, false, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y, ChainArgs{});
+        if (P > 1) conv_wino_kernel<3, true, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
+        else conv_wino_kernel<3, false, false><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y);
     }
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
@@ -1211,7 +1358,8 @@ static bool wino_chain_shape_ok(const MotifConvDesc* d, int L, long* tiles) {
     const long HW = (long)d->H * d->W;
     if (HW * 64 * 4 >= 0x7fffffffL) return false;
     const long T = (long)((d->W + 31) / 32) * ((d->H + 7) / 8) * d->N;
-    if (T * L >= (1L << 24)) return false;
+    if (T * L >= (1L << 24) || L > 256 || T > 6144) return false;      // the layer table (<= 16 KB) and the tile decode table (<= 24 KB) live in LDS
+    if (d->N >= 4096 || (d->W + 31) / 32 >= 1024 || (d->H + 7) / 8 >= 1024) return false;
     if (tiles) *tiles = T;
     return true;
 }
@@ -1219,7 +1367,7 @@ static bool wino_chain_shape_ok(const MotifConvDesc* d, int L, long* tiles) {
 extern "C" long motif_conv2d_chain_ws_words(const MotifConvDesc* d, int L) {
     long T = 0;
     if (!wino_chain_shape_ok(d, L, &T)) return 0;
-    return 64 + T * L;
+    return 64 + (long)L * d->N * ((d->H + 7) / 8);       // ticket, abort word, one completion counter per (layer, image, tile row)
 }
 
 extern "C" int motif_conv2d_chain_fwd(const MotifConvDesc* d, int L, const MotifChainLayer* layers, const float* x, float* out, float* work,
@@ -1230,6 +1378,7 @@ extern "C" int motif_conv2d_chain_fwd(const MotifConvDesc* d, int L, const Motif
     const long HW = (long)d->H * d->W, plane = (long)d->Cout * HW;
     const long bsx = d->in0_bs ? d->in0_bs : plane, bso = d->out_bs ? d->out_bs : plane;
     if ((((unsigned long long)x | (unsigned long long)out | (unsigned long long)work | (unsigned long long)layers) & 15) || ((bsx | bso) & 3)) return MOTIF_EINVAL;
+    if (bsx < 0 || bso < 0 || bsx * 4 >= (1L << 32) || bso * 4 >= (1L << 32) || (long)d->N * plane * 4 >= (1L << 40)) return MOTIF_ELIMIT;      // batch strides in bytes are 32-bit table fields
     if (work_floats < 0 || (work_floats > 0 && !work)) return MOTIF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ConvArgs a = {};
@@ -1253,11 +1402,12 @@ extern "C" int motif_conv2d_chain_fwd(const MotifConvDesc* d, int L, const Motif
     const long total = T * L;
     const int G = (int)(total < cus ? total : cus);
     const size_t ldsb = ((size_t)4 * 16 + (size_t)2 * 2 * (2 * 16 * 34 + 4) + (size_t)4 * 640 + (size_t)128 * 4) * 16;      // as motif_conv_wino_launch, NP = 2
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<2, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const size_t ldsc = ldsb + (size_t)L * 64 + (size_t)T * 4;          // + the resolved layer table and the tile decode table
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(ws, 0, (size_t)(64 + total) * 4, s);
+    e = hipMemsetAsync(ws, 0, (size_t)(64 + (long)L * d->N * tiles_y) * 4, s);
     if (e != hipSuccess) return (int)e;
-    conv_wino_kernel<2, false, false, true><<<dim3(G, 1, 1), 256, ldsb, s>>>(a, (int)T, tiles_y, ch);
+    conv_wino_chain_kernel<<<dim3(G, 1, 1), 256, ldsc, s>>>(a, (int)T, tiles_y, ch);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

@@ -216,6 +216,12 @@ class ResidualBlock_noBN(nn.Module):
         return self.conv2(self.conv1(x, act=RELU), res=x, res_mode=1, out=out)
 
 
+def run_resblocks(blocks, x, out=None):
+    """nn.Sequential of ResidualBlock_noBN (`Ours.py:349-356`): x -> x + conv2(relu(conv1(x))) block after block, as ONE launch where the
+    shape allows it (same bits as block by block: `ops.resblock_chain`)."""
+    return ops.resblock_chain([(rb.conv1.plan(), rb.conv2.plan()) for rb in blocks], x, out=out, act=RELU)
+
+
 class ZSM_encoder(nn.Module):
     def __init__(self, channel):
         super().__init__()
@@ -239,10 +245,7 @@ class ZSM_encoder(nn.Module):
         # the L1 features ARE the even entries of the sequence (Ours.py:383-391 copies them there): with one clip per call the last
         # residual block stores them in place (seq[0, 0::2] = N planar maps, batch stride of two); B > 1 keeps the copies
         in_place = B == 1
-        blocks = list(self.feature_extraction)
-        for rb in blocks[:-1]:
-            l1 = rb(l1)
-        l1 = blocks[-1](l1, out=seq[0, 0::2] if in_place else None)
+        l1 = run_resblocks(self.feature_extraction, l1, out=seq[0, 0::2] if in_place else None)
         l2 = self.fea_L2_conv2(self.fea_L2_conv1(l1, act=LRELU), act=LRELU)
         l3 = self.fea_L3_conv2(self.fea_L3_conv1(l2, act=LRELU), act=LRELU)
         l1 = seq[:, 0::2] if in_place else l1.view(B, N, *l1.shape[1:])
@@ -258,8 +261,7 @@ class ZSM_encoder(nn.Module):
                 seq[:, 2 * i + 2].copy_(fea2[0])
         feats = self.ConvBLSTM(seq)
         out = feats.view(B * T, -1, H, W)
-        for rb in self.recon_trunk:
-            out = rb(out)
+        out = run_resblocks(self.recon_trunk, out)          # 40 blocks = 80 convolutions: one persistent launch (ops.resblock_chain)
         return out.view(B, T, 64, H, W)
 
 

@@ -212,6 +212,7 @@ def conv2d(plan, x, x2=None, act=ACT_NONE, res=None, res_mode=0, act2=ACT_NONE, 
 
 
 CONV_CHAIN = os.environ.get("MOTIF_CONV_CHAIN", "1") != "0"     # residual chains as ONE persistent launch where the shape allows it
+CONV_CHAIN_MIN_TILES = int(os.environ.get("MOTIF_CONV_CHAIN_MIN_TILES", "256"))
 _chain_tables = {}
 
 
@@ -232,12 +233,22 @@ def resblock_chain(blocks, x, out=None, act=ACT_RELU):
     d = blocks[0][0].desc(n, h, w, c)
     ok = CONV_CHAIN and x.is_cuda and all(tuple(p.weight.shape) == (c, c, 3, 3) and p.stride == 1 and p.pad == 1 and p.dil == 1 and p.groups == 1 and
                                           p.pad_mode == 0 and (p.mma is None or p.mma == d.mma) for blk in blocks for p in blk)
+    # below one tile per CU and layer the chain is bound by its dependency latency (a tile time per layer, like the launches) and gains nothing
+    ok = ok and n * ((h + 7) // 8) * ((w + 31) // 32) >= CONV_CHAIN_MIN_TILES
     words = lib.motif_conv2d_chain_ws_words(ctypes.byref(d), L) if ok else 0
     if words <= 0 or ((x.data_ptr() | out.data_ptr()) & 15) or ((x.stride(0) | out.stride(0)) & 3):
         y = x
         for i, (p1, p2) in enumerate(blocks):
             y = conv2d(p2, conv2d(p1, y, act=act), res=y, res_mode=1, out=out if i == len(blocks) - 1 else None)
         return y
+    return conv2d_chain(blocks, x, out, act, d, words)
+
+
+def conv2d_chain(blocks, x, out, act, d, words):
+    """The launch of `resblock_chain` (`motif_conv2d_chain_fwd`); eligibility was checked there."""
+    lib = _lib.load()
+    n, c, h, w = x.shape
+    L = 2 * len(blocks)
     packed = [p.packed() for blk in blocks for p in blk]
     key = (tuple(t.data_ptr() for t in packed), tuple(p.bias.data_ptr() if p.bias is not None else 0 for blk in blocks for p in blk), act, x.device)
     tab = _chain_tables.get(key)

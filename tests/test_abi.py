@@ -70,3 +70,25 @@ def test_graft_entry_build_checks_the_library_it_built():
     its ABI version and exports against the binding -- it once asserted a stale version number and failed for a whole round unnoticed."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_chain_entry_takes_the_trunk_shapes_and_refuses_the_others(lib):
+    """`motif_conv2d_chain_ws_words` is host logic (no GPU): > 0 = the shape runs as one persistent launch, 0 = call the layers one by one."""
+    import ctypes
+    from motif_amd import _lib
+
+    def words(n, c, h, w, L, mma=7, **kw):
+        d = _lib.MotifConvDesc()
+        d.N, d.H, d.W, d.C0, d.C1, d.Cout, d.KH, d.KW = n, h, w, c, 0, c, 3, 3
+        d.stride, d.pad, d.dil, d.groups, d.pad_mode, d.mma = 1, 1, 1, 1, 0, mma
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return lib.motif_conv2d_chain_ws_words(ctypes.byref(d), L)
+    assert words(3, 64, 180, 320, 80) == 64 + 80 * 3 * 23          # ticket + abort + one word per (layer, image, tile row)
+    assert words(2, 64, 180, 320, 10) == 64 + 10 * 2 * 23
+    assert words(3, 64, 180, 320, 80, mma=6) == 0                   # two-part fp16 form only
+    assert words(3, 128, 180, 320, 80) == 0 and words(3, 32, 180, 320, 80) == 0      # 49 .. 64 channels
+    assert words(3, 64, 180, 322, 80) == 0                          # W % 4
+    assert words(3, 64, 180, 320, 80, stride=2) == 0 and words(3, 64, 180, 320, 80, groups=2) == 0 and words(3, 64, 180, 320, 80, pad_mode=1) == 0
+    assert words(3, 64, 180, 320, 300) == 0                         # the layer table lives in LDS
+    assert words(16, 64, 540, 960, 80) == 0                         # so does the tile decode table

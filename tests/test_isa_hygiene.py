@@ -36,6 +36,8 @@ def wino_isa(tmp_path_factory):
         blk = text[max(0, m.start() - 1500):m.end() + 1500]
         sp = re.search(r"\.vgpr_spill_count:\s+(\d+)", blk)
         meta[(int(m.group(2)), bool(int(m.group(3))), bool(int(m.group(4))))] = int(sp.group(1)) if sp else None
+    m = re.search(r"^_Z22conv_wino_chain_kernel8ConvArgsii9ChainArgs:", text, re.M)
+    kernels["chain"] = text[m.end():text.index(".Lfunc_end", m.end())].splitlines()
     return kernels, meta
 
 
@@ -49,15 +51,15 @@ def _instr(lines):
 def test_conv_wino_kernels_exist_without_flat_loads_and_without_spills_in_the_shipped_form(wino_isa):
     kernels, meta = wino_isa
     # (parts, multi-problem, transposed accumulators): the two-part form in both accumulator layouts, the three-part form row-major
-    assert set(kernels) == {(2, False, False), (2, True, False), (2, False, True), (2, True, True), (3, False, False), (3, True, False)}
+    assert set(kernels) == {(2, False, False), (2, True, False), (2, False, True), (2, True, True), (3, False, False), (3, True, False), "chain"}
     for key, lines in kernels.items():
         ops = [t.split()[0] for t in _instr(lines)]
-        assert not [o for o in ops if o.startswith("flat_")], "conv_wino_kernel<%d, %s, %s> has FLAT memory instructions" % key
+        assert not [o for o in ops if o.startswith("flat_")], "conv_wino_kernel %s has FLAT memory instructions" % (key,)
     for multi in (False, True):
         for tr in (False, True):
             assert meta[(2, multi, tr)] == 0, "the two-part kernel must not spill vector registers (%s)" % meta
     # the transposed form's epilogue stays out of LDS: no more LDS instructions than the row-major form's chunk body + staging alone
-    lds = {key: sum(1 for t in _instr(lines) if t.startswith("ds_")) for key, lines in kernels.items()}
+    lds = {key: sum(1 for t in _instr(lines) if t.startswith("ds_")) for key, lines in kernels.items() if key != "chain"}
     assert lds[(2, False, True)] < lds[(2, False, False)] // 2, lds
 
 
@@ -89,7 +91,46 @@ def test_wide_inline_assembly_stores_are_followed_by_two_wait_states(wino_isa):
         assert stores, key
         for i in stores:
             nxt = ins[i + 1]
-            assert nxt.startswith("s_nop") and int(nxt.split()[1]) >= 1, "conv_wino_kernel<%d, %s, %s>: %s / %s" % (key + (ins[i], nxt))
+            assert nxt.startswith("s_nop") and int(nxt.split()[1]) >= 1, "conv_wino_kernel %s: %s / %s" % (key, ins[i], nxt)
+
+
+def test_conv_wino_chain_kernel_signals_through_scalar_mailboxes_and_moves_activations_device_coherently(wino_isa):
+    """The chain kernel (motif_conv2d_chain_fwd): (i) its tickets and completion words are scalar atomics whose results land in s100 / s101
+    a chunk or a tile before they are used -- the compiler must never allocate those two registers (it stops at s99 on gfx950; were that to
+    change, a result could arrive in a register holding something else); (ii) activations, residuals and outputs move with sc1 (the XCDs' L2s
+    are not coherent inside a kernel), weights stay cached; (iii) the chunk body is the same single run of 72 matrix instructions."""
+    kernels, _ = wino_isa
+    lines = kernels["chain"]
+    in_asm, mailbox_outside, atomics = False, [], []
+    for ln in lines:
+        t = ln.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif t.startswith(";;#ASMEND"):
+            in_asm = False
+        elif re.search(r"\bs10[01]\b|s\[100:101\]|s\[9\d:10[01]\]", t) and not t.startswith(";"):
+            if not in_asm:
+                mailbox_outside.append(t)
+            if t.startswith("s_atomic_add"):
+                atomics.append(t)
+    assert not mailbox_outside, "compiler-generated code touches a mailbox register: %s" % mailbox_outside[:3]
+    assert len(atomics) >= 3 and all(t.endswith("glc") and re.match(r"s_atomic_add s10[01],", t) for t in atomics), atomics
+    ins = list(_instr(lines))
+    stores = [t for t in ins if t.startswith("global_store_dwordx4")]
+    assert stores and all(t.endswith("sc1") for t in stores), [t for t in stores if not t.endswith("sc1")][:3]
+    loads = [t for t in ins if t.startswith("buffer_load_dwordx4")]
+    coherent = [t for t in loads if t.endswith("sc1")]
+    assert len(coherent) >= 30 and len(loads) - len(coherent) >= 12, (len(loads), len(coherent))      # row pieces + residual quads | weight fragments
+    assert not [t for t in ins if t.startswith("flat_")]
+    assert sum(1 for t in ins if t.startswith("scratch_load")) <= 4, "spill reloads in the chain kernel wait for every store in flight"
+    idx = [i for i, ln in enumerate(lines) if "v_mfma_f32_32x32x16_f16" in ln]
+    runs, start, prev, n = [], idx[0], idx[0], 1
+    for i in idx[1:]:
+        if i - prev > 80:
+            runs.append(n); n = 0
+        n += 1; prev = i
+    runs.append(n)
+    assert max(runs) == 72, runs
 
 
 @pytest.fixture(scope="module")

@@ -416,6 +416,94 @@ def test_conv_wino_transposed_accumulators_give_the_bits_of_the_row_major_form(c
     assert float((outs[0].double().cpu() - (torch.tanh(ref) * res.double().cpu() if rm == 4 else ref)).abs().max()) < 1e3      # (finite; the value tests are the engine tests above)
 
 
+def _chain_blocks(c, nb, seed):
+    from motif_amd import ops
+    blocks = []
+    for b in range(nb):
+        pl = []
+        for j in range(2):
+            w = rnd(c, c, 3, 3, seed=seed + 10 * b + j, scale=1.0 / (3.0 * math.sqrt(c))).to(dev())
+            pl.append(ops.ConvPlan(w, rnd(c, seed=seed + 10 * b + j + 5, scale=0.1).to(dev()), 1, 1, 1, 1, 0))
+        blocks.append(tuple(pl))
+    return blocks
+
+
+@pytest.mark.parametrize("case", [(1, 64, 16, 32, 1, False), (1, 64, 40, 64, 2, False), (2, 64, 36, 100, 3, False), (3, 64, 180, 320, 4, False), (2, 64, 180, 320, 5, True),
+                                  (1, 56, 61, 64, 4, False), (1, 64, 45, 80, 12, False), (3, 64, 90, 160, 40, False)])
+def test_conv_chain_gives_the_bits_of_the_launches_layer_by_layer(case, keep_mma):
+    """Round 5, VERDICT r4 "trunk fusion": `motif_conv2d_chain_fwd` runs the 2 B convolutions of B residual blocks (module_util.py:34-52 in an
+    nn.Sequential, Ours.py:349-356) as ONE persistent launch -- tiles of all layers in ticket order, a tile waiting for the row words of the
+    layer before.  The per-tile computation is conv_wino's, so the result must equal B x 2 calls of motif_conv2d_fwd BIT FOR BIT: one tile,
+    fewer tiles than CUs (every tile waits for its producers), ragged tiles, C = 56, a batch-strided output view, the trunk's 80 layers; three
+    times over (the dependency order differs from run to run), with a clean status word."""
+    from motif_amd import ops
+    n, c, H, W, nb, strided = case
+    ops.set_conv_mma(ops.MMA_F16X2)
+    blocks = _chain_blocks(c, nb, 7)
+    x = rnd(n, c, H, W, seed=99).to(dev())
+
+    def out_view():
+        return torch.zeros(n, 2, c, H, W, device=dev())[:, 0] if strided else None
+    saved = ops.CONV_CHAIN, ops.CONV_CHAIN_MIN_TILES
+    st = torch.zeros(1, dtype=torch.int32, device=dev())
+    try:
+        ops.CONV_CHAIN = False
+        ref = ops.resblock_chain(blocks, x, out=out_view())
+        ops.CONV_CHAIN, ops.CONV_CHAIN_MIN_TILES = True, 1
+        calls = []
+        orig = ops.conv2d_chain
+        ops.conv2d_chain = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            for _ in range(3):
+                with ops.range_status(st):
+                    got = ops.resblock_chain(blocks, x, out=out_view())
+                assert torch.equal(got, ref)
+        finally:
+            ops.conv2d_chain = orig
+        assert len(calls) == 3, "the chain entry did not take the shape"
+        assert int(st.item()) == 0
+    finally:
+        ops.CONV_CHAIN, ops.CONV_CHAIN_MIN_TILES = saved
+    y = x.double().cpu()
+    for p1, p2 in blocks:       # (value check against fp64: the engine tests above hold the arithmetic; this guards the buffer rotation)
+        t = F.relu(F.conv2d(y, p1.weight.double().cpu(), p1.bias.double().cpu(), 1, 1))
+        y = y + F.conv2d(t, p2.weight.double().cpu(), p2.bias.double().cpu(), 1, 1)
+    assert float((ref.double().cpu() - y).abs().max()) <= 2e-5 * max(1.0, float(y.abs().max())) * math.sqrt(nb)
+
+
+def test_conv_chain_two_chains_in_flight_and_an_out_of_range_operand(keep_mma):
+    """Two chain launches on two streams at once (the clips in flight of bench.py): a workgroup that is not resident holds no ticket, so
+    neither launch can starve the other -- both finish and both are exact.  Then ONE feature of 1e5 in the input: the chain's kernels report
+    it in the status word (bit 0) like the single launches do."""
+    from motif_amd import ops
+    ops.set_conv_mma(ops.MMA_F16X2)
+    blocks = [_chain_blocks(64, 6, 300), _chain_blocks(64, 6, 500)]
+    xs = [rnd(3, 64, 96, 160, seed=31).to(dev()), rnd(3, 64, 96, 160, seed=32).to(dev())]
+    saved = ops.CONV_CHAIN, ops.CONV_CHAIN_MIN_TILES
+    try:
+        ops.CONV_CHAIN = False
+        refs = [ops.resblock_chain(b, x) for b, x in zip(blocks, xs)]
+        ops.CONV_CHAIN, ops.CONV_CHAIN_MIN_TILES = True, 1
+        [ops.resblock_chain(b, x) for b, x in zip(blocks, xs)]           # tables built, weights packed
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for rep in range(4):
+            outs = []
+            for s_, b, x in zip(streams, blocks, xs):
+                with torch.cuda.stream(s_):
+                    outs.append(ops.resblock_chain(b, x))
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0], refs[0]) and torch.equal(outs[1], refs[1])
+        st = torch.zeros(1, dtype=torch.int32, device=dev())
+        xb = xs[0].clone()
+        xb[1, 5, 40, 77] = 1.0e5
+        with ops.range_status(st):
+            ops.resblock_chain(blocks[0], xb)
+        assert int(st.item()) & 1
+    finally:
+        ops.CONV_CHAIN, ops.CONV_CHAIN_MIN_TILES = saved
+
+
 def test_conv_pw_guard_bands_channels_past_cin_and_couts_past_cout_touch_nothing(keep_mma):
     """conv_pw.hip relies on the buffer range check for channels past Cin (a ragged last 16-channel step), couts past
     Cout (a partial cout tile) and the masked lanes of a ragged pixel group.  The plane offsets are therefore part of the VECTOR

@@ -852,12 +852,16 @@ def test_range_guard_trips_on_a_single_out_of_range_feature_the_splat_would_laun
     ref_model.mma = "bf16x3"
 
     def inject(net):
-        mod = {"encoder": net.encoder.conv_first, "flow_branch": net.flow_process[1], "imnet_input": net.encoder.recon_trunk[39].conv2}[where]
+        # (the trunk's 80 layers are ONE launch -- ops.resblock_chain -- so its last layer cannot be wrapped: the encoder's OUTPUT is)
+        mod = {"encoder": net.encoder.conv_first, "flow_branch": net.flow_process[1], "imnet_input": net.encoder}[where]
         orig = mod.forward
 
         def fwd(*a, **k):
             y = orig(*a, **k)
-            y[0, 3, 5, 7] = 1.0e5
+            if y.dim() == 5:
+                y[0, 0, 3, 5, 7] = 1.0e5
+            else:
+                y[0, 3, 5, 7] = 1.0e5
             return y
         mod.forward = fwd
 

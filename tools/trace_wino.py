@@ -21,7 +21,13 @@ torch.cuda.synchronize()
 if os.environ.get("MMA"):
     ops.set_conv_mma(int(os.environ["MMA"]))
 ops.set_option("conv_engine", 5)
-for _ in range(int(os.environ.get("REPS", "2"))):      # REPS=500: the traced (last) launch sees the clock of a sustained run
+if os.environ.get("CHAIN"):     # CHAIN=<blocks>: the traced launch is ONE chain launch of that many residual blocks (ops.resblock_chain)
+    nbk = int(os.environ["CHAIN"])
+    blocks = [tuple(ops.ConvPlan(torch.randn(co, ci, 3, 3, device="cuda") / (3 * ci ** 0.5), torch.randn(co, device="cuda") * 0.1, 1, 1, 1, 1, 0) for _ in range(2)) for _ in range(nbk)]
+    for _ in range(int(os.environ.get("REPS", "2"))):
+        y = ops.resblock_chain(blocks, x)
+else:
+  for _ in range(int(os.environ.get("REPS", "2"))):      # REPS=500: the traced (last) launch sees the clock of a sustained run
     y = m(x, **kw)
 torch.cuda.synchronize()
 lib = _lib.load()
@@ -72,3 +78,15 @@ if os.environ.get("PRO"):
     print("prologue phases (cycles): table+barrier | issue weights+row pieces | wait for them | staging pieces | init + step-1 requests + barrier")
     print("   " + " ".join("%6.0f" % d[..., i][okc].mean() for i in range(5)))
     print("   per wave: " + " | ".join(" ".join("%5.0f" % d[:, w, i][okc[:, w]].mean() for i in range(5)) for w in range(4)))
+
+if os.environ.get("CHAIN"):
+    buf3 = (ctypes.c_longlong * (256 * 8 * 8))()
+    lib.motif_debug_chain_trace.restype = ctypes.c_int
+    lib.motif_debug_chain_trace(buf3, 256 * 8 * 8)
+    t3 = np.frombuffer(buf3, dtype=np.int64).reshape(256, 8, 8).astype(np.float64)
+    print("chain, wave 0, end of a tile (cycles): init_acc | ticket take | entry | issue 2 atomics | store wait | barrier | publish")
+    for k in range(1, 5):
+        okc = (t3[:, k, 0] > 0) & (t3[:, k, 7] > 0) & (t3[:, k, 2] > 0)
+        if okc.any():
+            d = t3[:, k, 1:8] - t3[:, k, 0:7]
+            print("  tile %d: %s" % (k, " ".join("%6.0f" % d[:, i][okc].mean() for i in range(7))))

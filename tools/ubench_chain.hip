@@ -118,6 +118,92 @@ __global__ __launch_bounds__(256) void tickets(unsigned* ws, int n) {
     }
 }
 
+// the same with SCALAR atomics (s_atomic_add ... glc: returns to an SGPR, counted by lgkmcnt -- independent of the vector-memory queue a
+// software-pipelined kernel keeps full): tickets by s_atomic_add, each cell incremented by a VECTOR atomic, then read back coherently by a
+// scalar atomic add of 0 from every workgroup (whatever XCD it runs on) after a device-wide count says all cells are done
+__device__ __forceinline__ unsigned s_fetch_add(unsigned* p, unsigned v) {
+    unsigned long long a = (unsigned long long)p;
+    asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(a) : "memory");
+    return v;
+}
+__global__ __launch_bounds__(256) void tickets_scalar(unsigned* ws, int n, unsigned* bad) {
+    __shared__ int sh[1];
+    for (;;) {
+        int tk = 0;
+        if (threadIdx.x < 64) tk = (int)s_fetch_add(ws, 1u);                 // wave 0 (uniform: one scalar instruction)
+        if (threadIdx.x == 0) sh[0] = tk;
+        __syncthreads();
+        tk = sh[0];
+        __syncthreads();
+        if (tk >= n) break;
+        int t_o = threadIdx.x;
+        asm volatile("" : "+v"(t_o));
+        if (t_o == 0) {
+            __hip_atomic_fetch_add(ws + 64 + tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(ws + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // wait (bounded) until all n cells were incremented, then every workgroup reads 64 cells through scalar atomics
+    if (threadIdx.x < 64) {
+        const long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (s_fetch_add(ws + 2, 0u) < (unsigned)n && __builtin_amdgcn_s_memrealtime() - t0 < 10000000ll) __builtin_amdgcn_s_sleep(8);
+        unsigned wrong = 0;
+        for (int i = 0; i < 64; ++i) wrong += s_fetch_add(ws + 64 + (blockIdx.x * 61 + i * 97) % n, 0u) != 1u;
+        if (threadIdx.x == 0 && wrong) atomicAdd(bad, wrong);
+    }
+}
+
+// round-trip latency of the signalling primitives under no load, one wave per workgroup on G workgroups: [0] scalar atomic add of 0 to a PRIVATE
+// word, [1] the same on ONE word shared by all, [2] vector atomic (returning) on the shared word, [3] sc1 vector load of the shared word
+__global__ void latency(unsigned* ws, long long* out, int iters) {
+    unsigned* mine = ws + 1024 + blockIdx.x * 64;
+    long long acc[4] = {};
+    unsigned sink = 0;
+    for (int it = 0; it < iters; ++it) {
+        long long t0 = __builtin_amdgcn_s_memtime();
+        sink += s_fetch_add(mine, 0u);
+        long long t1 = __builtin_amdgcn_s_memtime();
+        sink += s_fetch_add(ws + 512, 0u);
+        long long t2 = __builtin_amdgcn_s_memtime();
+        unsigned v = 0;
+        if (threadIdx.x == 0) v = __hip_atomic_fetch_add(ws + 512, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sink += __builtin_amdgcn_readfirstlane(v);
+        long long t3 = __builtin_amdgcn_s_memtime();
+        sink += __builtin_amdgcn_readfirstlane(__hip_atomic_load(ws + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        long long t4 = __builtin_amdgcn_s_memtime();
+        acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3;
+    }
+    if (threadIdx.x == 0) { for (int i = 0; i < 4; ++i) out[blockIdx.x * 4 + i] = acc[i] / iters; ws[900] = sink; }
+}
+
+// Does vmcnt retire loads and stores in ONE order on gfx950?  [store sc1 to a cold line; load of a hot line; s_waitcnt vmcnt(1)]: with in-order
+// retirement the wait ends when the STORE is acknowledged (~ the store latency), otherwise when either is (~ the load latency).
+__global__ void vm_order(unsigned* cold, const unsigned* hot, long long* out, int iters) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    long long acc[3] = {};
+    unsigned sink = 0;
+    u4 v = {1u, 2u, 3u, threadIdx.x};
+    for (int it = 0; it < iters; ++it) {
+        unsigned long long cp = (unsigned long long)(cold + ((size_t)(blockIdx.x * iters + it) * 3 + 0) * 4096);
+        unsigned bo = threadIdx.x * 16u;
+        unsigned hv;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        long long t0 = __builtin_amdgcn_s_memtime();
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" :: "v"(bo), "v"(v), "s"(cp) : "memory");
+        long long t1 = __builtin_amdgcn_s_memtime();
+        cp += 16384;
+        asm volatile("global_load_dword %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(hv) : "v"(bo & 63u), "s"((unsigned long long)hot) : "memory");
+        sink += hv;
+        long long t2 = __builtin_amdgcn_s_memtime();
+        asm volatile("global_store_dwordx4 %1, %2, %3 sc1\n\tglobal_load_dword %0, %4, %5\n\ts_waitcnt vmcnt(1)" : "=&v"(hv) : "v"(bo), "v"(v), "s"(cp), "v"(bo & 63u), "s"((unsigned long long)hot) : "memory");
+        long long t3 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sink += hv;
+        acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2;
+    }
+    if (threadIdx.x == 0) { for (int i = 0; i < 3; ++i) out[blockIdx.x * 3 + i] = acc[i] / iters; cold[0] = sink; }
+}
+
 static void host_model(std::vector<unsigned>& cur, const P& p) {
     const int T = p.T;
     std::vector<unsigned> nxt(cur.size());
@@ -202,6 +288,46 @@ int main(int argc, char** argv) {
         printf("tickets: counter ended at %u (want %d + 256), %d cells taken twice, %d never; by XCC:", h[0], n, dup, miss);
         for (int i = 0; i < 8; ++i) printf(" %d", xh[i]);
         printf("\n");
+    }
+    {
+        const int n = p.L * p.T;
+        unsigned* w2;
+        hipMalloc(&w2, (64 + 2 * (size_t)n) * 4);
+        hipMemset(w2, 0, (64 + 2 * (size_t)n) * 4);
+        tickets_scalar<<<256, 256>>>(w2, n, w2 + 3);
+        hipError_t e = hipDeviceSynchronize();
+        std::vector<unsigned> h(64 + (size_t)n);
+        hipMemcpy(h.data(), w2, h.size() * 4, hipMemcpyDeviceToHost);
+        int dup = 0, miss = 0;
+        for (int i = 0; i < n; ++i) { dup += h[64 + i] > 1; miss += h[64 + i] == 0; }
+        printf("scalar tickets (%s): counter ended at %u (want %d + 256), %d cells taken twice, %d never; scalar read-back saw %u stale cells\n",
+               hipGetErrorString(e), h[0], n, dup, miss, h[3]);
+    }
+    for (int G : {1, 256}) {
+        unsigned* w3; long long* o3;
+        hipMalloc(&w3, (1024 + 256 * 64) * 4); hipMalloc(&o3, 256 * 4 * 8);
+        hipMemset(w3, 0, (1024 + 256 * 64) * 4);
+        latency<<<G, 64>>>(w3, o3, 200);
+        hipDeviceSynchronize();
+        std::vector<long long> h(256 * 4);
+        hipMemcpy(h.data(), o3, G * 4 * 8, hipMemcpyDeviceToHost);
+        double m[4] = {};
+        for (int b = 0; b < G; ++b) for (int i = 0; i < 4; ++i) m[i] += (double)h[b * 4 + i] / G;
+        printf("latency, %3d workgroups (shader cycles): scalar atomic private %.0f | scalar atomic shared %.0f | vector atomic shared %.0f | sc1 load %.0f\n", G, m[0], m[1], m[2], m[3]);
+    }
+    {
+        unsigned *cold, *hot; long long* o4;
+        const int G4 = 64, it4 = 64;
+        hipMalloc(&cold, (size_t)G4 * it4 * 3 * 4096 * 4 + 65536); hipMalloc(&hot, 4096); hipMalloc(&o4, G4 * 3 * 8);
+        hipMemset(hot, 0, 4096);
+        vm_order<<<G4, 64>>>(cold, hot, o4, it4);
+        hipDeviceSynchronize();
+        std::vector<long long> h(G4 * 3);
+        hipMemcpy(h.data(), o4, G4 * 3 * 8, hipMemcpyDeviceToHost);
+        double m[3] = {};
+        for (int b = 0; b < G4; ++b) for (int i = 0; i < 3; ++i) m[i] += (double)h[b * 3 + i] / G4;
+        printf("vmcnt order (cycles): sc1 store alone %.0f | hot load alone %.0f | [store; load; vmcnt(1)] %.0f  -> %s\n", m[0], m[1], m[2],
+               m[2] > 0.7 * m[0] ? "in order (the wait covers the store)" : "OUT of order (the wait ended with the load)");
     }
     int bad = 0;
     run<3>(p, want, 3, "3: sc1 data path, no dependencies (not checked)");
