@@ -399,8 +399,8 @@ class LunaTokis(nn.Module):
     def _flow_encoder(self, x):
         fp = self.flow_process
         y = fp[1](fp[0](x), act=LRELU)
-        for i in range(3, 8):
-            y = fp[i](y, act=LRELU if i == 7 else NONE)
+        # the five LateralBlocks (conv - leaky ReLU - conv + x; the last one's sum through a leaky ReLU) as one launch where the shape allows it
+        y = ops.resblock_chain([(fp[i].layers[0].plan(), fp[i].layers[2].plan()) for i in range(3, 8)], y, act=LRELU, last_act=LRELU)
         return fp[9](y)
 
     def _raft_pairs(self, hr, pairs, n_flows, H, W, iters):

@@ -216,9 +216,10 @@ CONV_CHAIN_MIN_TILES = int(os.environ.get("MOTIF_CONV_CHAIN_MIN_TILES", "256"))
 _chain_tables = {}
 
 
-def resblock_chain(blocks, x, out=None, act=ACT_RELU):
+def resblock_chain(blocks, x, out=None, act=ACT_RELU, last_act=ACT_NONE):
     """x' = x + conv2(act(conv1(x))) over `blocks` = [(plan1, plan2), ...] (`module_util.py:34-52` in an nn.Sequential: the reconstruction
-    trunk and the feature extraction, `Ours.py:349-356`).  One persistent launch (`motif_conv2d_chain_fwd`: the tiles of all layers in
+    trunk and the feature extraction, `Ours.py:349-356`; with act = leaky ReLU and `last_act` applied to the LAST block's sum, the five
+    LateralBlocks of `flow_process`, `Ours.py:425-431`).  One persistent launch (`motif_conv2d_chain_fwd`: the tiles of all layers in
     dependency order, conv_wino.hip CHAIN) where the shape and the arithmetic allow it -- the same bits as the launches layer by layer,
     which is what runs otherwise.  x [N,C,H,W] planar; `out` may be a batch-strided view."""
     lib = _lib.load()
@@ -239,18 +240,19 @@ def resblock_chain(blocks, x, out=None, act=ACT_RELU):
     if words <= 0 or ((x.data_ptr() | out.data_ptr()) & 15) or ((x.stride(0) | out.stride(0)) & 3):
         y = x
         for i, (p1, p2) in enumerate(blocks):
-            y = conv2d(p2, conv2d(p1, y, act=act), res=y, res_mode=1, out=out if i == len(blocks) - 1 else None)
+            lastb = i == len(blocks) - 1
+            y = conv2d(p2, conv2d(p1, y, act=act), act=last_act if lastb else ACT_NONE, res=y, res_mode=1, out=out if lastb else None)
         return y
-    return conv2d_chain(blocks, x, out, act, d, words)
+    return conv2d_chain(blocks, x, out, act, d, words, last_act)
 
 
-def conv2d_chain(blocks, x, out, act, d, words):
+def conv2d_chain(blocks, x, out, act, d, words, last_act=ACT_NONE):
     """The launch of `resblock_chain` (`motif_conv2d_chain_fwd`); eligibility was checked there."""
     lib = _lib.load()
     n, c, h, w = x.shape
     L = 2 * len(blocks)
     packed = [p.packed() for blk in blocks for p in blk]
-    key = (tuple(t.data_ptr() for t in packed), tuple(p.bias.data_ptr() if p.bias is not None else 0 for blk in blocks for p in blk), act, x.device)
+    key = (tuple(t.data_ptr() for t in packed), tuple(p.bias.data_ptr() if p.bias is not None else 0 for blk in blocks for p in blk), act, last_act, x.device)
     tab = _chain_tables.get(key)
     if tab is None:
         # MotifChainLayer[L]: packed, bias, src, dst, res, act | res_mode << 8.  Buffers: 0 = x, 1 = out, 2 = T, 3 / 4 = X (x_b lives in X[b % 2]):
@@ -260,7 +262,7 @@ def conv2d_chain(blocks, x, out, act, d, words):
         for b, (p1, p2) in enumerate(blocks):
             xb = 0 if b == 0 else 3 + (b % 2)
             xn = 1 if b == nb - 1 else 3 + ((b + 1) % 2)
-            for p, src, dst, res, arm in ((p1, xb, 2, -1, act), (p2, 2, xn, xb, ACT_NONE | (1 << 8))):
+            for p, src, dst, res, arm in ((p1, xb, 2, -1, act), (p2, 2, xn, xb, (last_act if b == nb - 1 else ACT_NONE) | (1 << 8))):
                 bias = p.bias.detach().data_ptr() if p.bias is not None else 0
                 rows.append((p.packed().data_ptr(), bias, (src & 0xffffffff) | ((dst & 0xffffffff) << 32), (res & 0xffffffff) | ((arm & 0xffffffff) << 32)))
         import numpy as np

@@ -471,6 +471,31 @@ def test_conv_chain_gives_the_bits_of_the_launches_layer_by_layer(case, keep_mma
     assert float((ref.double().cpu() - y).abs().max()) <= 2e-5 * max(1.0, float(y.abs().max())) * math.sqrt(nb)
 
 
+def test_conv_chain_lateral_blocks_leaky_relu_and_an_activation_on_the_last_sum(keep_mma):
+    """The five LateralBlocks of `flow_process` (Ours.py:425-431): conv - leaky ReLU - conv + x, the LAST block's sum through a leaky ReLU
+    (epilogue = activation of (value + residual)): one chain launch, the bits of the ten launches."""
+    from motif_amd import ops
+    ops.set_conv_mma(ops.MMA_F16X2)
+    blocks = _chain_blocks(64, 5, 40)
+    x = rnd(2, 64, 90, 160, seed=17).to(dev())
+    saved = ops.CONV_CHAIN, ops.CONV_CHAIN_MIN_TILES
+    try:
+        ops.CONV_CHAIN = False
+        ref = ops.resblock_chain(blocks, x, act=ops.ACT_LRELU, last_act=ops.ACT_LRELU)
+        ops.CONV_CHAIN, ops.CONV_CHAIN_MIN_TILES = True, 1
+        got = ops.resblock_chain(blocks, x, act=ops.ACT_LRELU, last_act=ops.ACT_LRELU)
+    finally:
+        ops.CONV_CHAIN, ops.CONV_CHAIN_MIN_TILES = saved
+    assert torch.equal(got, ref)
+    y = x.double().cpu()
+    for i, (p1, p2) in enumerate(blocks):
+        t = F.leaky_relu(F.conv2d(y, p1.weight.double().cpu(), p1.bias.double().cpu(), 1, 1), 0.1)
+        y = y + F.conv2d(t, p2.weight.double().cpu(), p2.bias.double().cpu(), 1, 1)
+        if i == 4:
+            y = F.leaky_relu(y, 0.1)
+    assert float((ref.double().cpu() - y).abs().max()) <= 5e-5 * max(1.0, float(y.abs().max()))
+
+
 def test_conv_chain_two_chains_in_flight_and_an_out_of_range_operand(keep_mma):
     """Two chain launches on two streams at once (the clips in flight of bench.py): a workgroup that is not resident holds no ticket, so
     neither launch can starve the other -- both finish and both are exact.  Then ONE feature of 1e5 in the input: the chain's kernels report
