@@ -1400,7 +1400,8 @@ extern "C" int motif_conv2d_chain_fwd(const MotifConvDesc* d, int L, const Motif
     ch.L = L;
     const int tiles_y = (d->H + 7) / 8, cus = wn_cu_count();
     const long total = T * L;
-    const int G = (int)(total < cus ? total : cus);
+    int G = (int)(total < cus ? total : cus);
+    if (const int w = motif_opt(MOTIF_OPT_CONV_CHAIN_WGS); w > 0 && w < G) G = w;        // fewer workgroups leave CUs to the launches of other streams
     const size_t ldsb = ((size_t)4 * 16 + (size_t)2 * 2 * (2 * 16 * 34 + 4) + (size_t)4 * 640 + (size_t)128 * 4) * 16;      // as motif_conv_wino_launch, NP = 2
     const size_t ldsc = ldsb + (size_t)L * 64 + (size_t)T * 4;          // + the resolved layer table and the tile decode table
     hipError_t e = hipFuncSetAttribute((const void*)conv_wino_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
