@@ -97,7 +97,19 @@ __device__ __forceinline__ f32x16 mfma16(u32x4 w, u32x4 x, f32x16 c) {
 template <int NP>
 __device__ __forceinline__ float sin_turns(float t) {
     if constexpr (NP == 2) t *= 1.f / kSirenScale<2>;     // the accumulators of the two-part form carry 2^8 x the argument
+    // The v_fract in front is NOT needed for accuracy (gfx950's v_sin_f32 reduces its argument itself: against sin(2 pi x) in fp64 over
+    // +-1 ... +-3e7 turns the maximum error is 1.1-1.25e-7 with and without it) and costs one of ~5 vector instructions per activation --
+    // but WITHOUT it (-DSIREN_NO_FRACT) the two-part flow kernel is no longer reproducible from run to run (a third of its pixels differ by
+    // up to 9e-6 between two launches on the same inputs; imnet and the three-part form stay bit-identical).  v_sin_f32 itself is a pure
+    // function in every microbenchmark tried (alone, between matrix instructions, in bursts with immediate consumers, |x| up to 3e7); a
+    // dummy VALU instruction in the fract's place, wait states around the inline-assembly mixed FMAs, 16 wait states behind every matrix
+    // instruction and double-buffered weight fragments all leave it irreproducible.  The cause was not found in the time available, so the
+    // fract stays (DESIGN_LOG "Round 5"; tests/test_kernels_gpu.py::test_siren_kernels_are_reproducible_from_run_to_run pins the property).
+#ifdef SIREN_NO_FRACT
+    return __builtin_amdgcn_sinf(t);
+#else
     return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t));
+#endif
 }
 
 template <int MODE, int NP> struct SLayout {

@@ -1130,6 +1130,47 @@ def test_siren_kernels_vs_torch(HW):
         close(ops.siren_synth(blob, acc.to(dev()), l0, iy, ix, times.to(dev()), B, N, HH, WW, pre=pre), r, 2e-5, 1e-4, "synth split, " + what)
 
 
+def test_siren_kernels_are_reproducible_from_run_to_run():
+    """The three MLP kernels at the c2 size, six launches each on the same inputs: bit-identical outputs, in the default two-part form and
+    in the three-part form.  (Round 5: the two-part flow kernel lost this property when its sine lost the v_fract in front -- a third of
+    the pixels differed by up to 9e-6 from launch to launch, cause not found; siren_split.hip keeps the fract and this test pins it.)"""
+    from motif_amd import ops
+    from motif_amd.models.modules.SIREN import Siren
+    from motif_amd.utils.synth_weights import fill_state_dict
+    H, W, HH, WW = 180, 320, 720, 1280
+    iy, ix, rel_y, rel_x = _tables(H, W, HH, WW)
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.flow_imnet = Siren(67, [64, 64, 256], 2, 3, True)
+            self.imnet = Siren(66, [64, 64, 256], 2, 64, True)
+            self.synth_net = Siren(198, [64, 64, 64, 256], 3, 3, True)
+    mine = fill_state_dict(Holder()).to(dev())
+    B, N = 1, 3
+    feat = rnd(2 * B, 64, H, W, seed=1, scale=0.3).to(dev())
+    times = torch.tensor([[0.25, 0.5, 1.0]]).to(dev())
+    acc = rnd(B * N, 133, HH, WW, seed=5, scale=0.5)
+    acc[:, 130] = acc[:, 130].abs() * 2 + 1e-3
+    acc[:, :130] *= acc[:, 130:131]
+    acc[:, 131] = 1.0 + acc[:, 131].abs()
+    acc[:, 132] = torch.randint(0, 9, (B * N, HH, WW), generator=torch.Generator().manual_seed(6)).float()
+    acc = acc.to(dev())
+    res = rnd(B, 64, H, W, seed=7, scale=0.3).to(dev())
+    for pre in (3, 2):
+        fl0 = ops.conv2d(mine.flow_imnet.l0_plan(0, 64), feat)
+        il0 = ops.conv2d(mine.imnet.l0_plan(0, 64), feat)
+        sl0 = ops.conv2d(mine.synth_net.l0_plan(133, 197), res)
+        fb, ib, sb = (ops.siren_pack_split(k, m.linears(), pre=pre) for k, m in ((ops.SIREN_FLOW, mine.flow_imnet), (ops.SIREN_IMNET, mine.imnet), (ops.SIREN_SYNTH, mine.synth_net)))
+        runs = {"flow_imnet": lambda: ops.siren_flow(fb, fl0, iy, ix, rel_y, rel_x, times, N, HH, WW, pre=pre),
+                "imnet": lambda: ops.siren_imnet(ib, il0, iy, ix, rel_y, rel_x, HH, WW, pre=pre),
+                "synth_net": lambda: ops.siren_synth(sb, acc, sl0, iy, ix, times, B, N, HH, WW, pre=pre)}
+        for name, fn in runs.items():
+            ref = fn().clone()
+            for _ in range(5):
+                assert torch.equal(fn(), ref), "%s (pre = %d) differs from launch to launch" % (name, pre)
+
+
 # ------------------------------------------------------------------------------------------- fused MoTIF splat
 @pytest.mark.parametrize("far", [False, True])
 def test_splat_motif_owner_computes_vs_kernel_text(far):
