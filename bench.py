@@ -667,9 +667,10 @@ def main():
                                                else "fp32 MFMA 157.3 TFLOP/s"),
                                 "frac_of_6_product_bound": (ach / (BF16_MFMA_PEAK_TFLOPS / 6.0)) if a.mma == "f16x2" else None,
                                 "kernel": ("3x3 engine: conv_wino_kernel (Winograd F(2,3) along the rows, one wave per SIMD: 2/3 of the direct form's MFMAs for the "
-                                           "algorithmic FLOP counted here) wherever it applies, the direct conv_split2 / conv_split kernels for the layers with a "
-                                           "transcendental epilogue or a single 16-channel chunk") if split else "conv_igemm_kernel<2>",
-                                "flop_basis": "algorithmic (direct-form) FLOP of the launches; the Winograd kernel executes 2/3 of them on the matrix cores",
+                                           "algorithmic FLOP counted here) wherever it applies -- the residual trunks (recon_trunk, feature_extraction, the LateralBlocks of "
+                                           "flow_process: 100 layers) as THREE persistent chain launches, conv_wino_chain_kernel / motif_conv2d_chain_fwd --, the direct "
+                                           "conv_split2 / conv_split kernels for the layers with a transcendental epilogue or a single 16-channel chunk") if split else "conv_igemm_kernel<2>",
+                                "flop_basis": "algorithmic (direct-form) FLOP of the launches (a chain launch counts the FLOP of all its layers); the Winograd kernel executes 2/3 of them on the matrix cores",
                                 "launches_per_clip": r["launches"],
                                 "avg_launch_us": 1000.0 * r["ms"] / max(r["launches"], 1),
                                 "avg_launch_gflop": r["flops"] / max(r["launches"], 1) / 1e9,
