@@ -212,7 +212,7 @@ def conv2d(plan, x, x2=None, act=ACT_NONE, res=None, res_mode=0, act2=ACT_NONE, 
 
 
 CONV_CHAIN = os.environ.get("MOTIF_CONV_CHAIN", "1") != "0"     # residual chains as ONE persistent launch where the shape allows it
-CONV_CHAIN_MIN_TILES = int(os.environ.get("MOTIF_CONV_CHAIN_MIN_TILES", "256"))
+CONV_CHAIN_MIN_TILES = int(os.environ.get("MOTIF_CONV_CHAIN_MIN_TILES", "0"))      # 0: one tile per CU and layer (256 on an MI355X)
 _chain_tables = {}
 
 
@@ -235,7 +235,7 @@ def resblock_chain(blocks, x, out=None, act=ACT_RELU, last_act=ACT_NONE):
     ok = CONV_CHAIN and x.is_cuda and all(tuple(p.weight.shape) == (c, c, 3, 3) and p.stride == 1 and p.pad == 1 and p.dil == 1 and p.groups == 1 and
                                           p.pad_mode == 0 and (p.mma is None or p.mma == d.mma) for blk in blocks for p in blk)
     # below one tile per CU and layer the chain is bound by its dependency latency (a tile time per layer, like the launches) and gains nothing
-    ok = ok and n * ((h + 7) // 8) * ((w + 31) // 32) >= CONV_CHAIN_MIN_TILES
+    ok = ok and n * ((h + 7) // 8) * ((w + 31) // 32) >= (CONV_CHAIN_MIN_TILES or torch.cuda.get_device_properties(x.device).multi_processor_count)
     words = lib.motif_conv2d_chain_ws_words(ctypes.byref(d), L) if ok else 0
     if words <= 0 or ((x.data_ptr() | out.data_ptr()) & 15) or ((x.stride(0) | out.stride(0)) & 3):
         y = x

@@ -282,6 +282,39 @@ def test_shell_time_chunking_matches_reference():
     assert np.abs(p_mine - p_ref).max() < 0.05, (p_mine, p_ref)
 
 
+def test_residual_trunks_run_as_chain_launches_at_c2(mma_mode):
+    """At the benchmark's size the three residual trunks of a clip (feature_extraction, recon_trunk, the LateralBlocks of flow_process: 100
+    convolutions) are THREE launches of motif_conv2d_chain_fwd under the default arithmetic -- not a silent return to the single launches --
+    and the frames equal those of the single launches bit for bit."""
+    from motif_amd import ops
+    from motif_amd.data.synthetic import synthetic_sample
+    if mma_mode != DEFAULT_MMA:
+        pytest.skip("the chain kernel exists in the default two-part form")
+    net = build_net()
+    s = synthetic_sample(180, 320, 4, 7)
+    x = s["LQs"].cuda()
+    times = [t.cuda() for t in s["time"]]
+    calls = []
+    orig = ops.conv2d_chain
+    ops.conv2d_chain = lambda blocks, *a, **k: (calls.append(2 * len(blocks)), orig(blocks, *a, **k))[1]
+    try:
+        with torch.no_grad():
+            o, _, _ = net(x, None, times[3:4], s["scale"], use_GT=False, iter=4)
+            o = o.clone()
+    finally:
+        ops.conv2d_chain = orig
+    assert sorted(calls) == [10, 10, 80], calls
+    saved = ops.CONV_CHAIN
+    try:
+        ops.CONV_CHAIN = False
+        net.clear_cache()
+        with torch.no_grad():
+            o2, _, _ = net(x, None, times[3:4], s["scale"], use_GT=False, iter=4)
+    finally:
+        ops.CONV_CHAIN = saved
+    assert torch.equal(o, o2)
+
+
 def test_full_size_properties_c2():
     """BASELINE config 2 (LR 180x320 -> 720x1280, x6t): size-independent properties at full size --
     shapes, range, determinism of the t-independent cache across chunks, finite outputs, and agreement
