@@ -29,7 +29,8 @@ Extra objects on the JSON line:
   parity       PSNR / L-inf of the HIP path against the CPU oracle on the cpu_baseline clip (both engines).
   cpu_baseline the CPU oracle (oracle/, "port" of the reference): one 3-timestamp forward call at the c2 shape (after a warm-up
                call), plus a cropped clip and the reference's own CPU-runnable case c1.
-  streams1     the same job with one clip in flight; fp32_mfma: the same job on the fp32 MFMA.
+  batch1       the same job with ONE clip per forward (--batch 1: the headline configuration of rounds 1-4; the default step is one forward
+               over B = 2 independent clips, two forwards in flight); streams1: one forward in flight; fp32_mfma / bf16x3: other arithmetics.
   stages.pwc   PWC-Net forward on one 720x1280 pair + the 81-way cost volume against HBM.
   c5           (multi-GPU runs, or --mode tiled) one 540x960 clip in row bands: exact and cropped modes, PSNR of the latter.
 """
@@ -62,7 +63,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=2,
                     help="clips in flight per GPU, each on its own HIP stream and model instance (default 2: the next clip's launches fill the "
                          "tails of the current one's, +6 %% throughput; 1 = strictly one clip at a time)")
-    ap.add_argument("--batch", type=int, default=1, help="clips per step (one forward over a batch of B independent clips)")
+    ap.add_argument("--batch", type=int, default=2,
+                    help="clips per step: one forward over a batch of B independent clips (default 2 since round 5: +4 %% over B = 1 on the same box; "
+                         "the line's `batch1` leg is the B = 1 job of rounds 1-4)")
     ap.add_argument("--graph", action="store_true",
                     help="replay one HIP graph per clip instead of launching every kernel from the host (opt['hip_graph']): measured "
                          "32.9 vs 34.3 ms with one clip at a time, but 32.7 vs 30.4 ms with two clips in flight -- two graphs do not "
@@ -515,18 +518,22 @@ def main():
     HH, WW = h * a.scale, w * a.scale
     # two distinct clips per rank, resident in HBM before the timed region.  Global clip j = rank + world * i goes to rank j % world:
     # the striding of the reference's DistIterSampler (data/data_sampler.py:56, indices[rank::world]); clip j is seeded with j.
-    clips = []
-    for i in range(2):
-        s = synthetic_sample(h, w, a.scale, a.times, seed=rank + world * i, batch=a.batch)
-        s = {"LQs": s["LQs"].cuda(), "GT": s["GT"][:, :1].cuda(), "time": [t.cuda() for t in s["time"]], "scale": s["scale"]}
-        clips.append(s)
+    def resident(batch):
+        out = []
+        for i in range(2):
+            s = synthetic_sample(h, w, a.scale, a.times, seed=rank + world * i, batch=batch)
+            out.append({"LQs": s["LQs"].cuda(), "GT": s["GT"][:, :1].cuda(), "time": [t.cuda() for t in s["time"]], "scale": s["scale"]})
+        return out
+    clips = resident(a.batch)
+    clips1 = clips if a.batch == 1 else resident(1)       # one clip per step: the `batch1` leg and the instrumented (per-clip) stage table
+    cur = [clips]
 
     nstreams = [len(models)]                              # clips in flight in the loop being timed (streams1 leg: 1)
 
     def step(i):
         m = models[i % nstreams[0]]
         with torch.cuda.stream(streams[i % nstreams[0]]):
-            m.feed_data(clips[i % 2])
+            m.feed_data(cur[0][i % 2])
             m.test()
             if world > 1:
                 u8 = mdist.frames_to_uint8(m.fake_H.permute(1, 0, 2, 3, 4))       # [B,T,HH,WW,3] = this rank's clip, encode kernel
@@ -587,7 +594,7 @@ def main():
                                + ": 4-frame %dx%d LR clip -> %dx%d (x%d spatial), x%dt = %d timestamps, B=%d clip(s) per step per GPU, "
                                "RAFT-small iters=4, seeded key-hashed weights" % (h, w, HH, WW, a.scale, a.times - 1, a.times, a.batch),
                    "parallelism": "clips sharded per GPU (dp%d), uint8 frame gather to rank 0" % world,
-                   "clips_in_flight_per_gpu": a.streams,
+                   "clips_in_flight_per_gpu": a.streams * a.batch, "forwards_in_flight_per_gpu": a.streams, "clips_per_forward": a.batch,
                    "launch": "one HIP graph per clip (recorded from the second clip on, inputs copied in, replayed)" if a.graph else "host launches"},
     }
     # the range status words of the timed clips (include/motif_hip.h): 0 = no kernel of the two-part fp16 arithmetic met an operand beyond
@@ -615,12 +622,20 @@ def main():
                 ok = ok and bool(torch.equal(got[r * a.batch:(r + 1) * a.batch].to(mine.device), mine))
             line["gather_verified"] = ok                 # every rank's gathered frames == rank 0's own render of that rank's clip
         fence()
+    if a.batch > 1 and not a.no_streams1:
+        cur[0] = clips1                                  # the job of rounds 1-4: one clip per forward, same clips in flight
+        setup()
+        dtb = timed(1, a.steps)
+        cur[0] = clips
+        setup()
+        line["batch1"] = {"value": world * a.steps * (px // a.batch) / dtb, "unit": "px/s", "ms_per_step": 1000.0 * dtb / a.steps,
+                          "note": "the same job with B = 1 clip per forward (--batch 1), %d forwards in flight: the headline configuration of rounds 1-4" % a.streams}
     if a.streams > 1 and not a.no_streams1:
         nstreams[0] = 1                                  # strictly one clip at a time on the first stream / model instance
         dt1 = timed(1, a.steps)
         nstreams[0] = len(models)
         line["streams1"] = {"value": world * a.steps * px / dt1, "unit": "px/s", "ms_per_step": 1000.0 * dt1 / a.steps,
-                            "note": "the same job with ONE clip in flight per GPU (--streams 1); the headline keeps %d in flight" % a.streams}
+                            "note": "the same job with ONE forward (of B = %d clips) in flight per GPU (--streams 1); the headline keeps %d in flight" % (a.batch, a.streams)}
     if a.mma != "fp32" and not a.no_fp32_leg:
         # the same job on the fp32 MFMA (all ranks, same barriers), reported next to the headline value
         from motif_amd import ops
@@ -639,7 +654,8 @@ def main():
                              "note": "same job with --mma fp32 (v_mfma_f32_32x32x2_f32 contractions)"}
     if rank == 0:
         if not a.no_roofline:
-            r = instrumented_clip(model, clips[0])
+            model.feed_data(clips1[0]); model.test(); torch.cuda.synchronize()      # (the allocator's buffers of the one-clip shape)
+            r = instrumented_clip(model, clips1[0])        # ONE clip: the stage table is per clip whatever the batch of the timed loop
             ach = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
             split = a.mma != "fp32"
             traffic, traffic_src = None, None
@@ -657,8 +673,8 @@ def main():
             clip_flop = sum(v.get("tflop", 0.0) for k, v in r["table"].items() if isinstance(v, dict)) * 1e12
             line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                 "frac": ach / peak, "traffic": None, "traffic_from_profile": traffic, "traffic_source": traffic_src,
-                                "overall": {"tflop_executed_per_clip": clip_flop / 1e12, "achieved": clip_flop / (dt / a.steps) / 1e12,
-                                            "frac": clip_flop / (dt / a.steps) / 1e12 / peak,
+                                "overall": {"tflop_executed_per_clip": clip_flop / 1e12, "achieved": clip_flop / (dt / a.steps / a.batch) / 1e12,
+                                            "frac": clip_flop / (dt / a.steps / a.batch) / 1e12 / peak,
                                             "note": "dense FLOP of one clip (all conv / DCN / MLP stages as executed, t-independent part once) over "
                                                     "the timed wall time per clip, against the same peak"},
                                 "peak_basis": ("fp16 dense MFMA 2500 TFLOP/s / 3 fp16 products per fp32 MAC (the six-product bf16x3 form of rounds 2-4 "
