@@ -213,6 +213,7 @@ def conv2d(plan, x, x2=None, act=ACT_NONE, res=None, res_mode=0, act2=ACT_NONE, 
 
 CONV_CHAIN = os.environ.get("MOTIF_CONV_CHAIN", "1") != "0"     # residual chains as ONE persistent launch where the shape allows it
 CONV_CHAIN_MIN_TILES = int(os.environ.get("MOTIF_CONV_CHAIN_MIN_TILES", "0"))      # 0: one tile per CU and layer (256 on an MI355X)
+CONV_CHAIN_BYTES = int(os.environ.get("MOTIF_CONV_CHAIN_BYTES", str(280 << 20)))      # working set of one chain launch (three rotating buffers)
 _chain_tables = {}
 
 
@@ -243,6 +244,17 @@ def resblock_chain(blocks, x, out=None, act=ACT_RELU, last_act=ACT_NONE):
             lastb = i == len(blocks) - 1
             y = conv2d(p2, conv2d(p1, y, act=act), act=last_act if lastb else ACT_NONE, res=y, res_mode=1, out=out if lastb else None)
         return y
+    # the chain's three rotating buffers (+ input / output) live in the 256 MB memory-side cache while they fit: 9 images of 64 x 180 x 320
+    # as one chain took 1.11 ms per image against 0.96 for 3 or 6 (tools/chain_time.py) -- larger batches run as several chains
+    per = 3 * c * h * w * 4
+    nmax = max(1, CONV_CHAIN_BYTES // per)
+    if n > nmax:
+        for i0 in range(0, n, nmax):
+            i1 = min(n, i0 + nmax)
+            di = blocks[0][0].desc(i1 - i0, h, w, c)
+            wi = lib.motif_conv2d_chain_ws_words(ctypes.byref(di), L)
+            conv2d_chain(blocks, x[i0:i1], out[i0:i1], act, di, wi, last_act)
+        return out
     return conv2d_chain(blocks, x, out, act, d, words, last_act)
 
 

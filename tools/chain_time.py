@@ -8,7 +8,7 @@ dev = "cuda"
 ops.CONV_CHAIN_MIN_TILES = 1
 def mk(c, nb):
     return [tuple(ops.ConvPlan(torch.randn(c, c, 3, 3, device=dev) / (3 * c ** 0.5), torch.randn(c, device=dev) * 0.1, 1, 1, 1, 1, 0) for _ in range(2)) for _ in range(nb)]
-for (n, h, w, nb) in ((3, 180, 320, 40), (2, 180, 320, 5), (1, 90, 160, 40)):
+for (n, h, w, nb) in ((3, 180, 320, 40), (6, 180, 320, 40), (9, 180, 320, 40), (2, 180, 320, 5), (1, 90, 160, 40)):
     blocks = mk(64, nb); x = torch.randn(n, 64, h, w, device=dev)
     res = []
     for flag in (False, True):
