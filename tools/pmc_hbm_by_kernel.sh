@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_hbm_$c
-  timeout 400 rocprofv3 --pmc $c -d $R/gpurun_out/pmc_hbm_$c -o t --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --streams 1 --no-fp32-leg --no-cpu-baseline --no-roofline --no-pwc --no-streams1 > /dev/null 2>&1
+  timeout 400 rocprofv3 --pmc $c -d $R/gpurun_out/pmc_hbm_$c -o t --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --streams 1 --batch 1 --no-fp32-leg --no-cpu-baseline --no-roofline --no-pwc --no-streams1 > /dev/null 2>&1
 done
 python3 - $R/gpurun_out/pmc_hbm_FETCH_SIZE $R/gpurun_out/pmc_hbm_WRITE_SIZE <<'PY'
 import csv, sys, glob, collections

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/pmc_util
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA \
-    -d $R/gpurun_out/pmc_util -o t --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --streams 1 --no-fp32-leg --no-cpu-baseline --no-roofline --no-pwc --no-streams1 > /dev/null 2>&1
+    -d $R/gpurun_out/pmc_util -o t --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --streams 1 --batch 1 --no-fp32-leg --no-cpu-baseline --no-roofline --no-pwc --no-streams1 > /dev/null 2>&1
 python3 - $R/gpurun_out/pmc_util <<'PY'
 import csv, sys, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
