@@ -231,13 +231,19 @@ int motif_conv2d_fwd_multi(const MotifConvDesc* d, int P, const float* const* in
  * a tile starts when the <= 9 tiles of the layer before that it reads have been published (conv_wino.hip, CHAIN).
  *   d        shape and arithmetic of EVERY layer: mma = 7, groups 1, C1 = 0, 49 <= C0 = Cout <= 64, W % 4 == 0; d->act /
  *            res_mode are ignored (per layer below); d->in0_bs / out_bs = batch strides of x / out (0 = dense); d->status as usual,
- *            bit 1 = the chain did not advance for a second and was abandoned (results invalid; never seen in testing).
+ *            bit 1 = NO tile of the chain was published for a second (a stalled device; a workgroup that merely waits long while
+ *            other workgroups advance does not give up) and the launch was abandoned: results invalid; never seen in operation.
+ *            bit 2 = the layer table names a buffer the call does not provide (see `work_floats`), writes x, or has no source:
+ *            nothing was read or written.  With d->status = NULL either condition TRAPS the launch (the stream reports a
+ *            launch failure at its next synchronisation): an abandoned chain never looks like a finished one.
  *   layers   DEVICE array of L entries.  Buffer ids: 0 = x (never written), 1 = out, 2 + i = scratch buffer i =
- *            work + i * N * C * H * W (dense NCHW).  The caller orders the buffers so that a layer overwrites a buffer only
+ *            work + i * N * C * H * W (dense NCHW), valid for i < work_floats / (N * C * H * W) -- checked on the device
+ *            (the table is a device array) by a one-block kernel in front of the launch.  The caller orders the buffers so that a layer overwrites a buffer only
  *            when all its readers are producers-of-producers of the writing tile; the rotation of a residual trunk
  *            (conv1: X_b -> T; conv2: T (+ X_b) -> X_b+1, X alternating between two buffers) satisfies it with three buffers.
  *   ws       device scratch of motif_conv2d_chain_ws_words(d, L) 32-bit words (<= 0: this shape cannot run as a chain:
- *            call the layers one by one); zeroed by the entry on `stream` before the launch.
+ *            call the layers one by one); zeroed by the entry on `stream` before the launch.  Word 0 = ticket counter, 1 = abort
+ *            word, 2 = tiles published so far, 64.. = completion counters.
  * 16-byte aligned pointers; all on `stream`. */
 typedef struct MotifChainLayer {
     const float* packed;      /* motif_conv2d_pack blob of the layer (same desc but for the epilogue fields) */
@@ -338,6 +344,11 @@ int motif_instance_norm(const float* x, const float* res, float* out, int NC, in
 /* same, with a caller-owned fp64 workspace of NC*(2+128) doubles: large planes are split over many workgroups, both moments
  * in one pass over the tensor (fp64 sum and sum of squares) */
 int motif_instance_norm_ws(const float* x, const float* res, float* out, double* workspace, int NC, int HW, int mode, void* stream);
+/* InstanceNorm2d(C, affine=True): y = (x - mean) / sqrt(var + 1e-5) * gamma[c] + beta[c] per (image, channel) plane of x [N,C,HW].
+ * Replaces torch.nn.InstanceNorm2d(3, affine=True) at OpticalFlow/PWCNet_light.py:18 (applied at :259-260).  workspace as
+ * motif_instance_norm_ws (N*C*(2+128) doubles; NULL = one block per plane).  (ABI 9) */
+int motif_instance_norm_affine_ws(const float* x, const float* gamma, const float* beta, float* out, double* workspace,
+                                  int N, int C, int HW, void* stream);
 /* InstanceNorm whose statistics span several processes (one clip tiled over GPUs, SURVEY.md 8(e) row 3: "all_reduce of per-channel
  * sum x, sum x^2 for each of the 21 InstanceNorm layers of fnet", extractor.py:85-90,206-207): moments over the rows [row_lo,row_hi) a rank
  * owns -> sums [NC][3] doubles (sum, sum of squares, element count); the caller all-reduces them (SUM); apply normalises the whole

@@ -63,6 +63,7 @@ _SIGS = {
     "motif_reliability_fwd": (c_int, [P, P, c_long, P, P, P, P, c_int, c_int, c_int, P]),
     "motif_instance_norm": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "motif_instance_norm_ws": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "motif_instance_norm_affine_ws": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     "motif_instance_norm_moments": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "motif_instance_norm_apply": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "motif_avg_pool2": (c_int, [P, P, c_int, c_int, c_int, P]),
@@ -74,7 +75,7 @@ _SIGS = {
     "motif_flow_roundtrip": (c_int, [P, P, c_int, c_long, c_float, c_float, P]),
     "motif_deconv4x4s2": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
 }
-ABI_VERSION = 8          # include/motif_hip.h / api.hip: motif_abi_version()
+ABI_VERSION = 9          # include/motif_hip.h / api.hip: motif_abi_version()
 EXPORTS = tuple(_SIGS)
 
 

@@ -2,7 +2,7 @@
 #include "common.h"
 #include <string.h>
 
-extern "C" int motif_abi_version(void) { return 8; }   // 8: motif_conv2d_chain_fwd / motif_conv2d_chain_ws_words (conv_wino.hip, chain mode); 7: range status word (MotifConvDesc.status, `status` argument of motif_dcn_v2_fused_fwd_multi / motif_siren_synth_fwd / motif_siren_synth_pre_fwd), scaled low activation part in the two-part fp16 form; 6: MotifConvDesc.mma = 7 and the two-part fp16 forms (conv_wino.hip, siren_split.hip: motif_siren_pack_split mode + 8, pre = 3, `pre` argument of motif_siren_synth_pre_fwd); 5: option pp_rp removed, conv_engine 5 / 6 (conv_wino.hip), packed 3x3 blobs carry a Winograd block; 4: motif_siren_imnet_add_fwd, g_lr = NULL in motif_splat_motif_pre_fwd, siren split blobs in turns; 3: motif_set_option / motif_get_option (2: MotifConvDesc.mma, motif_siren_pack_split + pre=2, splat row0)
+extern "C" int motif_abi_version(void) { return 9; }   // 9: motif_instance_norm_affine_ws (PWCNet_light), status bit 2 / trap of motif_conv2d_chain_fwd; 8: motif_conv2d_chain_fwd / motif_conv2d_chain_ws_words (conv_wino.hip, chain mode); 7: range status word (MotifConvDesc.status, `status` argument of motif_dcn_v2_fused_fwd_multi / motif_siren_synth_fwd / motif_siren_synth_pre_fwd), scaled low activation part in the two-part fp16 form; 6: MotifConvDesc.mma = 7 and the two-part fp16 forms (conv_wino.hip, siren_split.hip: motif_siren_pack_split mode + 8, pre = 3, `pre` argument of motif_siren_synth_pre_fwd); 5: option pp_rp removed, conv_engine 5 / 6 (conv_wino.hip), packed 3x3 blobs carry a Winograd block; 4: motif_siren_imnet_add_fwd, g_lr = NULL in motif_splat_motif_pre_fwd, siren split blobs in turns; 3: motif_set_option / motif_get_option (2: MotifConvDesc.mma, motif_siren_pack_split + pre=2, splat row0)
 
 extern "C" int motif_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len) {
     int dev = 0;

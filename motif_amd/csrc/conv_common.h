@@ -25,7 +25,7 @@ struct ChainLayerDev { const float* packed; const float* bias; int src, dst, res
 struct ChainArgs {
     const ChainLayerDev* layers;
     float* work; long buf_floats;      // scratch buffer id i at work + (i - 2) * buf_floats, contiguous NCHW
-    unsigned* ws;                      // [0] ticket counter, [1] abort word, [64 + (layer * N + image) * tile rows + tile row] completed tiles of that row; zeroed before the launch
+    unsigned* ws;                      // [0] ticket counter, [1] abort word, [2] tiles published so far (progress: the abort clock restarts when it moves), [64 + (layer * N + image) * tile rows + tile row] completed tiles of that row; zeroed before the launch
     long wp_off;                       // floats from a layer's packed blob to its Winograd block
     int L;
 };

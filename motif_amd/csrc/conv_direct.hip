@@ -334,7 +334,9 @@ int motif_conv_direct_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStre
         dim3 grid((unsigned)((quads + 63) / 64), 1, d->N * P);
         // few workgroups and a long reduction (PWC-Net's flow heads on the coarse levels): 16 slices, four channels' loads in flight
         const int Cin = d->C0 + d->C1;
-        const bool tiny = d->KH == 3 && d->Cout <= 2 && (long)grid.x * grid.z < 512 && Cin >= 256;
+        // (decided from per-IMAGE quantities only: the slice count is the number of terms of the fixed-order partial-sum reduction, and an image
+        // of a batch must come out with the bits it has when run alone)
+        const bool tiny = d->KH == 3 && d->Cout <= 2 && (long)grid.x < 512 && Cin >= 256;
         auto region = [&](int ns, int nco) {               // 16-byte units per slice: its weights (3x3) or its partial sums, whichever is larger
             const int per = ((Cin + ns - 1) / ns + 1) & ~1;
             const int wq = d->KH == 3 ? (per * 9 * nco + 3) / 4 : 0;

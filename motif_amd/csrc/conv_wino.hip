@@ -387,31 +387,41 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, const int ntil
         return c1 == chain_rows_want();
     };
     // between tiles only (nothing of this workgroup in flight, so waiting here can block nobody this workgroup could unblock); bounded: a chain
-    // that does not advance for a second sets the abort word and status bit 1 instead of hanging the device
+    // in which NO tile of ANY workgroup has been published for a second (word 2 of the workspace counts published tiles: the clock restarts
+    // whenever it has moved, so a workgroup that merely waits long for its turn -- pre-emption, a debugger, another stream's kernels on the
+    // CUs -- does not give up while the chain advances) sets the abort word and status bit 1 instead of hanging the device.  Without a status
+    // word the launch traps: an abandoned chain must never look like a finished one.
     auto chain_wait = [&]() __attribute__((always_inline)) {
-        const long long t0 = __builtin_amdgcn_s_memrealtime();              // 100 MHz
+        unsigned t0 = (unsigned)__builtin_amdgcn_s_memrealtime();     // 100 MHz; the low word (differences are taken modulo 2^32 = 43 s)
+        int prog = -1;
+        auto give_up = [&]() __attribute__((always_inline)) {
+            if (lane_now() == 0) {
+                __hip_atomic_store(ch.ws + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.status) atomicOr(a.status, 2u); else asm volatile("s_trap 2");      // (not __builtin_trap: a no-return call in a divergent branch makes every value live across it a vector value)
+            }
+        };
+        if (a.dbg & 128) { give_up(); return false; }    // option conv_dbg bit 7: every workgroup gives up at its first tile -- the test of this path
         for (;;) {
             chain_rows_issue();
             if (chain_rows_take()) return true;
-            int ab;
+            int ab, pg;
             CHAIN_SADD("s101", 4, 0);                    // (s100 may hold a ticket in flight)
             CHAIN_STAKE("s101", ab);
             if (ab) return false;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ll) {
-                if (lane_now() == 0) {
-                    __hip_atomic_store(ch.ws + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (a.status) atomicOr(a.status, 2u);
-                }
-                return false;
-            }
+            CHAIN_SADD("s101", 8, 0);
+            CHAIN_STAKE("s101", pg);
+            const unsigned now = (unsigned)__builtin_amdgcn_s_memrealtime();
+            if (pg != prog) { prog = pg; t0 = now; }
+            if (now - t0 > 100000000u) { give_up(); return false; }
             __builtin_amdgcn_s_sleep(4);
         }
     };
     int cur_row = 0, cur_ty = 0, pend_row = 0, pend_ty = 0, fut_row = 0, fut_ty = 0;     // completion word / tile row of the current tile, the next, the one after
-    auto chain_publish = [&](int row, int ty) __attribute__((always_inline)) {      // lanes 0 .. 2: words row - 1, row, row + 1 (one atomic instruction)
+    auto chain_publish = [&](int row, int ty) __attribute__((always_inline)) {      // lanes 0 .. 2: words row - 1, row, row + 1; lane 3: the progress count (one atomic instruction)
         const int lc = lane_now();
-        const bool on = lc < 3 && (lc != 0 || ty > 0) && (lc != 2 || ty + 1 < tiles_y);
-        if (on) __hip_atomic_fetch_add(ch.ws + 64 + row + lc - 1, lc == 0 ? 1u : lc == 1 ? 1u << 10 : 1u << 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool on = lc < 4 && (lc != 0 || ty > 0) && (lc != 2 || ty + 1 < tiles_y);
+        const int word = lc == 3 ? 2 : 64 + row + lc - 1;                   // (an index on the uniform base: nothing 64-bit per lane to keep alive over the tile loop)
+        if (on) __hip_atomic_fetch_add(ch.ws + word, lc == 0 ? 1u : lc == 1 ? 1u << 10 : lc == 2 ? 1u << 20 : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // activations / residuals of a chain come from other XCDs inside this launch: device-coherent (sc1) accesses
     auto rload = [&](const float* base, unsigned off_elems) __attribute__((always_inline)) {
@@ -1349,6 +1359,26 @@ int motif_conv_wino_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream
 }
 
 // ---- chain mode (motif_conv2d_chain_fwd) -----------------------------------------------------------------------------------------
+// One block in front of the chain launch: zeroes the workspace (ticket, abort word, progress count, completion counters) and checks the
+// caller's layer table -- a DEVICE array the host entry cannot read -- against the scratch buffers the caller's workspace really holds
+// (ids 2 .. 1 + nbuf), that no layer writes x and that every layer has a source.  A bad table poisons the ticket counter: every workgroup
+// of the chain launch draws a ticket beyond the last tile and leaves before anything is read or written; status bit 2 reports it (without
+// a status word the launch traps -- it must not look like a finished one).
+__global__ __launch_bounds__(256) void conv_wino_chain_prepare_kernel(unsigned* ws, int words, const ChainLayerDev* layers, int L, int nbuf, unsigned* status) {
+    for (int i = threadIdx.x; i < words; i += 256) ws[i] = 0u;
+    int bad = 0;
+    for (int l = threadIdx.x; l < L; l += 256) {
+        const u32x4 q1 = *((const u32x4*)layers + 2 * l + 1);
+        const int ids = (int)q1[0], idd = (int)q1[1], idr = (int)q1[2];
+        bad |= (int)(ids < 0 || ids >= 2 + nbuf) | (int)(idd < 1 || idd >= 2 + nbuf) | (int)(idr >= 2 + nbuf);
+    }
+    if (__syncthreads_or(bad) && threadIdx.x == 0) {
+        ws[0] = 0x40000000u;
+        ws[1] = 1u;
+        if (status) atomicOr(status, 4u); else asm volatile("s_trap 2");
+    }
+}
+
 static_assert(sizeof(ChainLayerDev) == sizeof(MotifChainLayer) && sizeof(MotifChainLayer) == 32, "the device table is read as two 16-byte quads");
 
 static bool wino_chain_shape_ok(const MotifConvDesc* d, int L, long* tiles) {
@@ -1380,6 +1410,10 @@ extern "C" int motif_conv2d_chain_fwd(const MotifConvDesc* d, int L, const Motif
     if ((((unsigned long long)x | (unsigned long long)out | (unsigned long long)work | (unsigned long long)layers) & 15) || ((bsx | bso) & 3)) return MOTIF_EINVAL;
     if (bsx < 0 || bso < 0 || bsx * 4 >= (1L << 32) || bso * 4 >= (1L << 32) || (long)d->N * plane * 4 >= (1L << 40)) return MOTIF_ELIMIT;      // batch strides in bytes are 32-bit table fields
     if (work_floats < 0 || (work_floats > 0 && !work)) return MOTIF_EINVAL;
+    // scratch buffers the caller's workspace holds: ids 2 .. 1 + nbuf are valid in the (device-resident) layer table; the kernel checks every id
+    // against it when it resolves the table and reports a bad one through status bit 2 (all workgroups leave before anything is written)
+    const long nbuf_l = work ? work_floats / ((long)d->N * plane) : 0;
+    const int nbuf = (int)(nbuf_l > 64 ? 64 : nbuf_l);
     hipStream_t s = (hipStream_t)stream;
     ConvArgs a = {};
     a.in0[0] = x; a.out[0] = out; a.in0_bs[0] = bsx; a.out_bs[0] = bso;
@@ -1406,8 +1440,7 @@ extern "C" int motif_conv2d_chain_fwd(const MotifConvDesc* d, int L, const Motif
     const size_t ldsc = ldsb + (size_t)L * 64 + (size_t)T * 4;          // + the resolved layer table and the tile decode table
     hipError_t e = hipFuncSetAttribute((const void*)conv_wino_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(ws, 0, (size_t)(64 + (long)L * d->N * tiles_y) * 4, s);
-    if (e != hipSuccess) return (int)e;
+    conv_wino_chain_prepare_kernel<<<1, 256, 0, s>>>(ws, (int)(64 + (long)L * d->N * tiles_y), (const ChainLayerDev*)layers, L, nbuf, d->status);
     conv_wino_chain_kernel<<<dim3(G, 1, 1), 256, ldsc, s>>>(a, (int)T, tiles_y, ch);
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;

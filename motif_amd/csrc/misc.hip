@@ -309,8 +309,10 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
     return t;
 }
 
+// gamma / beta (may be NULL; C channels, plane = image * C + channel): InstanceNorm2d(affine=True), y = x_hat * gamma[c] + beta[c]
 __global__ __launch_bounds__(1024) void instance_norm_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                            float* __restrict__ out, int HW, int mode) {
+                                                            float* __restrict__ out, int HW, int mode,
+                                                            const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr, int C = 1) {
     __shared__ float sh[16];
     const long base = (long)blockIdx.x * HW;
     float s = 0.f;
@@ -320,8 +322,10 @@ __global__ __launch_bounds__(1024) void instance_norm_kernel(const float* __rest
     for (int i = threadIdx.x; i < HW; i += blockDim.x) { const float d = x[base + i] - mean; q += d * d; }
     const float var = block_sum(q, sh) / (float)HW;
     const float inv = 1.0f / sqrtf(var + 1e-5f);
+    const float ga = gamma ? gamma[blockIdx.x % C] : 1.f, be = gamma ? beta[blockIdx.x % C] : 0.f;
     for (int i = threadIdx.x; i < HW; i += blockDim.x) {
         float v = (x[base + i] - mean) * inv;
+        if (gamma) v = v * ga + be;
         if (mode >= 1) v = v > 0.f ? v : 0.f;
         if (mode == 2) { v += res[base + i]; v = v > 0.f ? v : 0.f; }
         out[base + i] = v;
@@ -360,7 +364,8 @@ __global__ void in_reduce_kernel(const double* __restrict__ part, double* __rest
 // moments kernel wrote: thread 0 adds them in slice order (the order the former reduce kernel used: same bits) -- one launch less.
 __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                       const double* __restrict__ stats, float* __restrict__ out, int HW, int mode,
-                                                      const double* __restrict__ part, int S) {
+                                                      const double* __restrict__ part, int S,
+                                                      const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr, int C = 1) {
     const int plane = blockIdx.y;
     const long base = (long)plane * HW;
     __shared__ double st[2];
@@ -376,6 +381,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__
     const float mean = (float)((part ? st[0] : stats[plane * 2]) / (double)HW);
     const float var = (float)((part ? st[1] : stats[plane * 2 + 1]) / (double)HW);
     const float inv = 1.0f / sqrtf(var + 1e-5f);
+    const float ga = gamma ? gamma[plane % C] : 1.f, be = gamma ? beta[plane % C] : 0.f;
     // 16 bytes per lane where the plane allows it (4-byte accesses cost the same vector-memory instruction for a quarter of the bytes)
     const bool v4 = (HW & 3) == 0 && ((((unsigned long long)(x + base)) | ((unsigned long long)(out + base)) | (mode == 2 ? (unsigned long long)(res + base) : 0ull)) & 15) == 0;
     if (v4) {
@@ -387,6 +393,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float t = (v[e] - mean) * inv;
+                if (gamma) t = t * ga + be;
                 if (mode >= 1) t = t > 0.f ? t : 0.f;
                 if (mode == 2) { t += r[e]; t = t > 0.f ? t : 0.f; }
                 v[e] = t;
@@ -397,6 +404,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__
     }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
         float v = (x[base + i] - mean) * inv;
+        if (gamma) v = v * ga + be;
         if (mode >= 1) v = v > 0.f ? v : 0.f;
         if (mode == 2) { v += res[base + i]; v = v > 0.f ? v : 0.f; }
         out[base + i] = v;
@@ -461,6 +469,25 @@ extern "C" int motif_instance_norm_ws(const float* x, const float* res, float* o
     double* part = workspace + 2L * NC;      // [NC][S][2]
     in_moments_kernel<<<dim3(S, NC), 256, 0, s>>>(x, part, HW, S);
     in_apply_kernel<<<dim3(S, NC), 256, 0, s>>>(x, res, stats, out, HW, mode, part, S);      // every block adds the S partials itself
+    MOTIF_LAUNCH_CHECK();
+    return MOTIF_OK;
+}
+
+// InstanceNorm2d(C, affine=True) (PWCNet_light's input normalisation, OpticalFlow/PWCNet_light.py:18,259-260): the kernels above with
+// y = x_hat * gamma[c] + beta[c]; x [N,C,HW] dense.  workspace as motif_instance_norm_ws (may be NULL: one block per plane).
+extern "C" int motif_instance_norm_affine_ws(const float* x, const float* gamma, const float* beta, float* out, double* workspace, int N, int C, int HW, void* stream) {
+    if (!x || !gamma || !beta || !out || N < 1 || C < 1 || HW < 1) return MOTIF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int NC = N * C;
+    int S = 1024 / NC;
+    if (S > HW / 4096) S = HW / 4096;
+    if (S > 64) S = 64;
+    if (!workspace || S < 2) instance_norm_kernel<<<NC, 1024, 0, s>>>(x, nullptr, out, HW, 0, gamma, beta, C);
+    else {
+        double* part = workspace + 2L * NC;
+        in_moments_kernel<<<dim3(S, NC), 256, 0, s>>>(x, part, HW, S);
+        in_apply_kernel<<<dim3(S, NC), 256, 0, s>>>(x, nullptr, workspace, out, HW, 0, part, S, gamma, beta, C);
+    }
     MOTIF_LAUNCH_CHECK();
     return MOTIF_OK;
 }

@@ -62,9 +62,19 @@ __device__ __forceinline__ float sub_f16_hi(float x, unsigned pk) { float r; asm
 template <int NP>
 __device__ __forceinline__ void split_pair(float x0, float x1, u32x4 (&out)[NP], int q) {
     if constexpr (NP == 2) {
+        // hi = rne16(x); lo = rne16(x - hi) by ONE mixed-precision FMA per value that rounds straight into its half of the packed register
+        // (v_fma_mixlo / mixhi_f16: half * -1.0 + x; x - hi is exact in fp32, so this is the single rounding the two-step form
+        // [v_fma_mix_f32, v_cvt_pk_f16_f32] made: the same bits, three instructions per pair instead of four -- round 6)
         const unsigned hi = pk_f16(x0, x1);
         out[0][q] = hi;
+#ifdef SIREN_SPLIT4
         out[1][q] = pk_f16(sub_f16_lo(x0, hi), sub_f16_hi(x1, hi));
+#else
+        unsigned lo;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(x0));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(x1));
+        out[1][q] = lo;
+#endif
     } else {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {

@@ -30,14 +30,22 @@ _GRID_CACHE = {}
 
 
 def coords_grid(batch, ht, wd, device):
-    """utils.py:75-78; a constant of (batch, size, device): built once, handed out read-only (callers clone what they update)."""
+    """utils.py:75-78; a constant of (batch, size, device): built once, handed out read-only (callers clone what they update).  Shared by
+    every model instance and stream of the process, hence: built under a host wait (the kernels that fill it run on the building stream;
+    without the wait another instance's stream could read it half-written), and evicted only after a device-wide wait (a launch of any
+    stream may still be reading the entry)."""
     key = (batch, ht, wd, str(device))
     g = _GRID_CACHE.get(key)
     if g is None:
         ys, xs = torch.meshgrid(torch.arange(ht, device=device), torch.arange(wd, device=device), indexing="ij")
-        g = _GRID_CACHE[key] = torch.stack([xs, ys], dim=0).float()[None].repeat(batch, 1, 1, 1).contiguous()
-        if len(_GRID_CACHE) > 16:
-            _GRID_CACHE.pop(next(iter(_GRID_CACHE)))
+        g = torch.stack([xs, ys], dim=0).float()[None].repeat(batch, 1, 1, 1).contiguous()
+        if g.is_cuda:
+            torch.cuda.current_stream(g.device).synchronize()
+        if len(_GRID_CACHE) >= 16:
+            if g.is_cuda:
+                torch.cuda.synchronize(g.device)
+            _GRID_CACHE.clear()
+        _GRID_CACHE[key] = g
     return g
 
 

