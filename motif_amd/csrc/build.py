@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), "libmotif_hip.so")
-SOURCES = ["api.hip", "conv_igemm.hip", "conv_split.hip", "conv_split2.hip", "conv_wino.hip", "conv_pw.hip", "conv_direct.hip", "siren.hip", "siren_split.hip", "splat.hip", "misc.hip", "corr.hip", "dcn.hip"]
+SOURCES = ["api.hip", "conv_igemm.hip", "conv_split.hip", "conv_split2.hip", "conv_wino.hip", "conv_pw.hip", "conv_ig16.hip", "conv_direct.hip", "siren.hip", "siren_split.hip", "splat.hip", "misc.hip", "corr.hip", "dcn.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value",
          "-Wno-pass-failed"]
 

@@ -234,3 +234,9 @@ int motif_conv_direct_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStre
 // round-4 kernel (conv_pw.hip): 1x1 layers on the fp16 matrix cores (two-part split, mma = 7), reading the fp32 engine's packed block
 bool motif_conv_pw_eligible(const MotifConvDesc* d, const ConvArgs& a, int P);
 int motif_conv_pw_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStream_t s);
+// round-6 kernel (conv_ig16.hip): every other layer shape (stride 2, 7x7, dilated, narrow / wide) on the fp16 matrix cores, mma = 7; its
+// fp16 fragment block follows the fp32 block in the packed blob
+bool motif_conv_ig16_pack_eligible(const MotifConvDesc* d);
+long motif_conv_ig16_packed_floats(const MotifConvDesc* d);
+int motif_conv_ig16_pack(const MotifConvDesc* d, const float* weight, float* packed16, hipStream_t s);
+int motif_conv_ig16_launch(const MotifConvDesc* d, ConvArgs& a, int P, long fp32_block_floats, hipStream_t s);

@@ -333,7 +333,8 @@ extern "C" long motif_conv2d_packed_size(const MotifConvDesc* d) {
     if (motif_conv_split_eligible(d)) return motif_conv_split_packed_floats(d);
     ConvPlan p;
     if (!plan_conv(d, &p)) return MOTIF_EINVAL;
-    return (long)d->groups * p.ncg * p.Kpad * p.WN;
+    // mma = 7: the fp16 fragment block of conv_ig16.hip follows the fp32 block (which conv_direct / conv_pw / the fp32 fall-back keep reading)
+    return (long)d->groups * p.ncg * p.Kpad * p.WN + (motif_conv_ig16_pack_eligible(d) ? motif_conv_ig16_packed_floats(d) : 0L);
 }
 
 extern "C" int motif_conv2d_pack(const MotifConvDesc* d, const float* weight, float* packed, void* stream) {
@@ -346,6 +347,7 @@ extern "C" int motif_conv2d_pack(const MotifConvDesc* d, const float* weight, fl
     long total = (long)d->groups * p.ncg * p.Kpad * p.WN;
     conv_pack_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(weight, packed, p.Cout_g, p.Cin_g, p.T, p.Kpad, p.ncg, p.WN, total);
     MOTIF_LAUNCH_CHECK();
+    if (motif_conv_ig16_pack_eligible(d)) return motif_conv_ig16_pack(d, weight, packed + total, (hipStream_t)stream);
     return MOTIF_OK;
 }
 
@@ -383,6 +385,10 @@ extern "C" int motif_conv2d_fwd_multi(const MotifConvDesc* d, int P, const float
     a.act = d->act; a.act2 = d->act2; a.act_split = d->act_split; a.res_mode = d->res_mode;
     if (motif_conv_direct_eligible(d, a, P)) return motif_conv_direct_launch(d, a, P, (hipStream_t)stream);      // narrow layer, large map
     if (motif_conv_pw_eligible(d, a, P)) return motif_conv_pw_launch(d, a, P, (hipStream_t)stream);              // 1x1 layer, mma = 7: conv_pw.hip
+    if (motif_conv_ig16_pack_eligible(d)) {                                                                      // everything else, mma = 7: conv_ig16.hip
+        const int rc = motif_conv_ig16_launch(d, a, P, (long)d->groups * p.ncg * p.Kpad * p.WN, (hipStream_t)stream);
+        if (rc != MOTIF_ELIMIT) return rc;               // (a shape it does not fit runs on the fp32 engine below)
+    }
     // 16-byte staging (conv_igemm_kernel VEC) where the layout allows it: rows of whole quads, aligned inputs, zero padding
     bool vec = (d->W & 3) == 0 && d->pad_mode == 0 && !motif_opt(MOTIF_OPT_CONV_NOVEC);
     for (int i = 0; i < P && vec; ++i)

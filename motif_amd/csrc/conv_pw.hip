@@ -34,7 +34,7 @@ __device__ __forceinline__ void pw_split8_act(const float (&v)[8], pw_u32x4& hi,
         const float r0 = pw_sub_lo(v[2 * q], hi[q]), r1 = pw_sub_hi(v[2 * q + 1], hi[q]);
         unsigned d;
         asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(d) : "v"(r0), "s"(s));
-        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(r1), "s"(s));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]\n\ts_nop 0" : "+v"(d) : "v"(r1), "s"(s));      // (one wait state behind a high-half write: hipcc does not look into asm -- siren_split.hip)
         lo[q] = d;
     }
 }

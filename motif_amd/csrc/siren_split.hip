@@ -55,8 +55,18 @@ __device__ __forceinline__ float bf_hi(unsigned p) { return __builtin_bit_cast(f
 
 __device__ __forceinline__ unsigned pk_f16(float a, float b) { const f16x2v h = {(_Float16)a, (_Float16)b}; return __builtin_bit_cast(unsigned, h); }
 // x - (float)half of a packed pair as ONE mixed-precision FMA (half * -1.0 + x; the product by -1 is exact)
-__device__ __forceinline__ float sub_f16_lo(float x, unsigned pk) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x)); return r; }
-__device__ __forceinline__ float sub_f16_hi(float x, unsigned pk) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x)); return r; }
+// s_nop 0 behind every inline-assembly mixed-precision instruction (round 6).  hipcc's hazard recognizer inserts the wait states gfx940+
+// needs between a VALU producer and its consumer -- among them ONE wait state behind an instruction that writes only the high half of its
+// destination (v_fma_mixhi_f16: LLVM's "dst_sel forwarding hazard") -- for its own instructions, but it does not look into an asm
+// statement.  Without the wait state the consumer that happens to sit in the next issue slot reads the register's OLD contents, depending on
+// how the two waves of the SIMD interleave: the flow kernel was irreproducible from run to run (a third of the pixels by up to 4e-6; found when
+// an unrelated change moved the code object and tests/test_model_gpu.py::test_default_precontracted_stage... began to fail; it is also what
+// round 5 met as "the sine without its fract is not reproducible").  tools/_dbg variants: nops in FRONT of the asm statements change nothing,
+// one wait state BEHIND them makes 6 runs x 3 stagger settings bit-identical, at no measurable cost (0.825 ms either way).
+#define SIREN_ASM_PRE
+#define SIREN_ASM_POST "\n\ts_nop 0"
+__device__ __forceinline__ float sub_f16_lo(float x, unsigned pk) { float r; asm(SIREN_ASM_PRE "v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" SIREN_ASM_POST : "=v"(r) : "v"(pk), "v"(x)); return r; }
+__device__ __forceinline__ float sub_f16_hi(float x, unsigned pk) { float r; asm(SIREN_ASM_PRE "v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" SIREN_ASM_POST : "=v"(r) : "v"(pk), "v"(x)); return r; }
 
 // one value pair -> its NP packed parts
 template <int NP>
@@ -195,8 +205,8 @@ __device__ __forceinline__ void split8_in(const float (&v)[8], u32x4 (&out)[NP])
             const unsigned hi = pk_f16(v[2 * q], v[2 * q + 1]);
             const float r0 = sub_f16_lo(v[2 * q], hi), r1 = sub_f16_hi(v[2 * q + 1], hi);
             unsigned d;
-            asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(d) : "v"(r0), "s"(s));
-            asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(r1), "s"(s));
+            asm(SIREN_ASM_PRE "v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" SIREN_ASM_POST : "=v"(d) : "v"(r0), "s"(s));
+            asm(SIREN_ASM_PRE "v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" SIREN_ASM_POST : "+v"(d) : "v"(r1), "s"(s));
             out[0][q] = hi;
             out[1][q] = d;
         }

@@ -679,7 +679,7 @@ def _dcn_fp64(x, weight, bias, offset, mask, dg):
 
 @pytest.mark.parametrize("ws", [1.0 / 24, 1e-2], ids=["w1/24", "w1e-2"])
 @pytest.mark.parametrize("xs", [1.0, 1e-2, 1e-3, 1e-4], ids=["x1", "x1e-2", "x1e-3", "x1e-4"])
-@pytest.mark.parametrize("layer", ["wino3x3", "pw1x1", "dcn"])
+@pytest.mark.parametrize("layer", ["wino3x3", "pw1x1", "dcn", "ig16_s2", "ig16_7x7s2", "ig16_dil4", "ig16_narrow"])
 def test_two_part_fp16_form_is_fp32_equivalent_at_every_activation_scale(layer, xs, ws, keep_mma):
     """the two-part fp16 form must not depend on the activations being of O(1).  The low activation part is stored
     times 2^11 (a normal fp16 number whenever the high part is one) and meets 2^-11 x the high weight part -- conv_wino.hip,
@@ -703,24 +703,106 @@ def test_two_part_fp16_form_is_fp32_equivalent_at_every_activation_scale(layer, 
             ops.set_conv_mma(mode)
             err[mode] = float((ops.dcn_v2_multi([plan], [x.to(dev())], [om], dg)[0].double().cpu() - ref).abs().max())
     else:
-        cin, k = (64, 3) if layer == "wino3x3" else (128, 1)
-        m = Conv2d(cin, 64, k, 1, k // 2)
+        # (cin, cout, k, stride, pad, dil); the ig16_* layers are conv_ig16.hip's (round 6): stride 2, a 7x7 stem, dilation, 24 -> 24 narrow
+        cin, cout, k, st, pd, dl = {"wino3x3": (64, 64, 3, 1, 1, 1), "pw1x1": (128, 64, 1, 1, 0, 1), "ig16_s2": (64, 64, 3, 2, 1, 1), "ig16_7x7s2": (3, 32, 7, 2, 3, 1),
+                                    "ig16_dil4": (96, 128, 3, 1, 4, 4), "ig16_narrow": (24, 24, 3, 1, 1, 1)}[layer]
+        m = Conv2d(cin, cout, k, st, pd, dl)
         with torch.no_grad():
             m.weight.copy_(rnd(*m.weight.shape, seed=1, scale=ws))
-            m.bias.copy_(rnd(64, seed=2, scale=2.0 * xs * ws))
+            m.bias.copy_(rnd(cout, seed=2, scale=2.0 * xs * ws))
         x = rnd(2, cin, 45, 80, seed=3, scale=xs)
-        ref = F.conv2d(x.double(), m.weight.double(), m.bias.double(), 1, k // 2)
+        ref = F.conv2d(x.double(), m.weight.double(), m.bias.double(), st, pd, dl)
         m = m.to(dev())
         outs = {}
-        for mode in modes:
-            ops.set_conv_mma(mode)
-            outs[mode] = m(x.to(dev())).double().cpu()
-            err[mode] = float((outs[mode] - ref).abs().max())
-        assert not torch.equal(outs[ops.MMA_F16X2], outs[ops.MMA_BF16X3]) and not torch.equal(outs[ops.MMA_F16X2], outs[ops.MMA_FP32]), "mma = 7 ran its own kernel"
+        try:
+            if layer.startswith("ig16"):
+                ops.set_option("conv_engine", 7)             # conv_ig16.hip wherever it fits (the dispatch gives it only the shapes it wins on)
+            for mode in modes:
+                ops.set_conv_mma(mode)
+                outs[mode] = m(x.to(dev())).double().cpu()
+                err[mode] = float((outs[mode] - ref).abs().max())
+        finally:
+            ops.set_option("conv_engine", 0)
+        assert not torch.equal(outs[ops.MMA_F16X2], outs[ops.MMA_FP32]), "mma = 7 ran its own kernel"
+        if not layer.startswith("ig16"):                 # (mma = 6 runs these shapes on the fp32 engine: conv_ig16.hip has the two-part form only)
+            assert not torch.equal(outs[ops.MMA_F16X2], outs[ops.MMA_BF16X3])
     scale = float(ref.abs().max())
     assert err[ops.MMA_FP32] < 3e-6 * scale, (err, scale)
     assert err[ops.MMA_BF16X3] <= 1.25 * err[ops.MMA_FP32] + 1e-7 * scale, (err, scale)
     assert err[ops.MMA_F16X2] <= 1.25 * err[ops.MMA_FP32] + 1e-7 * scale, (err, scale)
+
+
+IG16_CASES = [
+    # cin, cout, k, stride, pad, dil, groups, pad_mode, H, W, N, c0 (two-source split, 0 = one source), act, res_mode, act_split
+    (64, 64, 3, 2, 1, 1, 1, "zeros", 90, 160, 2, 0, "lrelu", 0, 0),          # the PCD / ZSM pyramid layers (Ours.py:141-144): VEC staging, one octet per chunk
+    (64, 64, 3, 2, 1, 1, 1, "zeros", 45, 78, 1, 0, "none", 0, 0),            # W % 4 != 0: scalar staging plan, ragged tiles
+    (3, 32, 7, 2, 3, 1, 1, "zeros", 128, 192, 2, 0, "relu", 0, 0),           # RAFT's stem: 3 real channels of the octet, 25 k-steps
+    (2, 64, 7, 1, 3, 1, 1, "zeros", 24, 40, 2, 0, "relu", 0, 0),             # motion encoder convf1: one cout tile per block (the 7x7 fragments of two do not fit)
+    (128, 128, 3, 1, 2, 2, 1, "zeros", 48, 64, 1, 0, "lrelu", 0, 0),         # PWC-Net's refiner, dilation 2 .. 8
+    (128, 96, 3, 1, 8, 8, 1, "zeros", 48, 64, 1, 0, "lrelu", 0, 0),
+    (96, 64, 3, 1, 16, 16, 1, "zeros", 48, 64, 1, 0, "lrelu", 0, 0),         # dilation 16: the patch of an octet does not fit -> stays on the fp32 engine (same answer)
+    (64, 32, 3, 1, 1, 1, 1, "zeros", 23, 40, 2, 0, "relu", 0, 0),            # 17 .. 32 couts with a short reduction (convf2)
+    (24, 24, 3, 2, 1, 1, 1, "zeros", 90, 160, 2, 0, "none", 2, 0),           # bottleneck conv2 with stride 2, residual after the activation
+    (32, 64, 1, 2, 0, 1, 1, "zeros", 40, 64, 2, 0, "none", 0, 0),            # down-sampling 1x1 stride 2: one tap per octet (half of every k-step empty)
+    (160, 96, 3, 2, 1, 1, 1, "reflect", 20, 28, 1, 64, "tanh", 4, 0),        # two sources (C0 = 64), reflect padding, stride 2, multiplicative residual
+    (14, 64, 3, 1, 1, 1, 2, "zeros", 32, 48, 2, 0, "lrelu", 1, 0),           # groups = 2 with 7 channels each (flow_process[0]), residual before the activation
+    (40, 48, 5, 1, 2, 1, 1, "zeros", 21, 36, 1, 0, "sigmoid", 0, 24),        # 5x5, activation split on a cout boundary
+    (200, 160, 1, 1, 0, 1, 1, "zeros", 19, 33, 1, 0, "relu", 0, 0),          # a 1x1 wider than conv_pw.hip takes
+]
+
+
+@pytest.mark.parametrize("case", IG16_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_ig16_generic_layers_on_the_fp16_cores_match_fp64_and_the_fp32_engine(case, keep_mma):
+    """Round 6: conv_ig16.hip -- stride 2, 7x7, dilated, narrow / wide, grouped, two-source, reflect-padded layers as an
+    implicit GEMM on the fp16 matrix cores with the two-part arithmetic.  Against fp64 with the bound every split kernel is held to
+    (error <= 1.25 x the fp32-MFMA engine's + 1e-7 of the output scale), and the launch must really have taken the new kernel (option
+    conv_engine = 6 = "fp32 engine for these shapes" gives other bits) except where the shape does not fit it."""
+    from motif_amd import ops
+    from motif_amd.models.modules.layers import Conv2d
+    cin, cout, k, st, pd, dl, groups, pm, H, W, N, c0, actn, rm, asplit = case
+    acts = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "tanh": ops.ACT_TANH, "sigmoid": ops.ACT_SIGMOID}
+    fact = {"none": lambda v: v, "relu": F.relu, "lrelu": lambda v: F.leaky_relu(v, 0.1), "tanh": torch.tanh, "sigmoid": torch.sigmoid}[actn]
+    m = Conv2d(cin, cout, k, st, pd, dl, groups, True, pm)
+    with torch.no_grad():
+        m.weight.copy_(rnd(*m.weight.shape, seed=1, scale=1.0 / math.sqrt(cin * k * k / groups)))
+        m.bias.copy_(rnd(cout, seed=2, scale=0.1))
+    x = rnd(N, cin, H, W, seed=3)
+    xp = F.pad(x.double(), (pd,) * 4, mode="reflect") if pm == "reflect" else x.double()
+    y = F.conv2d(xp, m.weight.double(), m.bias.double(), st, 0 if pm == "reflect" else pd, dl, groups)
+    res = rnd(*y.shape, seed=4)
+    r = res.double()
+    if rm == 1: y = y + r
+    y = torch.cat([fact(y[:, :asplit]), F.relu(y[:, asplit:])], 1) if asplit else fact(y)
+    if rm == 2: y = y + r
+    elif rm == 4: y = y * r
+    m = m.to(dev())
+    xd, rd = x.to(dev()), res.to(dev())
+    args = (xd[:, :c0].contiguous(), xd[:, c0:].contiguous()) if c0 else (xd, None)
+    kw = dict(act=acts[actn], res=rd if rm else None, res_mode=rm)
+    if asplit: kw.update(act2=ops.ACT_RELU, act_split=asplit)
+    outs = {}
+    try:
+        ops.set_conv_mma(ops.MMA_F16X2)
+        ops.set_option("conv_engine", 7)                 # the new kernel wherever the shape FITS (the default dispatch: only where it also pays)
+        outs["f16x2"] = m(*args, **kw).double().cpu()
+        ops.set_option("conv_engine", 6)
+        outs["forced_fp32_engine"] = m(*args, **kw).double().cpu()
+        ops.set_option("conv_engine", 0)
+        ops.set_conv_mma(ops.MMA_FP32)
+        outs["fp32"] = m(*args, **kw).double().cpu()
+    finally:
+        ops.set_option("conv_engine", 0)
+    scale = float(y.abs().max())
+    err = {kk: float((v - y).abs().max()) for kk, v in outs.items()}
+    assert err["fp32"] < 3e-6 * scale * max(1.0, math.sqrt(cin * k * k / groups / 600.0)), (err, scale)
+    assert err["f16x2"] <= 1.25 * err["fp32"] + 1e-7 * scale, (err, scale)
+    fits = not (dl == 16)                                # an octet's patch at dilation 16 is 20 480 floats: beyond one LDS buffer
+    assert torch.equal(outs["f16x2"], outs["forced_fp32_engine"]) != fits, "the launch did not take the kernel it should: %s" % (err,)
+    # the default dispatch: the layers named in conv_ig16.hip's rule (>= 24 channels per group and stride / dilation / width) take it, the others do not
+    pays = cin // groups >= 24 and (cin // groups * k * k >= 200 or cin // groups >= 64) and (st > 1 or dl > 1 or cin // groups >= 64 or cout // groups >= 48)
+    ops.set_conv_mma(ops.MMA_F16X2)
+    default = m(*args, **kw).double().cpu()
+    assert torch.equal(default, outs["f16x2"] if (pays and fits) else outs["forced_fp32_engine"])
 
 
 def test_range_status_word_is_set_by_the_kernel_that_meets_an_out_of_range_operand(keep_mma):
@@ -756,6 +838,16 @@ def test_range_status_word_is_set_by_the_kernel_that_meets_an_out_of_range_opera
     assert fired(lambda: m3(xb))[0] == 1
     xb = x1.clone(); xb[1, 127, 18, 32] = 7.0e4
     assert fired(lambda: m1(xb))[0] == 1
+    # conv_ig16.hip (round 6): a stride-2 3x3 layer; the out-of-range value sits where only ONE output pixel's window covers it
+    ms = Conv2d(64, 64, 3, 2, 1)
+    with torch.no_grad():
+        ms.weight.copy_(rnd(*ms.weight.shape, seed=9, scale=1.0 / 24)); ms.bias.zero_()
+    ms = ms.to(dev())
+    assert fired(lambda: ms(x3))[0] == 0
+    for val, where in ((1.0e5, (1, 63, 36, 51)), (-7.0e4, (0, 0, 0, 0)), (float("inf"), (1, 17, 21, 31))):
+        xb = x3.clone(); xb[where] = val
+        flag, out = fired(lambda: ms(xb))
+        assert flag == 1 and not bool(torch.isfinite(out).all()), (val, where)
     # no word: nothing to write, nothing breaks; mma = 6 computes the same layers in range
     xb = x3.clone(); xb[0, 3, 3, 3] = 1.0e5
     m3(xb)
