@@ -1,36 +1,37 @@
 #!/usr/bin/env python3
 """Benchmark of the MoTIF C-STVSR hot path on MI355X (contract: see the task's bench.py section).
 
-One step = one synthetic clip through feed_data -> test():  4-frame 180x320 LR -> 720x1280, x4 spatial,
-x6 temporal = 7 timestamps (BASELINE.json configs[1], "c2"), B = 1 clip per step per GPU, fp32.
-metric = HR pixels / second = T*B*HH*WW / wall, whole job over all ranks (clips shard embarrassingly:
-rank r renders its own clips, weak scaling; the only collective is the final gather of the uint8 frames).
+One step = one forward `feed_data -> test()` over B independent synthetic clips, each a 4-frame 180x320 LR clip -> 720x1280 (x4 spatial),
+x6 temporal = 7 timestamps (BASELINE.json configs[1], "c2"), fp32 in / out.  Default B = 2 clips per forward and 2 forwards in flight per GPU
+(`--batch`, `--streams`; the (B, streams) sweep is profiles/r06_inflight_sweep.txt: B = 2, two in flight is within 0.3 % of the best cell);
+the line's `batch1` leg is the B = 1 job that was the headline of rounds 1-4.
+metric = HR pixels / second = T*B*HH*WW*steps*ranks / wall, whole job over all ranks (clips shard embarrassingly: rank r renders its own clips,
+weak scaling; the only collective is the asynchronous gather of the uint8 frames to rank 0).
 
-Launch: `python bench.py --gpus N` starts N ranks itself (a `python -m torch.distributed.run` child, started before
-this process touches the GPU; nothing is re-exec'ed) when it is not already running under a launcher; under
-`torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.  Rank 0 prints the one JSON line.
+Launch: `python bench.py --gpus N` starts N ranks itself (a `python -m torch.distributed.run` child, started before this process touches the
+GPU; nothing is re-exec'ed) when it is not already running under a launcher; under `torch.distributed.run` (WORLD_SIZE set) it is one of the
+ranks.  Rank 0 prints the one JSON line.
 
-Arithmetic (--mma): "bf16x3" runs the dense contractions (3x3 convolutions, fused DCN, the three MLPs) on the
-bf16 matrix cores with every fp32 operand split exactly into three bf16 parts and six products accumulated in fp32 --
-fp32-equivalent (error below an fp32 FMA chain, tests/test_kernels_gpu.py::test_conv_split_engine_is_fp32_equivalent);
-"f16x2" (default, round 4) is the same except that the 3x3 stride-1 convolutions served by conv_wino.hip and the three MLPs
-(siren_split.hip) split every operand into TWO fp16 parts (hi = rne(x), lo = rne(x - hi): 22+ bits) and take three products -- half
-the matrix instructions, error against fp64 at or below the three-part form's (same tests); so do the fused DCN's window kernel and
-the 1x1 layers (conv_pw.hip); the few 3x3 layers conv_wino.hip does not take stay three-part.  "fp32" runs everything on v_mfma_f32_32x32x2_f32.  The line carries the
-bf16x3 and fp32-MFMA numbers of the same run as `bf16x3` and `fp32_mfma`.
+Arithmetic (--mma).  "f16x2" (default): every dense contraction on the fp16 matrix cores with each fp32 operand split into TWO fp16 parts and
+three products accumulated in fp32 (weights x 2^8, low activation part x 2^11: fp32-equivalent for tensor magnitudes 3e-5 .. 3e4, gated by
+tests/test_kernels_gpu.py against fp64 with the bound 1.25 x the fp32-MFMA engine's error; beyond fp16's range the kernel that meets the
+operand sets a status word and the shell renders the clip again with bf16x3) -- the 3x3 stride-1 layers (conv_wino.hip: Winograd F(2,3) along
+the rows; the three residual trunks as persistent chain launches), the 1x1 layers (conv_pw.hip), the fused DCN, the three MLPs
+(siren_split.hip) and, since round 6, the strided / dilated / wide layers (conv_ig16.hip); the few remaining split layers use three bf16 parts.
+"bf16x3": three bf16 parts, six products everywhere.  "fp32": v_mfma_f32_32x32x2_f32.  The line carries all three (`bf16x3`, `fp32_mfma`).
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = the 3x3 convolution engine (conv_split_kernel<3,4>, or conv_igemm_kernel<2> with
-               --mma fp32): algorithmic FLOP of its launches / their measured duration (events on the launch
-               stream, one instrumented clip after the timed region).  Peak: bf16 / fp16 dense MFMA 2500 TFLOP/s / products
-               per fp32 MAC = 833.3 TFLOP/s for f16x2 (3 products), 416.7 for bf16x3 (6), 157.3 TFLOP/s fp32 MFMA for fp32.
-  stages       the same measurement for every stage of the path (event pairs around each C-ABI call of the
-               instrumented clip): ms per clip, algorithmic work, achieved rate, the bound and the fraction of it.
-  parity       PSNR / L-inf of the HIP path against the CPU oracle on the cpu_baseline clip (both engines).
-  cpu_baseline the CPU oracle (oracle/, "port" of the reference): one 3-timestamp forward call at the c2 shape (after a warm-up
-               call), plus a cropped clip and the reference's own CPU-runnable case c1.
-  batch1       the same job with ONE clip per forward (--batch 1: the headline configuration of rounds 1-4; the default step is one forward
-               over B = 2 independent clips, two forwards in flight); streams1: one forward in flight; fp32_mfma / bf16x3: other arithmetics.
+  roofline     dominant kernel = the 3x3 convolution engine (conv_wino_kernel / conv_wino_chain_kernel): algorithmic (direct-form) FLOP of
+               its launches / their measured duration (event pairs on the launch stream, one instrumented clip after the timed region)
+               against fp16 dense MFMA 2500 TFLOP/s / 3 products per fp32 MAC = 833.3 (bf16x3: / 6 = 416.7; fp32: 157.3).  `traffic` = HBM
+               bytes per launch of those kernels from this round's rocprofv3 counter passes (profiles/r06_hbm_traffic.json: FETCH_SIZE doubled
+               per the guide + WRITE_SIZE), next to the algorithmic bytes of the same launches.
+  stages       the same measurement for every stage of the path: ms per clip, algorithmic work, achieved rate, the bound and the fraction of
+               it; the soft-splat also with its COUNTER bytes / time (what the kernel really moves) and what it waits for.
+  parity       PSNR / L-inf of the HIP path against the CPU oracle on a cropped c2 clip, all three arithmetics, gated.
+  cpu_baseline the CPU oracle (oracle/, "port" of the reference): one 3-timestamp forward call at the c2 shape (after a warm-up call),
+               plus the parity clip and the reference's own CPU-runnable case c1.
+  batch1 / streams1 / bf16x3 / fp32_mfma   the same job with one clip per forward / one forward in flight / the other arithmetics.
   stages.pwc   PWC-Net forward on one 720x1280 pair + the 81-way cost volume against HBM.
   c5           (multi-GPU runs, or --mode tiled) one 540x960 clip in row bands: exact and cropped modes, PSNR of the latter.
 """
@@ -131,6 +132,23 @@ def launcher_selftest(a, world, rank):
 # ------------------------------------------------------------------------------------------------- stage timers
 def conv_flops(desc_log):
     return sum(2.0 * n * co * (ci // g) * kh * kw * ho * wo for (n, co, ci, g, kh, kw, ho, wo) in desc_log)
+
+
+def conv_bytes(desc_log):
+    """Algorithmic HBM bytes of stride-1 same-size convolution launches: every input plane read once, every output plane written once
+    (weights: < 1 % of it).  A chain launch counts its layers one by one (N carries them): every activation moves through memory (sc1)."""
+    return sum(4.0 * n * (ci + co) * ho * wo for (n, co, ci, g, kh, kw, ho, wo) in desc_log)
+
+
+TRAFFIC_JSON = os.path.join("profiles", "r06_hbm_traffic.json")
+
+
+def counter_traffic():
+    """This round's HBM counter passes (tools/pmc_hbm_by_kernel.sh -> profiles/r06_hbm_traffic.json): bytes per launch by kernel, or None."""
+    path = os.path.join(ROOT, TRAFFIC_JSON)
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path)).get("kernels")
 
 
 IMNET_MAC, FLOW_MAC, SYNTH_MAC = 41088, 25536, 38016          # per point, SURVEY.md §8(a) B1-B3
@@ -254,9 +272,9 @@ def instrumented_clip(model, sample):
     in_stages = sum(s["ms"] for s in stages.values())
     table["_clip"] = {"ms_instrumented": round(c0.elapsed_time(c1), 3), "ms_in_stages": round(in_stages, 3), "calls_in_stages": len(rec),
                       "ms_outside_stages": round(c0.elapsed_time(c1) - in_stages, 3),
-                      "note": "outside = torch glue kernels (cat / copy / index_select / fill: ~100 launches, profiles/r04_bench_kernel_stats.txt) plus the "
-                              "idle time between an event pair's end and the next launch of this serialised, event-instrumented run; the timed "
-                              "bench loop has neither the events nor the serialisation"}
+                      "note": "outside = the 7 torch glue kernels left per clip (ConvLSTM cat + flip, fills, copies: profiles/r05_glue_profile.txt), the host "
+                              "gaps between an event pair's end and the next launch of this serialised, event-instrumented run (RAFT moved onto the main "
+                              "stream); the timed bench loop has neither the events nor the serialisation"}
     big = [(e0.elapsed_time(e1), d) for stage, e0, e1, _, d in rec if stage == "conv3x3"]
     allc = [(e0.elapsed_time(e1), d) for stage, e0, e1, _, d in rec if d is not None]
     if os.environ.get("MOTIF_BENCH_SHAPES"):
@@ -268,7 +286,26 @@ def instrumented_clip(model, sample):
         print("# conv shapes: (N,Cout,Cin,groups,KH,KW,Ho,Wo) launches total_ms TFLOP/s", file=sys.stderr)
         for d, (cnt, ms_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
             print("# %-40s %5d %9.3f %8.1f" % (d, cnt, ms_, conv_flops([d]) * cnt / (ms_ * 1e-3) / 1e12), file=sys.stderr)
-    return dict(launches=len(big), ms=sum(t for t, _ in big), flops=conv_flops([d for _, d in big]),
+    # HBM counter bytes (this round's rocprofv3 passes) beside the algorithmic ones, for the kernels whose bound is, or is claimed to be, memory
+    kern = counter_traffic()
+    if kern:
+        def per_launch(prefix):
+            rows = [v for k, v in kern.items() if k.startswith(prefix)]
+            n = sum(r["calls"] for r in rows)
+            return (sum((r["fetch_x2"] + r["write"]) * r["calls"] for r in rows) / n, n) if n else (None, 0)
+        sp, _ = per_launch("splat_owner_kernel")
+        if sp and "splat" in table and table["splat"].get("calls"):
+            ms_launch = table["splat"]["ms_per_clip"] / table["splat"]["calls"]
+            table["splat"]["traffic"] = {"hbm_bytes_per_launch": sp, "source": TRAFFIC_JSON,
+                                         "counter_gbs": round(sp / (ms_launch * 1e-3) / 1e9, 1), "counter_frac_of_hbm": round(sp / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "algorithmic_over_counter": round(table["splat"]["gbyte"] * 1e9 / table["splat"]["calls"] / sp, 3),
+                                         "note": "what the kernel really moves per launch (FETCH_SIZE x 2 + WRITE_SIZE) over its launch time: it is NOT bandwidth-bound "
+                                                 "-- matrix pipe idle, SQ_WAIT_ANY ~0.5 of the wave cycles: the bucket walk of the gather (one dependent LDS read per "
+                                                 "(source, corner) pair and plane) waits on LDS / L2 latency (profiles/r06_mfma_util_by_kernel.txt)"}
+        ch, nch_ = per_launch("conv_wino_chain_kernel")
+        if ch:
+            table["conv3x3"]["chain_traffic"] = {"hbm_bytes_per_launch": ch, "launches_profiled": nch_, "source": TRAFFIC_JSON}
+    return dict(launches=len(big), ms=sum(t for t, _ in big), flops=conv_flops([d for _, d in big]), bytes=conv_bytes([d for _, d in big]),
                 all_conv_ms=sum(t for t, _ in allc), all_conv_flops=conv_flops([d for _, d in allc]), table=table)
 
 
@@ -401,14 +438,29 @@ def pwc_stage():
         c1.record()
         torch.cuda.synchronize()
         ops.corr81 = timed_corr
+        flop = [0.0]
+        orig_conv = ops.conv2d
+
+        def counted_conv(plan, x, *args, **kw):
+            out = orig_conv(plan, x, *args, **kw)
+            co, cig, kh, kw_ = plan.weight.shape
+            flop[0] += 2.0 * x.shape[0] * co * cig * kh * kw_ * out.shape[2] * out.shape[3]
+            return out
+        ops.conv2d = counted_conv
         try:
             net(f0, f1)
             torch.cuda.synchronize()
         finally:
             ops.corr81 = orig
+            ops.conv2d = orig_conv
     ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rec)
     fl, by = sum(r[2] for r in rec), sum(r[3] for r in rec)
-    row = {"ms_per_pair": round(c0.elapsed_time(c1) / reps, 3), "input": "one 720x1280 frame pair (padded to 768x1280 inside, OpticalFlow/PWCNet.py:266-322)",
+    ms_pair = c0.elapsed_time(c1) / reps
+    peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if ops.get_conv_mma() == ops.MMA_F16X2 else BF16_MFMA_PEAK_TFLOPS / 6.0 if ops.get_conv_mma() != ops.MMA_FP32 else FP32_MFMA_PEAK_TFLOPS
+    row = {"ms_per_pair": round(ms_pair, 3), "input": "one 720x1280 frame pair (padded to 768x1280 inside, OpticalFlow/PWCNet.py:266-322)",
+           "bound": "mfma", "tflop": round(flop[0] / 1e12, 4), "achieved": round(flop[0] / (ms_pair * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+           "frac": round(flop[0] / (ms_pair * 1e-3) / 1e12 / peak, 4),
+           "frac_note": "convolution FLOP of the whole forward (51 layers on 6 pyramid levels, most of them launch-bound on maps of 12x20 .. 192x320) over its wall time",
            "corr81": {"ms": round(ms, 4), "calls": len(rec), "gflop": round(fl / 1e9, 3), "gbyte": round(by / 1e9, 4)}}
     if ms > 0:
         row["corr81"].update(bound="hbm", achieved=round(by / (ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -661,21 +713,26 @@ def main():
             r = instrumented_clip(model, clips1[0])        # ONE clip: the stage table is per clip whatever the batch of the timed loop
             ach = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
             split = a.mma != "fp32"
-            traffic, traffic_src = None, None
-            for name in ("r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_split_traffic.json") if split else ("r01_conv_traffic.json",):
-                tj = os.path.join(ROOT, "profiles", name)
-                if os.path.exists(tj):          # rocprofv3 PMC passes of this kernel (FETCH_SIZE / WRITE_SIZE), not collected in this run
-                    tdoc = json.load(open(tj))
-                    traffic = tdoc.get("hbm_bytes_per_launch")
-                    if traffic is None:         # round-3 file: one entry per kernel of the 3x3 engine, on the trunk launch (80 of the 184)
-                        traffic = {k: v["hbm_bytes_per_launch"] for k, v in tdoc.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
-                        traffic["algorithmic_bytes_per_launch"] = tdoc.get("algorithmic_bytes_per_launch")
-                    traffic_src = "profiles/" + name
-                    break
+            # HBM bytes per launch of the dominant kernel family from THIS round's counter passes (two rocprofv3 --pmc runs, not collected in
+            # this run: a profiled run is not a timed run), weighted over its launches; beside them the algorithmic bytes of the same launches
+            traffic, traffic_src, traffic_detail = None, None, None
+            kern = counter_traffic() if split else None
+            if kern:
+                rows = {k: v for k, v in kern.items() if k.startswith("conv_wino")}
+                ncalls = sum(v["calls"] for v in rows.values())
+                if ncalls:
+                    traffic = sum((v["fetch_x2"] + v["write"]) * v["calls"] for v in rows.values()) / ncalls
+                    traffic_src = TRAFFIC_JSON
+                    traffic_detail = {k: {"calls": v["calls"], "hbm_bytes_per_launch": v["fetch_x2"] + v["write"]} for k, v in rows.items()}
             peak = BF16_MFMA_PEAK_TFLOPS / (3.0 if a.mma == "f16x2" else 6.0) if split else FP32_MFMA_PEAK_TFLOPS
             clip_flop = sum(v.get("tflop", 0.0) for k, v in r["table"].items() if isinstance(v, dict)) * 1e12
             line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                                "frac": ach / peak, "traffic": None, "traffic_from_profile": traffic, "traffic_source": traffic_src,
+                                "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src, "traffic_by_kernel": traffic_detail,
+                                "algorithmic_bytes_per_launch": r["bytes"] / max(r["launches"], 1),
+                                "algorithmic_over_traffic": (r["bytes"] / max(r["launches"], 1) / traffic) if traffic else None,
+                                "traffic_note": "bytes per launch averaged over the launches of conv_wino_kernel<..> and conv_wino_chain_kernel in the profiled run "
+                                                "(a chain launch = 10 .. 80 layers, every activation through memory with sc1: its own row in traffic_by_kernel); the bound of "
+                                                "these kernels is the matrix pipe, the figure shows there are no wasted re-reads",
                                 "overall": {"tflop_executed_per_clip": clip_flop / 1e12, "achieved": clip_flop / (dt / a.steps / a.batch) / 1e12,
                                             "frac": clip_flop / (dt / a.steps / a.batch) / 1e12 / peak,
                                             "note": "dense FLOP of one clip (all conv / DCN / MLP stages as executed, t-independent part once) over "

@@ -61,7 +61,7 @@ __device__ __forceinline__ unsigned pk_f16(float a, float b) { const f16x2v h = 
 // statement.  Without the wait state the consumer that happens to sit in the next issue slot reads the register's OLD contents, depending on
 // how the two waves of the SIMD interleave: the flow kernel was irreproducible from run to run (a third of the pixels by up to 4e-6; found when
 // an unrelated change moved the code object and tests/test_model_gpu.py::test_default_precontracted_stage... began to fail; it is also what
-// round 5 met as "the sine without its fract is not reproducible").  tools/_dbg variants: nops in FRONT of the asm statements change nothing,
+// round 5 met as "the sine without its fract is not reproducible").  `-DSIREN_DBG_*` variants: nops in FRONT of the asm statements change nothing,
 // one wait state BEHIND them makes 6 runs x 3 stagger settings bit-identical, at no measurable cost (0.825 ms either way).
 #define SIREN_ASM_PRE
 #define SIREN_ASM_POST "\n\ts_nop 0"

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../motif_amd/csrc"
 mkdir -p ../../tools/_trace /tmp/motif_trace_obj
-for f in api conv_igemm conv_split conv_split2 conv_wino conv_pw conv_direct siren siren_split splat misc corr dcn; do
+for f in $(python3 -c "import build; print(' '.join(s[:-4] for s in build.SOURCES))"); do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-value -Wno-pass-failed -DMOTIF_TRACE -DMOTIF_SIREN_DBG -c $f.hip -o /tmp/motif_trace_obj/$f.o &
 done
 wait

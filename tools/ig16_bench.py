@@ -53,16 +53,19 @@ def t(fn, reps=20):
 
 def main():
     ops.set_mma("f16x2")
-    print("%-22s %-34s %10s %10s %7s" % ("layer", "cin,cout,k,s,p,d,g @ HxW xN", "ig16 us", "fp32 us", "ratio"))
+    print("%-22s %-34s %12s %12s %12s   %s" % ("layer", "cin,cout,k,s,p,d,g @ HxW xN", "ig16 us", "default us", "fp32 eng us", "default dispatch"))
     for cin, cout, k, st, pd, dl, g, H, W, N, tag in SHAPES:
         m = Conv2d(cin, cout, k, st, pd, dl, g).cuda()
         x = torch.randn(N, cin, H, W, device="cuda")
+        res = {}
+        outs = {}
+        for eng in (7, 0, 6):                            # conv_ig16.hip wherever the shape fits | the library's rule | the fp32 engine
+            ops.set_option("conv_engine", eng)
+            outs[eng] = m(x, act=ops.ACT_RELU)
+            res[eng] = t(lambda: m(x, act=ops.ACT_RELU))
         ops.set_option("conv_engine", 0)
-        a = t(lambda: m(x, act=ops.ACT_RELU))
-        ops.set_option("conv_engine", 6)
-        b = t(lambda: m(x, act=ops.ACT_RELU))
-        ops.set_option("conv_engine", 0)
-        print("%-22s %-34s %10.1f %10.1f %7.2f" % (tag, "%d,%d,%d,%d,%d,%d,%d @ %dx%d x%d" % (cin, cout, k, st, pd, dl, g, H, W, N), a, b, a / b), flush=True)
+        took = "conv_ig16" if not torch.equal(outs[0], outs[6]) else "fp32 engine / direct"
+        print("%-22s %-34s %12.1f %12.1f %12.1f   %s" % (tag, "%d,%d,%d,%d,%d,%d,%d @ %dx%d x%d" % (cin, cout, k, st, pd, dl, g, H, W, N), res[7], res[0], res[6], took), flush=True)
 
 
 if __name__ == "__main__":

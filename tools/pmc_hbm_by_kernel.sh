@@ -18,6 +18,14 @@ for d in sys.argv[1:]:
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:44]
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[k][r["Counter_Name"]] += 1
+import json, os
+doc = {"unit": "bytes per launch", "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB), two counters-only passes over `bench.py --steps 3 --warmup 1 --streams 1 --batch 1`; "
+       "fetch_x2 = FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM' (the counter tallies the 128-byte requests of wide coalesced streams at 64 bytes); WRITE_SIZE as reported",
+       "kernels": {}}
+for k, m in acc.items():
+    n = max(cnt[k]["FETCH_SIZE"], 1)
+    doc["kernels"][k] = {"calls": n, "fetch_raw": m["FETCH_SIZE"] / n * 1024.0, "fetch_x2": 2 * m["FETCH_SIZE"] / n * 1024.0, "write": m["WRITE_SIZE"] / max(cnt[k]["WRITE_SIZE"], 1) * 1024.0}
+json.dump(doc, open(os.path.join(os.path.dirname(sys.argv[1]), "hbm_traffic.json"), "w"), indent=1)
 print("%-46s %7s %14s %14s %14s" % ("kernel", "calls", "FETCH MB/call", "(x2) MB/call", "WRITE MB/call"))
 for k, m in sorted(acc.items(), key=lambda kv: -(kv[1]["FETCH_SIZE"] + kv[1]["WRITE_SIZE"]))[:14]:
     n = max(cnt[k]["FETCH_SIZE"], 1)
