@@ -334,8 +334,9 @@ def test_full_size_properties_c2():
         assert torch.isfinite(full).all() and float(full.min()) >= 0.0 and float(full.max()) <= 1.0
         net.clear_cache()
         solo, _, _ = net(x, None, times[6:7], s["scale"], use_GT=False, iter=4)
-    # splat sums are atomics-ordered, so allow fp32 reassociation noise only
-    assert float((solo[0] - full[6]).abs().max()) < 5e-4
+    # every kernel on the path is bit-reproducible (the owner-computes splat sums exact integers; round 6 removed the last run-to-run
+    # difference, a missing wait state in the two-part MLP kernels): the same timestamp rendered alone gives the same bits
+    assert torch.equal(solo[0], full[6]), float((solo[0] - full[6]).abs().max())
 
 
 def test_pwcnet_matches_reference_golden():
