@@ -109,26 +109,24 @@ __device__ __forceinline__ f32x16 mfma16(u32x4 w, u32x4 x, f32x16 c) {
 
 // The sine layers compute sin(30 * (W h + b)) (SIREN.py:44-45, omega_0 = 30).  Here every layer that feeds a sine is packed with its
 // weights and bias multiplied by 30 / 2pi (in fp64, before the 3-way bf16 split), so its accumulator holds the argument IN TURNS and the
-// sine is  v_fract_f32 + v_sin_f32  (the hardware sine takes turns; fract is exact) instead of the six instructions of a scaled
-// Cody-Waite reduction.  Accuracy: the accumulator is an fp32 sum either way -- its rounding (|x| * 2^-24 in radians, x the argument)
+// sine is ONE v_sin_f32 (the hardware sine takes turns and reduces the argument itself; until round 6 a v_fract_f32 stood in front of it)
+// instead of the six instructions of a scaled Cody-Waite reduction.  Accuracy: the accumulator is an fp32 sum either way -- its rounding (|x| * 2^-24 in radians, x the argument)
 // is the error of the argument in both forms; what is dropped is only the reference's extra rounding of 30 * (W h + b).  Measured
 // against the oracle in tests/test_kernels_gpu.py (same tolerances as before) and end to end in bench.py's parity block.
 #define SIREN_TURNS 4.774648292756860                         // 30 / (2 pi)
 template <int NP>
 __device__ __forceinline__ float sin_turns(float t) {
     if constexpr (NP == 2) t *= 1.f / kSirenScale<2>;     // the accumulators of the two-part form carry 2^8 x the argument
-    // The v_fract in front is NOT needed for accuracy (gfx950's v_sin_f32 reduces its argument itself: against sin(2 pi x) in fp64 over
-    // +-1 ... +-3e7 turns the maximum error is 1.1-1.25e-7 with and without it) and costs one of ~5 vector instructions per activation --
-    // but WITHOUT it (-DSIREN_NO_FRACT) the two-part flow kernel is no longer reproducible from run to run (a third of its pixels differ by
-    // up to 9e-6 between two launches on the same inputs; imnet and the three-part form stay bit-identical).  v_sin_f32 itself is a pure
-    // function in every microbenchmark tried (alone, between matrix instructions, in bursts with immediate consumers, |x| up to 3e7); a
-    // dummy VALU instruction in the fract's place, wait states around the inline-assembly mixed FMAs, 16 wait states behind every matrix
-    // instruction and double-buffered weight fragments all leave it irreproducible.  The cause was not found in the time available, so the
-    // fract stays (DESIGN_LOG "Round 5"; tests/test_kernels_gpu.py::test_siren_kernels_are_reproducible_from_run_to_run pins the property).
-#ifdef SIREN_NO_FRACT
-    return __builtin_amdgcn_sinf(t);
-#else
+    // No v_fract in front (round 6): gfx950's v_sin_f32 reduces its argument itself -- against sin(2 pi x) in fp64 over +-1 ... +-3e7 turns the
+    // maximum error is 1.1-1.25e-7 with and without it (round 5's measurement; 6 % of the results differ in the last bit) -- and it is one of ~5
+    // vector instructions per activation: flow_imnet 0.823 -> 0.787 ms, imnet 0.492 -> 0.479, synth 0.954 -> 0.945 (N = 3, c2 size).
+    // Round 5 had built exactly this and dropped it because the two-part flow kernel then differed from run to run; the cause was the missing
+    // wait state behind the inline-assembly v_fma_mixhi_f16 (SIREN_ASM_POST above), not the sine: with it, six launches x three stagger settings
+    // are bit-identical in both forms (tools/siren_determinism.py flow).  -DSIREN_FRACT restores the old form.
+#ifdef SIREN_FRACT
     return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t));
+#else
+    return __builtin_amdgcn_sinf(t);
 #endif
 }
 
