@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Full-size (BASELINE config 2) parity of the HIP path against the CPU oracle: one clip, LR 180x320 -> 720x1280.
-Slow on the CPU side (minutes); run by hand, result recorded in DESIGN.md."""
+"""Full-size parity of the HIP path against the CPU oracle: one clip of BASELINE config 2 (LR 180x320 -> 720x1280; default) or, with
+CONFIG=c3, config 3 (Vimeo-7 septuplet shape: 7 LR frames 256x448 -> 1024x1792).  TIMES = the timestamps rendered (default one: 0.5),
+MODES = the arithmetics.  Slow on the CPU side (minutes); run by hand, result recorded in DESIGN.md / profiles/."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,12 +14,13 @@ from oracle.motif_ref import MotifRef
 
 def main():
     times = [float(t) for t in os.environ.get("TIMES", "0.5").split(",")]
-    s = synthetic_sample(180, 320, 4, 7)
+    c3 = os.environ.get("CONFIG", "c2") == "c3"
+    s = synthetic_sample(256, 448, 4, 9, n_frames=7) if c3 else synthetic_sample(180, 320, 4, 7)
     tl = [torch.full((1, 1), t) for t in times]
     from motif_amd import ops
     net = fill_state_dict(LunaTokis()).cuda().eval()
     outs = {}
-    for mode in os.environ.get("MODES", "bf16x3,fp32").split(","):
+    for mode in os.environ.get("MODES", "f16x2,bf16x3,fp32").split(","):
         ops.set_mma(mode)
         net.clear_cache()
         with torch.no_grad():
@@ -30,7 +32,7 @@ def main():
     dt = time.time() - t0
     gt = s["GT"][0, 1:1 + len(times)]
     pr = util.y_psnr_per_frame(gt, ref[:, 0])
-    print("c2 full size, %d timestamp(s): oracle %.1f s on %d threads" % (len(times), dt, torch.get_num_threads()))
+    print("%s full size (LR %s), %d timestamp(s): oracle %.1f s on %d threads" % ("c3" if c3 else "c2", tuple(s["LQs"].shape), len(times), dt, torch.get_num_threads()))
     for mode, (out, flow) in outs.items():
         o = out.cpu()
         mse = float(((o.double() - ref.double()) ** 2).mean())
