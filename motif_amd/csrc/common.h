@@ -7,6 +7,21 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// MOTIF_SCALAR_F32: a kernel compiled WITHOUT the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32).
+// Round 6 (met in a fused RAFT bottleneck kernel that was dropped again -- DESIGN_LOG.md; tools/pk_fma_beside_mfma.hip reproduces it
+// without the library; profiles/r06_pk_fma_beside_mfma.txt):
+//     v_pk_fma_f32 d, a, b, c op_sel:[0,1,0]       with b a VECTOR register pair (the LOW result takes b's HIGH register)
+// came out wrong in its low half, in lanes 48..63 of the wave only, while an fp16 / bf16 MFMA kernel ran beside it on another stream -- never
+// alone, never beside fp32 MFMAs, never in the plain form, the op_sel_hi forms or with b a SCALAR register pair.  hipcc picks the form by itself
+// (SLP-paired scalar FMAs against a broadcast operand), so a kernel in which it picked an op_sel form on a vector-register source is compiled
+// without packed fp32 altogether; tests/test_isa_hygiene.py fails on any kernel of the BUILT library that holds one (every op_sel bit on a
+// vector-register source of a packed fp32 instruction, not only the one form seen to fail).  The attribute means nothing to the host pass.
+#if !defined(MOTIF_SCALAR_F32) && defined(__HIP_DEVICE_COMPILE__)
+#define MOTIF_SCALAR_F32 __attribute__((target("no-packed-fp32-ops")))
+#elif !defined(MOTIF_SCALAR_F32)
+#define MOTIF_SCALAR_F32
+#endif
+
 #define MOTIF_LAUNCH_CHECK()                         \
     do {                                             \
         hipError_t e__ = hipGetLastError();          \

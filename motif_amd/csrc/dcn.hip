@@ -14,7 +14,7 @@ struct DcnArgs {
     long offset_bs, mask_bs;
 };
 
-__global__ __launch_bounds__(64) void dcn_im2col_kernel(DcnArgs a) {
+__global__ __launch_bounds__(64) MOTIF_SCALAR_F32 void dcn_im2col_kernel(DcnArgs a) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     const int T = a.kh * a.kw;

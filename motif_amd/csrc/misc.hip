@@ -33,7 +33,7 @@ __device__ __forceinline__ float resize_fin(float v, float mul, int post) {
 }
 
 template <int VEC, bool UP2>
-__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+__global__ __launch_bounds__(256) MOTIF_SCALAR_F32 void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
                                                                int Ho, int Wo, float sh, float sw, int align, float mul, int post) {
     const int gpr = Wo / VEC + (Wo % VEC ? 1 : 0);                    // column groups per row
     const int gi = blockIdx.x * 256 + threadIdx.x;

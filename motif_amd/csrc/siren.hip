@@ -86,7 +86,7 @@ template <int MODE> struct Layout {
 // pre-activation and seeds the accumulator instead of the bias, and only the remaining input channels go
 // through MFMA steps.
 template <int MODE, int TP, bool PRE>
-__global__ __launch_bounds__(SIREN_THREADS) void siren_kernel(SirenArgs a) {
+__global__ __launch_bounds__(SIREN_THREADS) MOTIF_SCALAR_F32 void siren_kernel(SirenArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using L = Layout<MODE>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;

@@ -14,6 +14,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load(name):
@@ -780,6 +781,19 @@ def test_two_clips_in_flight_equal_the_serial_renders():
             assert torch.equal(m.netG._cache["feat"], feat), "encoder output changed under concurrency (rep %d)" % rep
             assert torch.equal(m.netG._cache["flow"], flow), "RAFT flow changed under concurrency (rep %d)" % rep
             assert float((m.fake_H - out).abs().max()) <= 1e-6
+
+
+def test_every_operator_call_of_a_clip_repeats_its_bits_beside_a_clip_in_flight(mma_mode):
+    """tools/beside_stress.py as a test (round 6): every distinct operator call of one clip (~86: each kernel of the path at each of its
+    shapes) is replayed on one stream, over and over for the length of a whole clip running on another stream (+ its RAFT side stream), and
+    every replay must equal the call's result alone.  A fused RAFT bottleneck kernel of round 6 failed exactly this (a packed fp32 FMA
+    whose low result takes the HIGH register of a vector pair comes out wrong in lanes 48..63 beside fp16 / bf16 MFMA kernels: DESIGN.md 4)
+    while the test above met it in one run of three."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("beside_stress", os.path.join(ROOT, "tools", "beside_stress.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    assert tool.main(["--mma", mma_mode, "--busy", "1.0", "--max-replays", "200"]) == 0, "a replay beside the clip differed (see the table above)"
 
 
 @pytest.mark.parametrize("which", ["Ours_4", "Ours_44"])

@@ -1,0 +1,177 @@
+// Which packed fp32 instructions keep their result while a matrix-core kernel runs beside them?  (gfx950 / MI355X; round 6)
+//
+// A fused RAFT bottleneck kernel of round 6 (fp32 FMAs that hipcc's SLP vectoriser had paired into v_pk_fma_f32; since dropped, DESIGN_LOG.md)
+// gave wrong results in ~10 % of its launches while an fp16 / bf16 MFMA kernel ran on another stream: the LOW half of a packed result, lanes
+// 48..63 of the wave only; never alone, never beside an fp32-MFMA kernel, never once the FMAs were scalar, and also with an s_waitcnt 0 behind
+// every instruction.  This program takes the model and the library out of the picture:
+//
+//   victim     every lane runs a chain of ONE packed instruction form (the accumulator chain of a convolution) on register data and the same chain
+//              with scalar instructions (inline asm both, so that nothing is re-paired); compared every 64 steps, reported per half of the
+//              result and per quarter of the wave;
+//   aggressor  a kernel of back-to-back MFMAs with operands read from LDS (bf16 32x32x16, f16 32x32x16, or fp32 32x32x2 as the control), 128
+//              registers and 2 workgroups per CU: room for victim waves on every SIMD;
+// launched on two streams, `rounds` times; then the victim alone.
+//
+// Result on MI355X (profiles/r06_pk_fma_beside_mfma.txt; the same on every box it ran on): ONLY `v_pk_fma_f32 d, a, b, d op_sel:[0,1,0]` with b in
+// vector registers differs -- low half, lanes 48..63, beside the bf16 and the f16 kernel, never beside the fp32 one or alone.  Its neighbours
+// (op_sel:[1,0,0], [1,1,0], the op_sel_hi forms, b in scalar registers, v_pk_mul / v_pk_add / v_pk_mov with op_sel) came out clean in every run.
+// tests/test_isa_hygiene.py keeps every op_sel bit on a vector-register source of a packed fp32 instruction out of the built library.
+//
+//   hipcc --offload-arch=gfx950 -O2 -o /tmp/pkfma tools/pk_fma_beside_mfma.hip && /tmp/pkfma [rounds]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
+struct Form { const char* text; int op, s0, s1, h0, h1; };      // op 0: p = a * b + p, 1: p = p * b, 2: p = p + b, 3: swap; which half of a / b feeds the low (s) / high (h) result
+#define NFORMS 14
+static constexpr Form FORMS[NFORMS] = {
+    {"v_pk_fma_f32 p, a, b, p", 0, 0, 0, 1, 1},
+    {"v_pk_fma_f32 p, a, b, p op_sel_hi:[1,0,1]", 0, 0, 0, 1, 0},
+    {"v_pk_fma_f32 p, a, b, p op_sel_hi:[0,1,1]", 0, 0, 0, 0, 1},
+    {"v_pk_fma_f32 p, a, b, p op_sel:[0,1,0]", 0, 0, 1, 1, 1},
+    {"v_pk_fma_f32 p, a, b, p op_sel:[1,0,0]", 0, 1, 0, 1, 1},
+    {"v_pk_fma_f32 p, a, b, p op_sel:[1,1,0]", 0, 1, 1, 1, 1},
+    {"v_pk_mul_f32 p, p, b op_sel:[0,1]", 1, 0, 1, 1, 1},
+    {"v_pk_mul_f32 p, p, b op_sel_hi:[1,0]", 1, 0, 0, 1, 0},
+    {"v_pk_add_f32 p, p, b op_sel:[0,1]", 2, 0, 1, 1, 1},
+    {"v_pk_add_f32 p, p, b op_sel_hi:[1,0]", 2, 0, 0, 1, 0},
+    {"v_pk_mov_b32 p, p, p op_sel:[1,0] (swap)", 3, 0, 0, 0, 0},
+    {"v_pk_fma_f32 p, a, s[b], p op_sel:[0,1,0]", 0, 0, 1, 1, 1},          // the multiplier pair in scalar registers (vector * uniform weight)
+    {"v_pk_fma_f32 p, a, s[b], p op_sel_hi:[1,0,1]", 0, 0, 0, 1, 0},
+    {"v_pk_fma_f32 p, s[a], b, p op_sel:[1,0,0]", 0, 1, 0, 1, 1},
+};
+
+template <int F>
+__device__ __forceinline__ void packed(f32x2& p, f32x2 a, f32x2 b) {
+    if (F == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p) : "v"(a), "v"(b));
+    if (F == 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p) : "v"(a), "v"(b));
+    if (F == 2) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p) : "v"(a), "v"(b));
+    if (F == 3) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(p) : "v"(a), "v"(b));
+    if (F == 4) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(p) : "v"(a), "v"(b));
+    if (F == 5) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0]" : "+v"(p) : "v"(a), "v"(b));
+    if (F == 6) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[0,1]" : "+v"(p) : "v"(b));
+    if (F == 7) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(p) : "v"(b));
+    if (F == 8) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1]" : "+v"(p) : "v"(b));
+    if (F == 9) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(p) : "v"(b));
+    if (F == 10) asm volatile("v_pk_mov_b32 %0, %0, %0 op_sel:[1,0]" : "+v"(p));       // low <- high, high <- low
+    if (F == 11) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(p) : "v"(a), "s"(__builtin_bit_cast(unsigned long long, b)));
+    if (F == 12) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p) : "v"(a), "s"(__builtin_bit_cast(unsigned long long, b)));
+    if (F == 13) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(p) : "s"(__builtin_bit_cast(unsigned long long, a)), "v"(b));
+}
+
+template <int op>
+__device__ __forceinline__ void scalar(float& q, float a, float b) {
+    if (op == 0) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(q) : "v"(a), "v"(b));
+    if (op == 1) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(q) : "v"(b));
+    if (op == 2) asm volatile("v_add_f32 %0, %0, %1" : "+v"(q) : "v"(b));
+}
+
+// One packed instruction per step on a running pair p (the chain of a convolution's accumulator), the same chain with scalar instructions on
+// (q0, q1); compared every 64 steps, p re-seated on q after a difference so that one slip is one report.
+template <int F>
+__global__ __launch_bounds__(256) void victim(const float* __restrict__ seed, unsigned* __restrict__ report, int iters, f32x2 ua, f32x2 ub) {
+    constexpr Form f = FORMS[F];                 // (compile-time: the loop is the packed instruction, its two scalar twins and the loop counter)
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const float s = seed[tid & 1023];
+    f32x2 a = {1.0f + s * 0.25f, 1.0f - s * 0.125f};
+    f32x2 b = f.op == 1 ? f32x2{1.f + s * 0.0009765625f, 1.f - s * 0.0009765625f} : f32x2{0.5f + s * 0.0625f, 0.75f - s * 0.03125f};
+    if (F == 11 || F == 12) b = ub;              // a kernel argument: uniform, lives in scalar registers
+    if (F == 13) a = ua;
+    f32x2 p = {1.f + s, 2.f - s};
+    float q0 = p[0], q1 = p[1];
+    for (int i = 0; i < iters; ++i) {
+        packed<F>(p, a, b);
+        if (f.op == 3) { float t; asm volatile("v_mov_b32 %0, %1\n\tv_mov_b32 %1, %2\n\tv_mov_b32 %2, %0" : "=&v"(t), "+v"(q0), "+v"(q1)); }
+        else {
+            scalar<f.op>(q0, a[f.s0], b[f.s1]);
+            scalar<f.op>(q1, a[f.h0], b[f.h1]);
+        }
+        if ((i & 63) == 63) {
+            if (__float_as_uint(p[0]) != __float_as_uint(q0)) { atomicAdd(&report[0], 1u); atomicOr(&report[4 + ((threadIdx.x & 63) >> 4)], 1u); p[0] = q0; }
+            if (__float_as_uint(p[1]) != __float_as_uint(q1)) { atomicAdd(&report[1], 1u); atomicOr(&report[8 + ((threadIdx.x & 63) >> 4)], 1u); p[1] = q1; }
+        }
+    }
+    if (tid == 0) atomicAdd(&report[2], 1u);
+}
+
+// KIND 0: bf16 32x32x16, 1: f16 32x32x16, 2: fp32 32x32x2 (control)
+template <int KIND>
+__global__ __launch_bounds__(256) void aggressor(float* __restrict__ sink, int iters) {
+    f32x16 acc[4];
+    for (int j = 0; j < 4; ++j)
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    const float x = (float)(threadIdx.x & 7) * 0.125f;
+    bf16x8 ab, bb;
+    f16x8 ah, bh;
+    for (int e = 0; e < 8; ++e) { ab[e] = (__bf16)x; bb[e] = (__bf16)(1.f - x); ah[e] = (_Float16)x; bh[e] = (_Float16)(1.f - x); }
+    __shared__ bf16x8 lb[512];
+    __shared__ f16x8 lh[512];
+    lb[threadIdx.x] = ab; lb[threadIdx.x + 256] = bb; lh[threadIdx.x] = ah; lh[threadIdx.x + 256] = bh;
+    __syncthreads();
+    for (int i = 0; i < iters; ++i) {
+        if (KIND == 0) { ab = lb[(threadIdx.x + i) & 511]; bb = lb[(threadIdx.x + 2 * i) & 511]; }      // operands through LDS like the real kernels
+        if (KIND == 1) { ah = lh[(threadIdx.x + i) & 511]; bh = lh[(threadIdx.x + 2 * i) & 511]; }
+        for (int j = 0; j < 4; ++j) {
+            if (KIND == 0) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, acc[j], 0, 0, 0);
+            if (KIND == 1) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[j], 0, 0, 0);
+            if (KIND == 2) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, 1.f - x, acc[j], 0, 0, 0);
+        }
+    }
+    float t = 0.f;
+    for (int j = 0; j < 4; ++j)
+        for (int e = 0; e < 16; ++e) t += acc[j][e];
+    if (t == 12345.678f) sink[0] = t;
+}
+
+template <int F>
+static void run(int kind, int rounds, const float* seed, unsigned* report, float* sink, hipStream_t sv, hipStream_t sa) {
+    CK(hipMemset(report, 0, 64));
+    for (int r = 0; r < rounds; ++r) {
+        if (kind == 0) aggressor<0><<<256 * 2, 256, 0, sa>>>(sink, 60000);
+        if (kind == 1) aggressor<1><<<256 * 2, 256, 0, sa>>>(sink, 60000);
+        if (kind == 2) aggressor<2><<<256 * 2, 256, 0, sa>>>(sink, 15000);
+        for (int k = 0; k < 8; ++k) victim<F><<<256 * 8, 256, 0, sv>>>(seed, report, 1 << 14, f32x2{1.0859375f, 0.94921875f}, f32x2{0.53515625f, 0.73828125f});
+        CK(hipDeviceSynchronize());
+    }
+    unsigned h[16];
+    CK(hipMemcpy(h, report, 64, hipMemcpyDeviceToHost));
+    printf("  %-48s %9u %9u   %u%u%u%u  %u%u%u%u\n", FORMS[F].text, h[0], h[1], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
+}
+
+template <int F>
+static void run_all(int kind, int rounds, const float* seed, unsigned* report, float* sink, hipStream_t sv, hipStream_t sa) {
+    run<F>(kind, rounds, seed, report, sink, sv, sa);
+    if constexpr (F + 1 < NFORMS) run_all<F + 1>(kind, rounds, seed, report, sink, sv, sa);
+}
+
+int main(int argc, char** argv) {
+    const int rounds = argc > 1 ? atoi(argv[1]) : 6;
+    float *seed, *sink;
+    unsigned* report;
+    CK(hipMalloc(&seed, 4096));
+    CK(hipMalloc(&sink, 64));
+    CK(hipMalloc(&report, 64));
+    std::vector<float> hs(1024);
+    for (int i = 0; i < 1024; ++i) hs[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f;
+    CK(hipMemcpy(seed, hs.data(), 4096, hipMemcpyHostToDevice));
+    hipStream_t sv, sa;
+    CK(hipStreamCreate(&sv));
+    CK(hipStreamCreate(&sa));
+    const char* names[4] = {"beside the bf16 MFMA kernel (v_mfma_f32_32x32x16_bf16)", "beside the f16 MFMA kernel (v_mfma_f32_32x32x16_f16)",
+                            "beside the fp32 MFMA kernel (v_mfma_f32_32x32x2_f32)", "alone"};
+    printf("comparisons (of %d launches x 2048 x 256 lanes x 256 per line: every 64 steps of a chain of %d) in which the packed chain differed from the scalar one;\n"
+           "quarters of the wave hit (lanes 0-15, 16-31, 32-47, 48-63)\n", rounds * 8, 1 << 14);
+    for (int kind = 0; kind < 4; ++kind) {
+        printf("%s\n  %-48s %9s %9s   %s  %s\n", names[kind], "form", "low half", "high half", "low ", "high");
+        run_all<0>(kind, rounds, seed, report, sink, sv, sa);
+    }
+    return 0;
+}
