@@ -14,7 +14,10 @@ run of three.  This tool is the test that finds such a kernel at once:
             over -- issued between the clip's operators, as many replays as keep stream A busy for the whole clip (so the call meets every
             kernel of the path beside it), each compared with the reference ON the stream (no host wait: the streams really overlap).
 
-    python tools/beside_stress.py [--mma f16x2|bf16x3|fp32] [--only OPERATOR] [--busy 1.5] [--max-replays 400]
+The operator calls of a PWC-Net pair (OpticalFlow/PWCNet.py at 448 x 1024: the cost volumes, the dilated refiner, the transposed convolutions --
+kernels the generator's clip does not launch) are captured and replayed beside the clip in the same way (--no-pwc leaves them out).
+
+    python tools/beside_stress.py [--mma f16x2|bf16x3|fp32] [--only OPERATOR] [--busy 1.5] [--max-replays 400] [--no-pwc]
 
 Exit code 1 when any replay differed.  (profiles/r06_beside_stress.txt: the run of this round.)"""
 import argparse
@@ -61,6 +64,7 @@ def main(argv=None):
     ap.add_argument("--busy", type=float, default=1.5, help="replays per clip = busy * clip time / the call's time alone")
     ap.add_argument("--max-replays", type=int, default=400)
     ap.add_argument("--size", default="180x320")
+    ap.add_argument("--no-pwc", action="store_true", help="leave PWC-Net's operator calls out")
     a = ap.parse_args(argv)
     h, w = (int(v) for v in a.size.split("x"))
     ops.set_mma(a.mma)
@@ -135,16 +139,27 @@ def main(argv=None):
     for n in names:
         setattr(ops, n, wrap(n))
     try:
-        return _run(a, model, clip, captured, state, tally, replay_queue, replay, A, B)
+        pwc = None
+        if not a.no_pwc:
+            from motif_amd.OpticalFlow.PWCNet import PWCNet
+            net = fill_state_dict(PWCNet()).cuda().eval()
+            g = torch.Generator().manual_seed(7)
+            pair = (torch.rand(1, 3, 448, 1024, generator=g).cuda(), torch.rand(1, 3, 448, 1024, generator=g).cuda())
+            pwc = lambda: net(*pair)
+        return _run(a, model, clip, captured, state, tally, replay_queue, replay, A, B, pwc)
     finally:
         for n in names:
             setattr(ops, n, orig[n])
 
 
-def _run(a, model, clip, captured, state, tally, replay_queue, replay, A, B):
+def _run(a, model, clip, captured, state, tally, replay_queue, replay, A, B, pwc):
     with torch.no_grad():
         model.feed_data(clip)
         model.test()
+        hooks = state["hooks"]                                          # operators per clip: the replays are spread over them
+        if pwc is not None:
+            pwc()
+        state["hooks"] = hooks
         torch.cuda.synchronize()
         state["mode"] = "alone"
         skipped = []
