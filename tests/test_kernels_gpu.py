@@ -1063,10 +1063,14 @@ def test_backwarp_and_reliability_maps():
     close(f, ff, 5e-6, 1e-5, "flow_feat")
 
 
-def test_pwc_backward_warp():
+@pytest.mark.parametrize("n, c, h, w", [(2, 5, 24, 40), (1, 128, 24, 40), (2, 33, 12, 20), (1, 13, 7, 70)],
+                         ids=["c5", "c128_level6", "ragged_channel_group", "ragged_row"])
+def test_pwc_backward_warp(n, c, h, w):
+    """PWCNet.py:146-177 against the oracle; the kernel spreads a pixel's channels over workgroups of 8 channels x 64 pixels (round 6), so a
+    channel count that is not a multiple of 8 and a row that is not a multiple of 64 are cases of their own."""
     from oracle.pwc_ref import backward_warp
     from motif_amd import ops
-    img, flow = rnd(2, 5, 24, 40, seed=1), rnd(2, 2, 24, 40, seed=2, scale=6.0)
+    img, flow = rnd(n, c, h, w, seed=1), rnd(n, 2, h, w, seed=2, scale=6.0)
     close(ops.pwc_backward_warp(img.to(dev()), flow.to(dev())), backward_warp(img, flow), 3e-6, 0, "pwc warp")
 
 
