@@ -75,6 +75,68 @@ __global__ __launch_bounds__(256) MOTIF_SCALAR_F32 void resize_bilinear_kernel(c
     }
 }
 
+// x2 upsampling (align_corners = false), the wide form (round 6): a thread makes 8 output columns of the TWO output rows 2k, 2k+1 from the three
+// input rows they share -- per row one 16-byte load (columns 4j .. 4j+3) and its two neighbours, 9 loads for 16 outputs where the form above
+// issues 32 (PCD's 64-channel pyramids, 8 images: 118 MB written per launch at 1.7 TB/s before).  Every output is the SAME expression of the
+// same operands as in resize_bilinear_kernel<4, true> (row / column indices, weights and clamps are formed the same way), so the bits are equal;
+// option resize_narrow = 1 keeps the form above (the A/B of tests/test_kernels_gpu.py).  W % 4 == 0, H >= 2, 16-byte aligned planes.
+__global__ __launch_bounds__(256) MOTIF_SCALAR_F32 void resize_up2_wide_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                                                                 float sh, float sw, float mul, int post) {
+    const int W8 = W >> 2;                                            // threads per row pair: Wo / 8
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi >= H * W8) return;
+    const int k = gi / W8, j = gi - k * W8;
+    const long nc = blockIdx.y;
+    const float* p = in + nc * (long)H * W;
+    const int Wo = 2 * W;
+    // the two output rows' source rows and weights, exactly as the per-row form computes them
+    int y0[2], y1[2];
+    float ly[2], hy[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        float sy = sh * ((2 * k + r) + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+        y0[r] = (int)sy; y1[r] = y0[r] + (y0[r] < H - 1 ? 1 : 0);
+        ly[r] = sy - y0[r]; hy[r] = 1.f - ly[r];
+    }
+    // rows held: R0 = y0[0], R1 = y1[0], R2 = y1[1]; y0[1] is R0 (k = 0) or R1
+    const int rows[3] = {y0[0], y1[0], y1[1]};
+    float c[3][6];                                                    // columns 4j-1 .. 4j+4, clamped to the row like the narrow form's window
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float* rp = p + (long)rows[r] * W + 4 * j;
+        const f32x4 m = *(const f32x4*)rp;
+        c[r][0] = rp[j > 0 ? -1 : 0];
+        c[r][1] = m[0]; c[r][2] = m[1]; c[r][3] = m[2]; c[r][4] = m[3];
+        c[r][5] = rp[4 * j + 4 < W ? 4 : 3];
+    }
+    const bool second_from_r1 = y0[1] == y1[0];                       // (false only for k = 0 and for H - 1 == y0: then y0[1] == y0[0])
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        float top[6], bot[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            top[i] = r == 0 ? c[0][i] : (second_from_r1 ? c[1][i] : c[0][i]);
+            bot[i] = r == 0 ? c[1][i] : c[2][i];
+        }
+        float* o = out + nc * (long)(2 * H) * Wo + (long)(2 * k + r) * Wo + 8 * j;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {                                 // the narrow form's window of output group g: columns 4j + 2g - 1 .. + 2
+            f32x4 v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float sx = sw * ((8 * j + 4 * g + u) + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+                const int x0 = (int)sx;
+                const float lx = sx - x0, hx = 1.f - lx;
+                constexpr int i0[4] = {0, 1, 1, 2};
+                const int i = 2 * g + i0[u];
+                const float a = top[i], b = top[i + 1], cc = bot[i], d = bot[i + 1];
+                v[u] = resize_fin(hy[r] * (hx * a + lx * b) + ly[r] * (hx * cc + lx * d), mul, post);
+            }
+            *(f32x4*)(o + 4 * g) = v;
+        }
+    }
+}
+
 extern "C" int motif_resize_bilinear(const float* in, float* out, int NC, int H, int W, int Ho, int Wo,
                                      int align_corners, float mul, int post, void* stream) {
     if (!in || !out || NC < 1 || H < 1 || W < 1 || Ho < 1 || Wo < 1 || post < 0 || post > 1) return MOTIF_EINVAL;
@@ -83,7 +145,11 @@ extern "C" int motif_resize_bilinear(const float* in, float* out, int NC, int H,
     if (align_corners) { sh = Ho > 1 ? (float)(H - 1) / (Ho - 1) : 0.f; sw = Wo > 1 ? (float)(W - 1) / (Wo - 1) : 0.f; }
     else { sh = (float)H / Ho; sw = (float)W / Wo; }
     hipStream_t s = (hipStream_t)stream;
-    if (Wo % 4 == 0 && ((uintptr_t)out & 15) == 0) {
+    if (!align_corners && Ho == 2 * H && Wo == 2 * W && H >= 2 && (W & 3) == 0 && (((uintptr_t)out | (uintptr_t)in) & 15) == 0 &&
+        !motif_opt(MOTIF_OPT_RESIZE_NARROW)) {
+        dim3 grid(cdiv((long)H * (W / 4), 256), NC);
+        resize_up2_wide_kernel<<<grid, 256, 0, s>>>(in, out, H, W, sh, sw, mul, post);
+    } else if (Wo % 4 == 0 && ((uintptr_t)out & 15) == 0) {
         dim3 grid(cdiv((long)Ho * (Wo / 4), 256), NC);
         if (!align_corners && Ho == 2 * H && Wo == 2 * W && W >= 2)
             resize_bilinear_kernel<4, true><<<grid, 256, 0, s>>>(in, out, H, W, Ho, Wo, sh, sw, align_corners, mul, post);

@@ -987,6 +987,26 @@ def test_resize_bilinear(shape, align):
     close(ops.resize_bilinear(x.to(dev()), (ho, wo), align, 0.25), ref, 2e-6, 0, "resize")
 
 
+@pytest.mark.parametrize("n, c, h, w", [(8, 64, 45, 80), (2, 3, 9, 16), (1, 1, 2, 4), (1, 2, 7, 12), (3, 5, 90, 160)])
+def test_resize_x2_wide_form_gives_the_bits_of_the_narrow_form_and_matches_torch(n, c, h, w):
+    """x2 upsampling with 8 columns x 2 rows per thread (round 6: 9 loads per 16 outputs instead of 32) against the 4-column form it replaces
+    (option resize_narrow = 1): the same expression of the same operands per output, so the bits must be equal -- first / last rows and
+    columns (clamped windows), the two-row minimum, the scale factor and RAFT's normalisation included; and against torch."""
+    from motif_amd import ops
+    x = rnd(n, c, h, w, seed=11, scale=3.0)
+    xd = x.to(dev())
+    wide = ops.resize_bilinear(xd, (2 * h, 2 * w), False, 0.25)
+    wide_norm = ops.resize_bilinear(xd, (2 * h, 2 * w), False, raft_norm=True)
+    ops.set_option("resize_narrow", 1)
+    try:
+        narrow = ops.resize_bilinear(xd, (2 * h, 2 * w), False, 0.25)
+        narrow_norm = ops.resize_bilinear(xd, (2 * h, 2 * w), False, raft_norm=True)
+    finally:
+        ops.set_option("resize_narrow", 0)
+    assert torch.equal(wide, narrow) and torch.equal(wide_norm, narrow_norm)
+    close(wide, F.interpolate(x, size=(2 * h, 2 * w), mode="bilinear", align_corners=False) * 0.25, 2e-6, 0, "resize x2")
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 360, 640), (2, 96, 90, 160), (1, 5, 37, 53)])
 def test_instance_norm_all_modes_large_planes(shape):
     """The split-plane instance norm (moments in fp64 over slices, 16-byte accesses where the plane allows) against torch, with
