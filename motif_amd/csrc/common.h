@@ -12,10 +12,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // without the library; profiles/r06_pk_fma_beside_mfma.txt):
 //     v_pk_fma_f32 d, a, b, c op_sel:[0,1,0]       with b a VECTOR register pair (the LOW result takes b's HIGH register)
 // came out wrong in its low half, in lanes 48..63 of the wave only, while an fp16 / bf16 MFMA kernel ran beside it on another stream -- never
-// alone, never beside fp32 MFMAs, never in the plain form, the op_sel_hi forms or with b a SCALAR register pair.  hipcc picks the form by itself
-// (SLP-paired scalar FMAs against a broadcast operand), so a kernel in which it picked an op_sel form on a vector-register source is compiled
-// without packed fp32 altogether; tests/test_isa_hygiene.py fails on any kernel of the BUILT library that holds one (every op_sel bit on a
-// vector-register source of a packed fp32 instruction, not only the one form seen to fail).  The attribute means nothing to the host pass.
+// alone, never beside fp32 MFMAs.  The form is necessary for the failure, not sufficient (other code layouts of the same instruction ran
+// clean; what the failing ones share is not known), so it is fenced by form and widely: hipcc picks it by itself (SLP-paired scalar FMAs
+// against a broadcast operand), a kernel in which it picked ANY op_sel bit on a vector-register source of a packed fp32 instruction is
+// compiled without packed fp32 altogether, and tests/test_isa_hygiene.py fails on any kernel of the BUILT library that holds one.  (op_sel on a
+// SCALAR register pair -- conv_direct.hip's weights -- is a per-instruction selection and stays.)  The attribute means nothing to the host pass.
 #if !defined(MOTIF_SCALAR_F32) && defined(__HIP_DEVICE_COMPILE__)
 #define MOTIF_SCALAR_F32 __attribute__((target("no-packed-fp32-ops")))
 #elif !defined(MOTIF_SCALAR_F32)

@@ -12,10 +12,15 @@
 //              registers and 2 workgroups per CU: room for victim waves on every SIMD;
 // launched on two streams, `rounds` times; then the victim alone.
 //
-// Result on MI355X (profiles/r06_pk_fma_beside_mfma.txt; the same on every box it ran on): ONLY `v_pk_fma_f32 d, a, b, d op_sel:[0,1,0]` with b in
-// vector registers differs -- low half, lanes 48..63, beside the bf16 and the f16 kernel, never beside the fp32 one or alone.  Its neighbours
-// (op_sel:[1,0,0], [1,1,0], the op_sel_hi forms, b in scalar registers, v_pk_mul / v_pk_add / v_pk_mov with op_sel) came out clean in every run.
-// tests/test_isa_hygiene.py keeps every op_sel bit on a vector-register source of a packed fp32 instruction out of the built library.
+// Result on MI355X (profiles/r06_pk_fma_beside_mfma.txt; reproduced on every box, 8 runs): ONLY `v_pk_fma_f32 d, a, b, d op_sel:[0,1,0]` with b
+// in vector registers differs -- low half, lanes 48..63, beside the bf16 and the f16 kernel, never beside the fp32 one or alone.
+// CAUTION when reading the zeros: the failing form itself ran CLEAN in other layouts of this very program (an extra kernel argument -- other
+// registers for a, b, p --, fixed registers in six bank combinations, padding in or before the loop at every 4-byte alignment: probes of
+// round 6 that are not kept, DESIGN_LOG.md), so a form that is clean in the ONE layout it has here is weak evidence, and this
+// file must be rebuilt and re-checked after any edit: it is kept in the state that reproduces.  The form is necessary (both failing
+// programs hold it, the fused kernel's one configuration without it never differed), not sufficient.
+// tests/test_isa_hygiene.py keeps every op_sel bit on a vector-register source of a packed fp32 instruction out of the built library;
+// tools/beside_stress.py checks every operator of the path beside a clip in flight, whatever the cause.
 //
 //   hipcc --offload-arch=gfx950 -O2 -o /tmp/pkfma tools/pk_fma_beside_mfma.hip && /tmp/pkfma [rounds]
 #include <hip/hip_runtime.h>
