@@ -829,7 +829,9 @@ extern "C" int motif_dcn_v2_fused_fwd_multi(int P, const float* const* input, co
     // round-1 tree (d21b251, 2400 concurrent launches, tools/dbg/race_dcn4.py) nor with this kernel; what changed here: the
     // weights go global -> LDS directly, which removed the kernel's scratch use (3 / 11 spilled VGPRs before), and the LDS-DMA
     // is drained by an explicit vmcnt(0) before each barrier.  tests/test_kernels_gpu.py::test_dcn_concurrent_with_conv_split
-    // and the model-level run-to-run test keep watching it.  MOTIF_DCN_WAVES=8 / 4 forces a form.
+    // and the model-level run-to-run test keep watching it.  MOTIF_DCN_WAVES=8 / 4 forces a form.  (Round 6 met what that report may have
+    // been: a packed fp32 instruction form that comes out wrong in lanes 48..63 beside fp16 / bf16 MFMA kernels of another stream
+    // (common.h: MOTIF_SCALAR_F32) -- the built library is scanned for it, and no kernel of this file holds it.)
     // window form (dcn_win_kernel): bf16x3 engine, rows of whole 16-byte units, 32-bit offsets over 4 planes; one 8-wave block
     // per CU (147 KB of LDS)
     const bool split = mma == 6 || mma == 7;
