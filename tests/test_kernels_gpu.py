@@ -987,6 +987,32 @@ def test_resize_bilinear(shape, align):
     close(ops.resize_bilinear(x.to(dev()), (ho, wo), align, 0.25), ref, 2e-6, 0, "resize")
 
 
+@pytest.mark.parametrize("mode", ["f16x2", "fp32"])
+@pytest.mark.parametrize("h, w", [(45, 80), (90, 160)])
+def test_an_image_has_the_same_bits_alone_and_in_a_batch_for_every_operator_of_the_alignment(mode, h, w, keep_mma):
+    """Batch invariance in the default and the fp32 arithmetic: the two-source 3x3 layer, the plain 3x3 layer, the offset layer
+    + deformable convolution and the x2 resize of the PCD alignment (Ours.py:107-172) on a batch of three images against each image alone --
+    what the bit-identity of row-tiled and per-timestamp multi-GPU rendering rests on.  (`bf16x3` picks between two 3x3 kernels by the
+    launch's tile count and is NOT batch-invariant on these map sizes: documented, not tested here.)"""
+    from motif_amd import ops
+    from motif_amd.models.modules.Ours import PCD_Align, convm, dcnm, up2m, LRELU
+    from motif_amd.utils.synth_weights import fill_state_dict
+    ops.set_mma(mode)
+    m = fill_state_dict(PCD_Align(64, 8, use_time=False)).to(dev()).eval()
+    a, b = rnd(3, 64, h, w, seed=1).to(dev()), rnd(3, 64, h, w, seed=2).to(dev())
+    layers = {
+        "3x3 128->64, two sources": lambda x, y: convm([m.L1_offset_conv1_1, m.L1_offset_conv1_2], [x, y], [y, x], act=LRELU),
+        "3x3 64->64": lambda x, y: convm([m.L1_offset_conv3_1, m.L1_offset_conv3_2], [x, y], act=LRELU),
+        "offset layer 64->216 + deformable convolution": lambda x, y: dcnm([m.L1_dcnpack_1, m.L1_dcnpack_2], [x, y], [y, x], LRELU),
+        "x2 resize": lambda x, y: up2m(torch.stack([x, y]), 2.0),
+    }
+    with torch.no_grad():
+        for name, fn in layers.items():
+            full = fn(a, b)
+            for i in range(3):
+                assert torch.equal(full[:, i:i + 1], fn(a[i:i + 1], b[i:i + 1])), "%s: image %d differs from itself alone (%s)" % (name, i, mode)
+
+
 @pytest.mark.parametrize("n, c, h, w", [(8, 64, 45, 80), (2, 3, 9, 16), (1, 1, 2, 4), (1, 2, 7, 12), (3, 5, 90, 160)])
 def test_resize_x2_wide_form_gives_the_bits_of_the_narrow_form_and_matches_torch(n, c, h, w):
     """x2 upsampling with 8 columns x 2 rows per thread (round 6: 9 loads per 16 outputs instead of 32) against the 4-column form it replaces
