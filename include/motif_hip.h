@@ -41,7 +41,7 @@ int motif_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
  * the values change only through motif_set_option.  Every option defaults to 0 = "let the library choose"; none of them
  * changes a result beyond kernel-selection rounding.  Names: conv_dbg, conv_ck, conv_nospec, conv_engine (1 = always the
  * round-2 two-block 3x3 kernel, 2 / 3 / 4 = the round-3 kernel with 12- / 8-row tiles (one workgroup per CU) / 6-row tiles (two per CU) wherever it applies, 5 = the round-4 Winograd F(2,3) kernel (conv_wino.hip) wherever it applies, 6 = never that one (nor conv_pw.hip / conv_ig16.hip: the fp32 engine for their layers), 7 = conv_ig16.hip (round 6: stride 2, 7x7, dilated, narrow / wide layers on the fp16 matrix cores) wherever a shape FITS it instead of only where it pays, 0 = the library's choice: the Winograd kernel for every eligible 3x3 layer with a plain epilogue, else by tile count), lds_pad, corr81 (1 tiled / 2 small / 3 tiled with nine waves per block),
- * dcn_nowin, dcn_waves (4 / 8), dcn_front_pad, dcn_back_pad, siren_stagger, conv_novec (1 = 4-byte staging in the fp32 engine), conv_nodirect (1 = the narrow layers on large maps stay on the MFMA engine instead of conv_direct.hip), conv_wino_tr (1 = the Winograd kernel's experimental form with transposed accumulators and a register-only epilogue wherever the activation is uniform over the couts: bit-identical, measured no faster; 0 = row-major accumulators, LDS-transposed epilogue), conv_wino_rpre (1 = the Winograd kernel requests all residual quads in the epilogue, as in round 4; 0 = the first two passes' quads under the tile's last chunk), conv_chain_wgs (workgroups of a motif_conv2d_chain_fwd launch; 0 = one per CU), resize_narrow (1 = motif_resize_bilinear keeps the 4-column form for x2 upsampling; 0 = 8 columns x 2 rows per thread, bit-identical).  Returns MOTIF_EINVAL for an unknown name.
+ * dcn_nowin, dcn_waves (4 / 8), dcn_front_pad, dcn_back_pad, siren_stagger, conv_novec (1 = 4-byte staging in the fp32 engine), conv_nodirect (1 = the narrow layers on large maps stay on the MFMA engine instead of conv_direct.hip), conv_wino_tr (1 = the Winograd kernel's experimental form with transposed accumulators and a register-only epilogue wherever the activation is uniform over the couts: bit-identical, measured no faster; 0 = row-major accumulators, LDS-transposed epilogue), conv_wino_rpre (1 = the Winograd kernel requests all residual quads in the epilogue, as in round 4; 0 = the first two passes' quads under the tile's last chunk), conv_chain_wgs (workgroups of a motif_conv2d_chain_fwd launch; 0 = one per CU), resize_narrow (1 = motif_resize_bilinear keeps the 4-column form for x2 upsampling; 0 = 8 columns x 2 rows per thread, bit-identical), conv_direct_quads (1 = the deep direct form keeps quad-indexed workgroups with loaded edge pixels on small maps; 0 = whole rows per workgroup and shuffled edge pixels, bit-identical).  Returns MOTIF_EINVAL for an unknown name.
  * Not thread-safe against concurrent launches -- a test / tuning aid, not part of the data path. */
 int motif_set_option(const char* name, int value);
 int motif_get_option(const char* name, int* value);

@@ -22,7 +22,7 @@ extern "C" int motif_device_info(int* cu_count, int* lds_bytes, char* arch, int 
 #include <ctype.h>
 namespace {
 const char* const kOptNames[MOTIF_OPT_COUNT] = {"conv_dbg", "conv_ck", "conv_nospec", "conv_engine", "lds_pad", "corr81",
-                                                "dcn_nowin", "dcn_waves", "dcn_front_pad", "dcn_back_pad", "siren_stagger", "conv_novec", "conv_nodirect", "conv_wino_tr", "conv_wino_rpre", "conv_chain_wgs", "resize_narrow"};
+                                                "dcn_nowin", "dcn_waves", "dcn_front_pad", "dcn_back_pad", "siren_stagger", "conv_novec", "conv_nodirect", "conv_wino_tr", "conv_wino_rpre", "conv_chain_wgs", "resize_narrow", "conv_direct_quads"};
 struct OptTable {
     int v[MOTIF_OPT_COUNT];
     OptTable() {

@@ -42,7 +42,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 // Tuning / test switches (include/motif_hip.h: motif_set_option).  Read from the environment once, never per launch.
 enum MotifOpt { MOTIF_OPT_CONV_DBG, MOTIF_OPT_CONV_CK, MOTIF_OPT_CONV_NOSPEC, MOTIF_OPT_CONV_ENGINE, MOTIF_OPT_LDS_PAD,
                 MOTIF_OPT_CORR81, MOTIF_OPT_DCN_NOWIN, MOTIF_OPT_DCN_WAVES, MOTIF_OPT_DCN_FRONT_PAD, MOTIF_OPT_DCN_BACK_PAD,
-                MOTIF_OPT_SIREN_STAGGER, MOTIF_OPT_CONV_NOVEC, MOTIF_OPT_CONV_NODIRECT, MOTIF_OPT_CONV_WINO_TR, MOTIF_OPT_CONV_WINO_RPRE, MOTIF_OPT_CONV_CHAIN_WGS, MOTIF_OPT_RESIZE_NARROW, MOTIF_OPT_COUNT };
+                MOTIF_OPT_SIREN_STAGGER, MOTIF_OPT_CONV_NOVEC, MOTIF_OPT_CONV_NODIRECT, MOTIF_OPT_CONV_WINO_TR, MOTIF_OPT_CONV_WINO_RPRE, MOTIF_OPT_CONV_CHAIN_WGS, MOTIF_OPT_RESIZE_NARROW, MOTIF_OPT_CONV_DIRECT_QUADS, MOTIF_OPT_COUNT };
 int motif_opt(int id);                                   // api.hip
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -153,16 +153,31 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
 // ~2 us of L2 latency per channel pair: every 529 .. 661 -> 2 flow head of PWC-Net took 80 us whatever the map size, RAFT's 128 -> 2 head
 // 26 us.  The workgroup's dynamic LDS is NS regions of `rs` 16-byte units: a wave's weights first, its partial sums afterwards (the
 // same wave, in program order: no barrier between the two uses).
-template <int NCO, int K, int NS>
+// ROWS (round 6, K == 3): a workgroup owns WHOLE rows (64 / W4 of them; W <= 256), so the pixel left of a quad and the pixel right of it are held
+// by the neighbouring lanes and come by a lane shuffle instead of two more loads per (channel, row): 12 registers per channel in flight instead
+// of 18, and SIX channels' loads in flight where the 128-register cap of the 16-slice form allowed three -- PWC-Net's 529 .. 661 -> 2 flow heads
+// (42 channels per slice: 14 load latencies, 75 us on every level) walk 7.  Same multiply-adds in the same order: bit-identical to the quad
+// form (option conv_direct_quads = 1 keeps that one; tests/test_kernels_gpu.py compares them).
+template <int NCO, int K, int NS, bool ROWS = false>
 __global__ __launch_bounds__(64 * NS) void conv_direct_deep_kernel(ConvArgs a, int rs) {
     extern __shared__ __attribute__((aligned(16))) f32x4 dsm[];        // [NS][rs]
     const int pz = blockIdx.z / a.N, n = blockIdx.z - pz * a.N;
     const int W4 = a.W >> 2, nquads = W4 * a.H;
     const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q = blockIdx.x * 64 + lane;
-    const bool live = q < nquads;
-    const int qc = live ? q : nquads - 1;
-    const int y = qc / W4, x = (qc - y * W4) * 4;
+    bool live;
+    int y, x;
+    if constexpr (ROWS) {
+        const int rpb = 64 / W4;                                     // rows per workgroup
+        const int r = lane / W4, xq = lane - r * W4;
+        const int yy = blockIdx.x * rpb + r;
+        live = r < rpb && yy < a.H;
+        y = min(yy, a.H - 1); x = xq * 4;
+    } else {
+        const int q = blockIdx.x * 64 + lane;
+        live = q < nquads;
+        const int qc = live ? q : nquads - 1;
+        y = qc / W4; x = (qc - y * W4) * 4;
+    }
     const long HW = (long)a.H * a.W;
     const float* in0n = a.in0[pz] + (long)n * a.in0_bs[pz];
     const float* in1n = a.in1[pz] ? a.in1[pz] + (long)n * a.in1_bs[pz] : nullptr;
@@ -199,7 +214,7 @@ __global__ __launch_bounds__(64 * NS) void conv_direct_deep_kernel(ConvArgs a, i
     for (int o = 0; o < NCO; ++o) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto plane_of = [&](int c) { return c < a.C0 ? in0n + (long)c * HW : in1n + (long)(c - a.C0) * HW; };
     auto wrow_of = [&](int c) { return wp + (long)(((c >> 1) * T) * 2 + (c & 1)) * 32; };
-    constexpr int CG = K == 1 ? 8 : (NS >= 16 ? 3 : 2);    // channels whose loads are in flight together (the 16-slice form serves small maps: latency; four spill at its 128-register cap)
+    constexpr int CG = K == 1 ? 8 : ROWS ? 6 : (NS >= 16 ? 3 : 2);    // channels whose loads are in flight together (the 16-slice form serves small maps: latency; four spill at its 128-register cap)
     auto group = [&](int c0, auto n_tag) {
         constexpr int NG = decltype(n_tag)::value;
         if constexpr (K == 1) {
@@ -224,12 +239,23 @@ __global__ __launch_bounds__(64 * NS) void conv_direct_deep_kernel(ConvArgs a, i
                     const bool rowok = yy >= 0 && yy < a.H;
                     const float* rp = plane_of(c0 + i) + (long)(rowok ? yy : y) * a.W + x;
                     m[i][dy] = *(const f32x4*)rp;
-                    l[i][dy] = rp[x > 0 ? -1 : 0];
-                    rr[i][dy] = rp[x + 4 < a.W ? 4 : 3];
+                    if constexpr (!ROWS) {
+                        l[i][dy] = rp[x > 0 ? -1 : 0];
+                        rr[i][dy] = rp[x + 4 < a.W ? 4 : 3];
+                    }
                 }
             // every load of the group is REQUESTED before the first multiply: left alone, the scheduler sinks each channel's loads next to
             // their uses to save registers and the slice becomes one load latency per channel (72 us for 42 channels, round 5 ISA)
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ROWS) {                       // the neighbours' edge pixels (lanes of other rows are never used: x > 0 / x + 4 < W below)
+#pragma unroll
+                for (int i = 0; i < NG; ++i)
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        l[i][dy] = __shfl_up(m[i][dy][3], 1);
+                        rr[i][dy] = __shfl_down(m[i][dy][0], 1);
+                    }
+            }
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
                 const float* wrow = wl + (c0 + i - cbeg) * (T * NCO);
@@ -349,7 +375,16 @@ int motif_conv_direct_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStre
         if (lds_ > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_direct_deep_kernel<NCOV, KV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
         conv_direct_deep_kernel<NCOV, KV, NSV><<<grid, 64 * NSV, lds_, s>>>(a, rs_);                                        \
     } while (0)
-        if (tiny) MOTIF_LAUNCH_DEEP(2, 3, 16);
+        // whole rows per workgroup where the row fits a wave (per-image quantities only, like `tiny`)
+        const bool rows = tiny && (d->W >> 2) <= 64 && !motif_opt(MOTIF_OPT_CONV_DIRECT_QUADS);
+        if (rows) {
+            const int rpb = 64 / (d->W >> 2);
+            grid.x = (unsigned)((d->H + rpb - 1) / rpb);
+            const int rs_ = region(16, 2);
+            const size_t lds_ = (size_t)16 * rs_ * 16;
+            if (lds_ > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_direct_deep_kernel<2, 3, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);
+            conv_direct_deep_kernel<2, 3, 16, true><<<grid, 64 * 16, lds_, s>>>(a, rs_);
+        } else if (tiny) MOTIF_LAUNCH_DEEP(2, 3, 16);
         else if (d->KH == 1) MOTIF_LAUNCH_DEEP(4, 1, 8);
         else if (d->Cout <= 2) MOTIF_LAUNCH_DEEP(2, 3, 8);
         else MOTIF_LAUNCH_DEEP(4, 3, 8);

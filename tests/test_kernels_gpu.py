@@ -581,6 +581,31 @@ def test_conv_chain_abandoned_or_mis_tabled_launch_reports_and_touches_nothing(k
         ops.CONV_CHAIN, ops.CONV_CHAIN_MIN_TILES = saved
 
 
+@pytest.mark.parametrize("cin, cout, h, w, n", [(529, 2, 12, 20, 1), (661, 2, 24, 40, 2), (597, 2, 48, 80, 2), (565, 2, 96, 160, 1), (300, 1, 20, 24, 1), (277, 2, 7, 256, 1)])
+def test_conv_direct_deep_form_with_whole_rows_per_workgroup_gives_the_bits_of_the_quad_form(cin, cout, h, w, n):
+    """The 16-slice deep direct form on small maps (PWC-Net's flow heads), round 6: a workgroup owns whole rows and takes the pixels left and
+    right of a quad from the neighbouring lanes (six channels' loads in flight instead of three) -- against the quad-indexed form with loaded
+    edge pixels (option conv_direct_quads = 1): the same multiply-adds in the same order, so equal bits; rows of 5 .. 64 quads, a last
+    workgroup with fewer rows, one and two couts; and against fp64."""
+    from motif_amd import ops
+    from motif_amd.models.modules.layers import Conv2d
+    m = Conv2d(cin, cout, 3, 1, 1)
+    with torch.no_grad():
+        m.weight.copy_(rnd(*m.weight.shape, seed=1, scale=1.0 / math.sqrt(cin * 9)))
+        m.bias.copy_(rnd(cout, seed=2, scale=0.1))
+    x = rnd(n, cin, h, w, seed=3)
+    y = F.conv2d(x.double(), m.weight.double(), m.bias.double(), 1, 1)
+    m, xd = m.to(dev()), x.to(dev())
+    rows = m(xd)
+    ops.set_option("conv_direct_quads", 1)
+    try:
+        quads = m(xd)
+    finally:
+        ops.set_option("conv_direct_quads", 0)
+    assert torch.equal(rows, quads)
+    assert float((rows.double().cpu() - y).abs().max()) < 2e-6 * float(y.abs().max()) * max(1.0, math.sqrt(cin * 9 / 1800.0))
+
+
 def test_conv_direct_deep_form_gives_an_image_the_same_bits_alone_and_in_a_batch():
     """the 16- / 8-slice choice of the deep direct form (the number of terms of its fixed-order partial-sum reduction) was made from
     N x workgroups-per-image, so a PWC-Net flow head gave a pair other bits in a batch of 9 than alone.  It is decided per image now."""
