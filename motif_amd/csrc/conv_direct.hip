@@ -376,19 +376,24 @@ int motif_conv_direct_launch(const MotifConvDesc* d, ConvArgs& a, int P, hipStre
         conv_direct_deep_kernel<NCOV, KV, NSV><<<grid, 64 * NSV, lds_, s>>>(a, rs_);                                        \
     } while (0)
         // whole rows per workgroup where the row fits a wave (per-image quantities only, like `tiny`)
-        const bool rows = tiny && (d->W >> 2) <= 64 && !motif_opt(MOTIF_OPT_CONV_DIRECT_QUADS);
-        if (rows) {
-            const int rpb = 64 / (d->W >> 2);
-            grid.x = (unsigned)((d->H + rpb - 1) / rpb);
-            const int rs_ = region(16, 2);
-            const size_t lds_ = (size_t)16 * rs_ * 16;
-            if (lds_ > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_direct_deep_kernel<2, 3, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);
-            conv_direct_deep_kernel<2, 3, 16, true><<<grid, 64 * 16, lds_, s>>>(a, rs_);
-        } else if (tiny) MOTIF_LAUNCH_DEEP(2, 3, 16);
+        const bool rows = d->KH == 3 && d->Cout <= 2 && (d->W >> 2) <= 64 && !motif_opt(MOTIF_OPT_CONV_DIRECT_QUADS);
+#define MOTIF_LAUNCH_DEEP_ROWS(NSV)                                                                                        \
+    do {                                                                                                                     \
+        const int rpb = 64 / (d->W >> 2);                                                                                    \
+        grid.x = (unsigned)((d->H + rpb - 1) / rpb);                                                                         \
+        const int rs_ = region(NSV, 2);                                                                                      \
+        const size_t lds_ = (size_t)NSV * rs_ * 16;                                                                          \
+        if (lds_ > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_direct_deep_kernel<2, 3, NSV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+        conv_direct_deep_kernel<2, 3, NSV, true><<<grid, 64 * NSV, lds_, s>>>(a, rs_);                                      \
+    } while (0)
+        if (rows && tiny) MOTIF_LAUNCH_DEEP_ROWS(16);
+        else if (rows) MOTIF_LAUNCH_DEEP_ROWS(8);                     // (RAFT's 128 -> 2 flow head: 8 slices of 16 channels, two groups instead of eight)
+        else if (tiny) MOTIF_LAUNCH_DEEP(2, 3, 16);
         else if (d->KH == 1) MOTIF_LAUNCH_DEEP(4, 1, 8);
         else if (d->Cout <= 2) MOTIF_LAUNCH_DEEP(2, 3, 8);
         else MOTIF_LAUNCH_DEEP(4, 3, 8);
 #undef MOTIF_LAUNCH_DEEP
+#undef MOTIF_LAUNCH_DEEP_ROWS
         MOTIF_LAUNCH_CHECK();
         return MOTIF_OK;
     }

@@ -581,12 +581,13 @@ def test_conv_chain_abandoned_or_mis_tabled_launch_reports_and_touches_nothing(k
         ops.CONV_CHAIN, ops.CONV_CHAIN_MIN_TILES = saved
 
 
-@pytest.mark.parametrize("cin, cout, h, w, n", [(529, 2, 12, 20, 1), (661, 2, 24, 40, 2), (597, 2, 48, 80, 2), (565, 2, 96, 160, 1), (300, 1, 20, 24, 1), (277, 2, 7, 256, 1)])
+@pytest.mark.parametrize("cin, cout, h, w, n", [(529, 2, 12, 20, 1), (661, 2, 24, 40, 2), (597, 2, 48, 80, 2), (565, 2, 96, 160, 1), (300, 1, 20, 24, 1), (277, 2, 7, 256, 1),
+                                                (128, 2, 90, 160, 2), (96, 1, 130, 132, 1)])
 def test_conv_direct_deep_form_with_whole_rows_per_workgroup_gives_the_bits_of_the_quad_form(cin, cout, h, w, n):
     """The 16-slice deep direct form on small maps (PWC-Net's flow heads), round 6: a workgroup owns whole rows and takes the pixels left and
     right of a quad from the neighbouring lanes (six channels' loads in flight instead of three) -- against the quad-indexed form with loaded
     edge pixels (option conv_direct_quads = 1): the same multiply-adds in the same order, so equal bits; rows of 5 .. 64 quads, a last
-    workgroup with fewer rows, one and two couts; and against fp64."""
+    workgroup with fewer rows, one and two couts, the 8-slice form too (RAFT's 128 -> 2 flow head); and against fp64."""
     from motif_amd import ops
     from motif_amd.models.modules.layers import Conv2d
     m = Conv2d(cin, cout, 3, 1, 1)
