@@ -1198,10 +1198,13 @@ def test_pool_transpose_gates_axpby():
         assert torch.equal(ops.flow_roundtrip(pred.to(dev()), 20.0, ratio).cpu(), want), "flow round trip must keep the four roundings"
 
 
-def test_deconv4x4s2():
+@pytest.mark.parametrize("n, cin, h, w", [(2, 37, 6, 10), (1, 597, 24, 40), (2, 70, 9, 130), (1, 64, 5, 7)], ids=["plain", "sliced_597", "sliced_ragged_70", "sliced_64"])
+def test_deconv4x4s2(n, cin, h, w):
+    """ConvTranspose2d(k 4, s 2, p 1) of PWC-Net's moduleUpflow / moduleUpfeat (PWCNet.py:117-125); >= 64 input channels take the sliced form
+    (8 channel slices per workgroup, eight channels' loads in flight per step and a remainder loop: 597 = 8 x 75 - 3, 70 = 8 x 9 - 2)."""
     from motif_amd import ops
-    x, w, b = rnd(2, 37, 6, 10, seed=1), rnd(37, 2, 4, 4, seed=2, scale=0.1), rnd(2, seed=3)
-    close(ops.deconv4x4s2(x.to(dev()), w.to(dev()), b.to(dev())), F.conv_transpose2d(x, w, b, 2, 1), 1e-5, 1e-5)
+    x, wt, b = rnd(n, cin, h, w, seed=1), rnd(cin, 2, 4, 4, seed=2, scale=0.1), rnd(2, seed=3)
+    close(ops.deconv4x4s2(x.to(dev()), wt.to(dev()), b.to(dev())), F.conv_transpose2d(x, wt, b, 2, 1), 2e-5, 1e-5)
 
 
 # ------------------------------------------------------------------------------------------- correlations
